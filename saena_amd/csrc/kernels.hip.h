@@ -1,0 +1,344 @@
+// kernels.hip.h -- hand-written gfx950 (CDNA4, wave64) kernels of the Saena V-cycle hot path.
+//
+// Everything here is HBM-bandwidth bound integer/fp64 streaming work; there is
+// no dense contraction and therefore no MFMA.  What matters on MI355X:
+//   * val/col are read with 16-byte-per-lane coalesced loads (1 KiB per wave
+//     instruction), never per-row strided;
+//   * products are staged in LDS and reduced per row by G lanes with DPP/
+//     bpermute shuffles, so 7-nnz Poisson rows do not idle 57 of 64 lanes;
+//   * smoother / residual / correction arithmetic is fused into the SpMV
+//     epilogue: rhs, inv_diag, u and d are touched exactly once per sweep;
+//   * row blocks are dealt to XCDs in contiguous chunks so neighbouring blocks
+//     (which share x lines) hit the same 4 MiB L2.
+//
+// Reference loops restated (file:line in paralab/Saena):
+//   local CSR loop          src/saena_matrix_matvec.cpp:68-80
+//   remote CSC scatter      src/saena_matrix_matvec.cpp:93-109  (here: remote CSR, no atomics)
+//   halo pack               src/saena_matrix_matvec.cpp:25-26, :464 (float)
+//   jacobi update           src/saena_matrix.cpp:1061-1070
+//   chebyshev update        src/saena_matrix.cpp:1099-1130, include/saena_matrix.tpp:35-43
+//   residual                include/saena_matrix.tpp:16-23
+//   u -= P e                src/saena_object_solve.cpp:1360-1361
+//   dotProduct              include/aux_functions.h:116-123
+//   solve_coarsest_CG       src/saena_object_solve.cpp:14-114
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sk {
+
+constexpr int BLOCK   = 256;    // 4 waves
+constexpr int CAP     = 2048;   // products staged per row block (16 KiB of LDS)
+constexpr int LDS_N   = CAP + 8;
+constexpr int MAXROWS = 256;    // rows per row block (one pass at 1 lane/row)
+constexpr int NXCD    = 8;
+
+enum Epi : int {
+    EPI_SPMV = 0,      // y = s
+    EPI_RESIDUAL,      // y = s - rhs
+    EPI_JACOBI,        // t = s - rhs; t *= inv_diag*omega; y = u - t
+    EPI_CHEBY0,        // d = (c*inv_diag)*(rhs - s);              y = u + d
+    EPI_CHEBYK,        // d = d1*d + (c*inv_diag)*(rhs - s);       y = u + d
+    EPI_SUB,           // y = y - s            (u -= P e)
+    EPI_COUNT
+};
+
+struct SpmvArgs {
+    const int    *row_ptr;   // [M+1]
+    const int    *col;       // local column ids (already rebased), padded by >= 8 zeros
+    const double *val;       // padded by >= 8 zeros
+    const int    *blk_row;   // [nblk+1] row-block boundaries
+    const double *x;         // input vector (local slice, or the halo buffer for the remote part)
+    double       *y;         // output
+    const double *rhs;
+    const double *inv_diag;
+    const double *u;         // smoother input iterate (== x for the local part)
+    double       *d;         // chebyshev direction
+    double        c0;        // omega | c
+    double        c1;        // d1
+    int           nblk;
+    const int    *rows;      // remote part: compact list of rows that own remote entries (else nullptr)
+};
+
+// Remote-part epilogues: the local kernel already applied the epilogue to
+// s_local; every epilogue is affine in s, so the halo contribution is a
+// correction on the rows that have remote entries.
+template <int EPI>
+__device__ __forceinline__ void epilogue_remote(const SpmvArgs &a, int r, double s) {
+    if constexpr (EPI == EPI_SPMV || EPI == EPI_RESIDUAL) {
+        a.y[r] += s;
+    } else if constexpr (EPI == EPI_JACOBI) {
+        a.y[r] -= (a.inv_diag[r] * a.c0) * s;
+    } else if constexpr (EPI == EPI_CHEBY0 || EPI == EPI_CHEBYK) {
+        const double t = (a.c0 * a.inv_diag[r]) * s;
+        a.d[r] -= t;
+        a.y[r] -= t;
+    } else if constexpr (EPI == EPI_SUB) {
+        a.y[r] -= s;
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue(const SpmvArgs &a, int r, double s) {
+    if constexpr (EPI == EPI_SPMV) {
+        a.y[r] = s;
+    } else if constexpr (EPI == EPI_RESIDUAL) {
+        a.y[r] = s - a.rhs[r];
+    } else if constexpr (EPI == EPI_JACOBI) {
+        double t = s - a.rhs[r];
+        t *= a.inv_diag[r] * a.c0;
+        a.y[r] = a.u[r] - t;
+    } else if constexpr (EPI == EPI_CHEBY0) {
+        const double dd = (a.c0 * a.inv_diag[r]) * (a.rhs[r] - s);
+        a.d[r] = dd;
+        a.y[r] = a.u[r] + dd;
+    } else if constexpr (EPI == EPI_CHEBYK) {
+        const double res = (a.c0 * a.inv_diag[r]) * (a.rhs[r] - s);
+        const double dd  = (a.c1 * a.d[r]) + res;
+        a.d[r] = dd;
+        a.y[r] = a.u[r] + dd;
+    } else if constexpr (EPI == EPI_SUB) {
+        a.y[r] = a.y[r] - s;
+    }
+}
+
+// contiguous chunk of the grid per XCD (blocks b, b+8, ... share an XCD)
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int per = n / NXCD, rem = n % NXCD;
+    const int x = b % NXCD, k = b / NXCD;
+    // XCD x owns [x*per + min(x,rem), ...) ; blocks beyond the even part fall through unchanged
+    const int start = x * per + (x < rem ? x : rem);
+    const int len   = per + (x < rem ? 1 : 0);
+    return k < len ? start + k : b;
+}
+
+// sum of v over the G lanes of a row group (G power of two <= 64)
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// K1: row-block CSR SpMV with fused epilogue.
+//   phase 1: the block streams its nnz range [p0,p1) with 16-B loads, gathers
+//            x and writes val*x to LDS (one rounding, like the CPU's mul);
+//   phase 2: G lanes per row add the row's products in column order (G = 1
+//            reproduces the reference's sequential sum bit for bit) and the
+//            group leader applies the epilogue.
+// A row block with a single row longer than CAP takes the long-row path.
+template <int EPI, int G>
+__global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
+    __shared__ __attribute__((aligned(16))) double lds[LDS_N];
+    const int tid = threadIdx.x;
+    const int b   = xcd_remap(blockIdx.x, a.nblk);
+    const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
+    const int p0 = a.row_ptr[r0], p1 = a.row_ptr[r1];
+
+    if (r1 - r0 == 1 && p1 - p0 > CAP) {              // ---- one long row
+        double s = 0.0;
+        for (int k = p0 + tid; k < p1; k += BLOCK) s += a.val[k] * a.x[a.col[k]];
+        s = group_sum<64>(s);
+        if ((tid & 63) == 0) lds[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double t = lds[0];
+#pragma unroll
+            for (int w = 1; w < BLOCK / 64; ++w) t += lds[w];
+            const int r = a.rows ? a.rows[r0] : r0;
+            if (a.rows) epilogue_remote<EPI>(a, r, t); else epilogue<EPI>(a, r, t);
+        }
+        return;
+    }
+
+    // ---- phase 1: coalesced 16-B loads of val/col, gather x, products to LDS
+    const int a0 = p0 & ~3;
+    const int nq = (p1 - a0 + 3) >> 2;                // quads of 4 nnz
+    constexpr int ITER = (LDS_N / 4 + BLOCK - 1) / BLOCK;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int q = tid + it * BLOCK;
+        if (q < nq) {
+            const int idx = a0 + 4 * q;
+            const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
+            const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
+            const int4    c   = *reinterpret_cast<const int4 *>(a.col + idx);
+            double2 o01, o23;
+            o01.x = v01.x * a.x[c.x];
+            o01.y = v01.y * a.x[c.y];
+            o23.x = v23.x * a.x[c.z];
+            o23.y = v23.y * a.x[c.w];
+            *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
+            *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: G lanes per row
+    constexpr int ROWS_PER_PASS = BLOCK / G;
+    const int g = tid / G, l = tid % G;
+    for (int r = r0 + g; r < r1; r += ROWS_PER_PASS) {
+        const int s = a.row_ptr[r] - a0, e = a.row_ptr[r + 1] - a0;
+        double sum = 0.0;
+        for (int k = s + l; k < e; k += G) sum += lds[k];
+        sum = group_sum<G>(sum);
+        if (l == 0) {
+            if (a.rows) epilogue_remote<EPI>(a, a.rows[r], sum); else epilogue<EPI>(a, r, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: halo pack, vSend[i] = v[vIndex[i]] (optionally rounded through float, the
+// reference's matvec_sparse_float halo)
+__global__ __launch_bounds__(BLOCK) void k_pack(const double *__restrict__ v, const int *__restrict__ vIndex,
+                                                double *__restrict__ send, int n, int as_float) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
+        double t = v[vIndex[i]];
+        if (as_float) t = (double)(float)t;
+        send[i] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K10: streaming vector kernels (16 B per lane, grid-stride)
+__global__ __launch_bounds__(BLOCK) void k_fill(double *__restrict__ y, double a, size_t n) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    const size_t n2 = n >> 1;
+    double2 v; v.x = a; v.y = a;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n2; i += stride) reinterpret_cast<double2 *>(y)[i] = v;
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = a;
+}
+
+// y = a*x + b*y   (b == 0 never reads y)
+__global__ __launch_bounds__(BLOCK) void k_axpby(double a, const double *__restrict__ x, double b, double *__restrict__ y, size_t n) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    const size_t n2 = n >> 1;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n2; i += stride) {
+        const double2 xv = reinterpret_cast<const double2 *>(x)[i];
+        double2 yv;
+        if (b == 0.0) { yv.x = a * xv.x; yv.y = a * xv.y; }
+        else { yv = reinterpret_cast<double2 *>(y)[i]; yv.x = a * xv.x + b * yv.x; yv.y = a * xv.y + b * yv.y; }
+        reinterpret_cast<double2 *>(y)[i] = yv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = (b == 0.0) ? a * x[n - 1] : a * x[n - 1] + b * y[n - 1];
+}
+
+// pCG fused update (saena_object_solve.cpp:2593-2596): u -= alpha p ; r -= alpha h
+__global__ __launch_bounds__(BLOCK) void k_pcg_update(double alpha, const double *__restrict__ p, const double *__restrict__ h,
+                                                      double *__restrict__ u, double *__restrict__ r, size_t n) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        u[i] -= alpha * p[i];
+        r[i] -= alpha * h[i];
+    }
+}
+
+// K9: dot product, stage 1: per-block partial (wave shuffle + LDS), stage 2 by k_reduce_partials
+__device__ __forceinline__ double block_sum(double s, double *sh) {
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) t += sh[w];
+    }
+    __syncthreads();
+    return t;   // valid in thread 0
+}
+
+__global__ __launch_bounds__(BLOCK) void k_dot_partial(const double *__restrict__ x, const double *__restrict__ y, size_t n,
+                                                       double *__restrict__ partial) {
+    __shared__ double sh[BLOCK / 64];
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) s += x[i] * y[i];
+    const double t = block_sum(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// out[0] = sum(partial[0..np))  (single block; fixed order => run-to-run deterministic)
+__global__ __launch_bounds__(BLOCK) void k_reduce_partials(const double *__restrict__ partial, int np, double *__restrict__ out) {
+    __shared__ double sh[BLOCK / 64];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += BLOCK) s += partial[i];
+    const double t = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+// ---------------------------------------------------------------------------
+// Coarsest-level CG (solve_coarsest_CG, saena_object_solve.cpp:14-114) as ONE
+// workgroup: the <= ~100-row system lives in LDS for the whole solve, so the
+// up-to-150 iterations cost no kernel launches and no HBM traffic.
+// Single-rank form (the coarsest operator is replicated on every rank).
+constexpr int CG_MAXN   = 1024;     // rows supported by the LDS-resident solver
+constexpr int CG_BLOCK  = 256;
+
+struct CoarseCGArgs {
+    const int    *row_ptr;
+    const int    *col;
+    const double *val;
+    int           n;
+    const double *rhs;
+    double       *u;          // in/out (caller zeroes it, as vcycle does)
+    int           max_iter;
+    double        tol;
+    int          *iters_out;  // may be nullptr
+};
+
+__device__ __forceinline__ double cg_block_dot(const double *a, const double *b, int n, double *sh) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += CG_BLOCK) s += a[i] * b[i];
+    s = group_sum<64>(s);
+    __syncthreads();                       // sh reuse
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < CG_BLOCK / 64; ++w) t += sh[w];
+    return t;                              // every thread holds the same value
+}
+
+__global__ __launch_bounds__(CG_BLOCK) void k_coarse_cg(const CoarseCGArgs a) {
+    __shared__ double res[CG_MAXN], dir[CG_MAXN], mt[CG_MAXN], uu[CG_MAXN];
+    __shared__ double sh[CG_BLOCK / 64];
+    const int n = a.n, tid = threadIdx.x;
+    for (int i = tid; i < n; i += CG_BLOCK) { res[i] = a.rhs[i]; dir[i] = a.rhs[i]; uu[i] = a.u[i]; }
+    __syncthreads();
+    const double initial_dot = cg_block_dot(res, res, n, sh);
+    const double thres = initial_dot * a.tol * a.tol;
+    double dot = initial_dot;
+    int max_iter = a.max_iter;
+    if (dot < a.tol * a.tol) max_iter = 0;
+    int i = 1;
+    constexpr int G = 8;                    // lanes per row in the LDS matvec
+    while (i < max_iter) {
+        __syncthreads();
+        for (int r = tid / G; r < n; r += CG_BLOCK / G) {       // mt = A dir
+            double s = 0.0;
+            for (int k = a.row_ptr[r] + (tid % G); k < a.row_ptr[r + 1]; k += G) s += a.val[k] * dir[a.col[k]];
+            s = group_sum<G>(s);
+            if ((tid % G) == 0) mt[r] = s;
+        }
+        __syncthreads();
+        double factor = cg_block_dot(dir, mt, n, sh);
+        factor = dot / factor;
+        for (int j = tid; j < n; j += CG_BLOCK) { uu[j] += factor * dir[j]; res[j] -= factor * mt[j]; }
+        __syncthreads();
+        const double dot_prev = dot;
+        dot = cg_block_dot(res, res, n, sh);
+        if (dot < thres) break;
+        factor = dot / dot_prev;
+        for (int j = tid; j < n; j += CG_BLOCK) dir[j] = res[j] + factor * dir[j];
+        i++;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += CG_BLOCK) a.u[j] = uu[j];
+    if (i == max_iter && max_iter != 0) i--;
+    if (tid == 0 && a.iters_out) *a.iters_out = i;
+}
+
+} // namespace sk

@@ -1,0 +1,928 @@
+// sgpu_runtime.hip -- C ABI (include/saena_gpu.h) over the gfx950 kernels.
+//
+// One process = one rank = one MI355X.  Two HIP streams per rank: `cs` runs
+// the kernels, `hs` carries the x-vector halo (RCCL send/recv over xGMI) so the
+// exchange overlaps the local SpMV exactly where the reference overlaps
+// MPI_Isend/Irecv with its local loop (src/saena_matrix_matvec.cpp:32-80).
+#include "../../include/saena_gpu.h"
+#include "kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(SGPU_ERR_HIP, "%s:%d %s: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define NCCLCHK(expr)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess) return fail(SGPU_ERR_RCCL, "%s:%d %s: %s", __FILE__, __LINE__, #expr, ncclGetErrorString(r_)); \
+    } while (0)
+#define CHK(expr)                                                                                      \
+    do {                                                                                               \
+        int s_ = (expr);                                                                               \
+        if (s_ != SGPU_OK) return s_;                                                                  \
+    } while (0)
+
+struct Ctx {
+    bool        live = false;
+    int         device = 0, rank = 0, nranks = 1;
+    hipStream_t cs = nullptr, hs = nullptr;
+    ncclComm_t  comm = nullptr;
+    double     *partials = nullptr;   // dot partial sums
+    double     *dscalar = nullptr;    // device scalars (dot result)
+    double     *hscalar = nullptr;    // pinned host mirror
+    int        *dint = nullptr;       // device int scratch (coarse CG iterations, barrier)
+    int        *hint = nullptr;       // pinned
+    int         n_partials = 1024;
+};
+Ctx g;
+
+int need_ctx() { return g.live ? SGPU_OK : fail(SGPU_ERR_STATE, "sgpu_init has not been called"); }
+
+template <class T>
+int dev_upload(T **dst, const T *src, size_t n, size_t pad = 0) {
+    *dst = nullptr;
+    const size_t bytes = (n + pad) * sizeof(T);
+    if (hipMalloc(reinterpret_cast<void **>(dst), bytes ? bytes : sizeof(T)) != hipSuccess)
+        return fail(SGPU_ERR_NOMEM, "hipMalloc of %zu bytes failed", bytes);
+    if (pad) HIPCHK(hipMemsetAsync(*dst, 0, bytes ? bytes : sizeof(T), g.cs));
+    if (n) HIPCHK(hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, g.cs));
+    HIPCHK(hipStreamSynchronize(g.cs));
+    return SGPU_OK;
+}
+
+// One CSR part (local, or remote-over-halo) laid out for k_csr_stream.
+struct CsrPart {
+    int     nrows = 0;            // rows covered by row_ptr (M, or number of remote rows)
+    int64_t nnz = 0;
+    int    *row_ptr = nullptr, *col = nullptr, *blk_row = nullptr, *rows = nullptr;
+    double *val = nullptr;
+    int     nblk = 0;
+    int     lanes = 1;            // G
+    void free_all() {
+        hipFree(row_ptr); hipFree(col); hipFree(blk_row); hipFree(rows); hipFree(val);
+        row_ptr = col = blk_row = rows = nullptr; val = nullptr;
+    }
+};
+
+int pow2floor(int x) { int p = 1; while (2 * p <= x) p *= 2; return p; }
+
+// Row-block plan: consecutive rows while the block holds <= CAP products and
+// <= MAXROWS rows; a row longer than CAP gets a block of its own.
+void plan_blocks(const std::vector<int> &rp, std::vector<int> &blk) {
+    const int M = (int)rp.size() - 1;
+    blk.clear();
+    blk.push_back(0);
+    int r = 0;
+    while (r < M) {
+        const int start = r;
+        const int p0 = rp[r];
+        while (r < M && r - start < sk::MAXROWS && rp[r + 1] - p0 <= sk::CAP) ++r;
+        if (r == start) ++r;      // long row
+        blk.push_back(r);
+    }
+}
+
+int auto_lanes(int nrows, int nblk) {
+    if (nblk <= 0 || nrows <= 0) return 1;
+    const int rows_per_blk = std::max(1, (nrows + nblk - 1) / nblk);
+    return std::min(64, std::max(1, pow2floor(sk::BLOCK / rows_per_blk)));
+}
+
+int build_part(CsrPart &P, const std::vector<int> &rp, const std::vector<int> &col, const std::vector<double> &val,
+               const std::vector<int> *rows) {
+    P.nrows = (int)rp.size() - 1;
+    P.nnz   = rp.back();
+    std::vector<int> blk;
+    plan_blocks(rp, blk);
+    P.nblk  = (int)blk.size() - 1;
+    P.lanes = auto_lanes(P.nrows, P.nblk);
+    CHK(dev_upload(&P.row_ptr, rp.data(), rp.size()));
+    CHK(dev_upload(&P.col, col.data(), col.size(), 8));
+    CHK(dev_upload(&P.val, val.data(), val.size(), 8));
+    CHK(dev_upload(&P.blk_row, blk.data(), blk.size()));
+    if (rows) CHK(dev_upload(&P.rows, rows->data(), rows->size()));
+    return SGPU_OK;
+}
+
+} // namespace
+
+struct sgpu_op {
+    index_t M = 0, N_local = 0;
+    CsrPart loc, rem;
+    bool    has_remote = false;
+    double *inv_diag = nullptr;
+    double *tmp = nullptr;        // smoother ping-pong buffer [M]
+    double *dvec = nullptr;       // chebyshev d [M]
+    // halo plan
+    int     vIndexSize = 0, recvSize = 0;
+    int    *vIndex = nullptr;
+    double *send_buf = nullptr, *recv_buf = nullptr;
+    std::vector<int> sendRank, sendCount, sendDispl, recvRank, recvCount, recvDispl;
+    int     halo_fp32 = 0;
+    bool    injected = false;     // test hook: halo supplied by sgpu_debug_inject_halo
+    hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
+};
+
+namespace {
+
+using KernelFn = void (*)(const sk::SpmvArgs);
+
+template <int EPI>
+KernelFn pick_g(int lanes) {
+    switch (lanes) {
+        case 1:  return sk::k_csr_stream<EPI, 1>;
+        case 2:  return sk::k_csr_stream<EPI, 2>;
+        case 4:  return sk::k_csr_stream<EPI, 4>;
+        case 8:  return sk::k_csr_stream<EPI, 8>;
+        case 16: return sk::k_csr_stream<EPI, 16>;
+        case 32: return sk::k_csr_stream<EPI, 32>;
+        default: return sk::k_csr_stream<EPI, 64>;
+    }
+}
+
+KernelFn pick(int epi, int lanes) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return pick_g<sk::EPI_SPMV>(lanes);
+        case sk::EPI_RESIDUAL: return pick_g<sk::EPI_RESIDUAL>(lanes);
+        case sk::EPI_JACOBI:   return pick_g<sk::EPI_JACOBI>(lanes);
+        case sk::EPI_CHEBY0:   return pick_g<sk::EPI_CHEBY0>(lanes);
+        case sk::EPI_CHEBYK:   return pick_g<sk::EPI_CHEBYK>(lanes);
+        default:               return pick_g<sk::EPI_SUB>(lanes);
+    }
+}
+
+struct EpiArgs {
+    const double *rhs = nullptr, *inv_diag = nullptr, *u = nullptr;
+    double       *d = nullptr;
+    double        c0 = 0.0, c1 = 0.0;
+};
+
+int launch_part(const CsrPart &P, int epi, const double *x, double *y, const EpiArgs &e) {
+    if (P.nblk == 0) return SGPU_OK;
+    sk::SpmvArgs a;
+    a.row_ptr = P.row_ptr; a.col = P.col; a.val = P.val; a.blk_row = P.blk_row;
+    a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
+    a.c0 = e.c0; a.c1 = e.c1; a.nblk = P.nblk; a.rows = P.rows;
+    hipLaunchKernelGGL(pick(epi, P.lanes), dim3(P.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+    HIPCHK(hipGetLastError());
+    return SGPU_OK;
+}
+
+// Start the halo exchange of x on the halo stream (pack on cs, send/recv on hs).
+int halo_begin(sgpu_op *op, const double *x) {
+    if (g.nranks == 1 || (op->vIndexSize == 0 && op->recvSize == 0)) return SGPU_OK;
+    if (op->vIndexSize) {
+        hipLaunchKernelGGL(sk::k_pack, dim3((op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
+                           x, op->vIndex, op->send_buf, op->vIndexSize, op->halo_fp32);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(op->ev_packed, g.cs));
+    HIPCHK(hipStreamWaitEvent(g.hs, op->ev_packed, 0));
+    NCCLCHK(ncclGroupStart());
+    for (size_t i = 0; i < op->sendRank.size(); ++i)
+        NCCLCHK(ncclSend(op->send_buf + op->sendDispl[i], (size_t)op->sendCount[i], ncclDouble, op->sendRank[i], g.comm, g.hs));
+    for (size_t i = 0; i < op->recvRank.size(); ++i)
+        NCCLCHK(ncclRecv(op->recv_buf + op->recvDispl[i], (size_t)op->recvCount[i], ncclDouble, op->recvRank[i], g.comm, g.hs));
+    NCCLCHK(ncclGroupEnd());
+    HIPCHK(hipEventRecord(op->ev_halo, g.hs));
+    return SGPU_OK;
+}
+
+// y = epi(A x): halo on hs || local part on cs, then the remote correction.
+int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
+    CHK(halo_begin(op, x));
+    CHK(launch_part(op->loc, epi, x, y, e));
+    if (op->has_remote && (g.nranks > 1 || op->injected)) {
+        if (g.nranks > 1) HIPCHK(hipStreamWaitEvent(g.cs, op->ev_halo, 0));
+        CHK(launch_part(op->rem, epi, op->recv_buf, y, e));
+    }
+    return SGPU_OK;
+}
+
+int ensure_tmp(sgpu_op *op) {
+    if (!op->tmp) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->tmp), std::max<size_t>(1, op->M) * sizeof(double)));
+    return SGPU_OK;
+}
+int ensure_d(sgpu_op *op) {
+    if (!op->dvec) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->dvec), std::max<size_t>(1, op->M) * sizeof(double)));
+    return SGPU_OK;
+}
+
+int grid_for(size_t n) { return (int)std::min<size_t>(2048, std::max<size_t>(1, (n / 2 + sk::BLOCK - 1) / sk::BLOCK)); }
+
+// iter Jacobi sweeps ping-ponging u <-> alt; *out = buffer holding the result.
+int jacobi_pp(sgpu_op *op, int iter, double omega, double *u, double *alt, const double *rhs, double **out) {
+    if (!op->inv_diag) return fail(SGPU_ERR_ARG, "jacobi: operator has no inv_diag");
+    double *cur = u, *nxt = alt;
+    for (int j = 0; j < iter; ++j) {
+        EpiArgs e; e.rhs = rhs; e.inv_diag = op->inv_diag; e.u = cur; e.c0 = omega;
+        CHK(apply(op, sk::EPI_JACOBI, cur, nxt, e));
+        std::swap(cur, nxt);
+    }
+    *out = cur;
+    return SGPU_OK;
+}
+
+// saena_matrix::chebyshev scalars, src/saena_matrix.cpp:1084-1091,1113-1117
+int cheby_pp(sgpu_op *op, int iter, double eig_max, double *u, double *alt, const double *rhs, double **out) {
+    if (!op->inv_diag) return fail(SGPU_ERR_ARG, "chebyshev: operator has no inv_diag");
+    CHK(ensure_d(op));
+    const double alpha = 0.13 * eig_max, beta = eig_max;
+    const double delta = (beta - alpha) / 2.0, theta = (beta + alpha) / 2.0;
+    const double s1 = theta / delta, twos1 = 2.0 * s1;
+    double rhok = 1.0 / s1;
+    double *cur = u, *nxt = alt;
+    if (iter <= 0) { *out = cur; return SGPU_OK; }
+    {
+        EpiArgs e; e.rhs = rhs; e.inv_diag = op->inv_diag; e.u = cur; e.d = op->dvec; e.c0 = 1.0 / theta;
+        CHK(apply(op, sk::EPI_CHEBY0, cur, nxt, e));
+        std::swap(cur, nxt);
+    }
+    for (int i = 1; i < iter; ++i) {
+        const double rhokp1 = 1.0 / (twos1 - rhok);
+        const double two_rhokp1 = 2.0 * rhokp1;
+        const double d1 = rhokp1 * rhok;
+        const double d2 = two_rhokp1 / delta;
+        rhok = rhokp1;
+        EpiArgs e; e.rhs = rhs; e.inv_diag = op->inv_diag; e.u = cur; e.d = op->dvec; e.c0 = d2; e.c1 = d1;
+        CHK(apply(op, sk::EPI_CHEBYK, cur, nxt, e));
+        std::swap(cur, nxt);
+    }
+    *out = cur;
+    return SGPU_OK;
+}
+
+int dot_local_async(const double *x, const double *y, size_t n, double *dout) {
+    const int nb = (int)std::min<size_t>(g.n_partials, std::max<size_t>(1, (n + sk::BLOCK - 1) / sk::BLOCK));
+    hipLaunchKernelGGL(sk::k_dot_partial, dim3(nb), dim3(sk::BLOCK), 0, g.cs, x, y, n, g.partials);
+    hipLaunchKernelGGL(sk::k_reduce_partials, dim3(1), dim3(sk::BLOCK), 0, g.cs, g.partials, nb, dout);
+    HIPCHK(hipGetLastError());
+    return SGPU_OK;
+}
+
+const double JACOBI_OMEGA_REF = (double)(float)(2.0 / 3);   // saena_matrix.h:182
+
+} // namespace
+
+// ===========================================================================
+extern "C" {
+
+const char *sgpu_last_error(void) { return g_err.c_str(); }
+
+int sgpu_get_unique_id(void *out128) {
+    if (!out128) return fail(SGPU_ERR_ARG, "null unique-id buffer");
+    static_assert(sizeof(ncclUniqueId) == SGPU_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    memcpy(out128, &id, sizeof id);
+    return SGPU_OK;
+}
+
+int sgpu_init(int device_id, int rank, int nranks, const void *uid) {
+    if (g.live) return fail(SGPU_ERR_STATE, "sgpu_init called twice");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SGPU_ERR_ARG, "bad rank %d of %d", rank, nranks);
+    if (nranks > 1 && !uid) return fail(SGPU_ERR_ARG, "nranks > 1 needs an RCCL unique id");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev == 0) return fail(SGPU_ERR_HIP, "no HIP device visible: libsaena_amd needs an MI355X (there is no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(SGPU_ERR_ARG, "device %d not in [0,%d)", device_id, ndev);
+    HIPCHK(hipSetDevice(device_id));
+    g.device = device_id; g.rank = rank; g.nranks = nranks;
+    HIPCHK(hipStreamCreateWithFlags(&g.cs, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&g.hs, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&g.partials), g.n_partials * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&g.dscalar), 16 * sizeof(double)));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&g.hscalar), 16 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&g.dint), 16 * sizeof(int)));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&g.hint), 16 * sizeof(int), hipHostMallocDefault));
+    if (nranks > 1) {
+        ncclUniqueId id;
+        memcpy(&id, uid, sizeof id);
+        NCCLCHK(ncclCommInitRank(&g.comm, nranks, id, rank));
+    }
+    g.live = true;
+    return SGPU_OK;
+}
+
+int sgpu_finalize(void) {
+    if (!g.live) return SGPU_OK;
+    hipDeviceSynchronize();
+    if (g.comm) { ncclCommDestroy(g.comm); g.comm = nullptr; }
+    hipFree(g.partials); hipFree(g.dscalar); hipHostFree(g.hscalar); hipFree(g.dint); hipHostFree(g.hint);
+    hipStreamDestroy(g.cs); hipStreamDestroy(g.hs);
+    g = Ctx();
+    return SGPU_OK;
+}
+
+int sgpu_rank(void) { return g.rank; }
+int sgpu_nranks(void) { return g.nranks; }
+
+int sgpu_device_sync(void) {
+    CHK(need_ctx());
+    HIPCHK(hipStreamSynchronize(g.hs));
+    HIPCHK(hipStreamSynchronize(g.cs));
+    return SGPU_OK;
+}
+
+int sgpu_barrier(void) {
+    CHK(sgpu_device_sync());
+    if (g.nranks > 1) {
+        HIPCHK(hipMemsetAsync(g.dint, 0, sizeof(int), g.cs));
+        NCCLCHK(ncclAllReduce(g.dint, g.dint, 1, ncclInt, ncclSum, g.comm, g.cs));
+        HIPCHK(hipStreamSynchronize(g.cs));
+    }
+    return SGPU_OK;
+}
+
+// ---- vectors ----
+int sgpu_vec_alloc(value_t **dev, size_t n) {
+    CHK(need_ctx());
+    if (!dev) return fail(SGPU_ERR_ARG, "null out pointer");
+    if (hipMalloc(reinterpret_cast<void **>(dev), std::max<size_t>(1, n) * sizeof(value_t)) != hipSuccess)
+        return fail(SGPU_ERR_NOMEM, "hipMalloc of %zu doubles failed", n);
+    return SGPU_OK;
+}
+int sgpu_vec_free(value_t *dev) { CHK(need_ctx()); HIPCHK(hipFree(dev)); return SGPU_OK; }
+int sgpu_vec_upload(value_t *dev, const value_t *host, size_t n) {
+    CHK(need_ctx());
+    HIPCHK(hipMemcpyAsync(dev, host, n * sizeof(value_t), hipMemcpyHostToDevice, g.cs));
+    HIPCHK(hipStreamSynchronize(g.cs));
+    return SGPU_OK;
+}
+int sgpu_vec_download(value_t *host, const value_t *dev, size_t n) {
+    CHK(need_ctx());
+    HIPCHK(hipStreamSynchronize(g.hs));
+    HIPCHK(hipMemcpyAsync(host, dev, n * sizeof(value_t), hipMemcpyDeviceToHost, g.cs));
+    HIPCHK(hipStreamSynchronize(g.cs));
+    return SGPU_OK;
+}
+int sgpu_vec_fill(value_t *dev, value_t a, size_t n) {
+    CHK(need_ctx());
+    if (n == 0) return SGPU_OK;
+    hipLaunchKernelGGL(sk::k_fill, dim3(grid_for(n)), dim3(sk::BLOCK), 0, g.cs, dev, a, n);
+    HIPCHK(hipGetLastError());
+    return SGPU_OK;
+}
+int sgpu_vec_copy(value_t *dst, const value_t *src, size_t n) {
+    CHK(need_ctx());
+    HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(value_t), hipMemcpyDeviceToDevice, g.cs));
+    return SGPU_OK;
+}
+int sgpu_vec_axpby(value_t a, const value_t *x, value_t b, value_t *y, size_t n) {
+    CHK(need_ctx());
+    if (n == 0) return SGPU_OK;
+    hipLaunchKernelGGL(sk::k_axpby, dim3(grid_for(n)), dim3(sk::BLOCK), 0, g.cs, a, x, b, y, n);
+    HIPCHK(hipGetLastError());
+    return SGPU_OK;
+}
+int sgpu_dot(const value_t *x, const value_t *y, size_t n, value_t *out) {
+    CHK(need_ctx());
+    CHK(dot_local_async(x, y, n, g.dscalar));
+    if (g.nranks > 1) NCCLCHK(ncclAllReduce(g.dscalar, g.dscalar, 1, ncclDouble, ncclSum, g.comm, g.cs));
+    HIPCHK(hipMemcpyAsync(g.hscalar, g.dscalar, sizeof(double), hipMemcpyDeviceToHost, g.cs));
+    HIPCHK(hipStreamSynchronize(g.cs));
+    *out = g.hscalar[0];
+    return SGPU_OK;
+}
+
+// ---- operators ----
+int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
+    CHK(need_ctx());
+    if (!d || !out) return fail(SGPU_ERR_ARG, "null descriptor");
+    if (d->M < 0 || d->N_local < 0 || d->nnz_l_local < 0 || d->nnz_l_remote < 0) return fail(SGPU_ERR_ARG, "negative size");
+    if (d->nnz_l_local >= INT32_MAX || d->nnz_l_remote >= INT32_MAX) return fail(SGPU_ERR_ARG, "local nnz must fit int32");
+    if (d->M && !d->nnzPerRow_local) return fail(SGPU_ERR_ARG, "nnzPerRow_local is null");
+    if (d->nnz_l_local && (!d->col_local || !d->val_local)) return fail(SGPU_ERR_ARG, "col_local/val_local is null");
+    std::unique_ptr<sgpu_op> op(new sgpu_op());
+    op->M = d->M; op->N_local = d->N_local; op->halo_fp32 = d->halo_fp32;
+
+    // local part: prefix-sum row pointers, rebase columns (v_p = v - split[rank], saena_matrix_matvec.cpp:56)
+    {
+        std::vector<int> rp((size_t)d->M + 1, 0);
+        for (index_t i = 0; i < d->M; ++i) {
+            if (d->nnzPerRow_local[i] < 0) return fail(SGPU_ERR_ARG, "negative row length at row %d", i);
+            rp[i + 1] = rp[i] + d->nnzPerRow_local[i];
+        }
+        if (rp[d->M] != d->nnz_l_local) return fail(SGPU_ERR_ARG, "sum(nnzPerRow_local)=%d != nnz_l_local=%ld", rp[d->M], (long)d->nnz_l_local);
+        std::vector<int> col((size_t)d->nnz_l_local);
+        for (nnz_t k = 0; k < d->nnz_l_local; ++k) {
+            const long c = (long)d->col_local[k] - d->col_offset;
+            if (c < 0 || c >= d->N_local) return fail(SGPU_ERR_ARG, "col_local[%ld]=%d outside this rank's column block", (long)k, d->col_local[k]);
+            col[k] = (int)c;
+        }
+        std::vector<double> val(d->val_local, d->val_local + d->nnz_l_local);
+        CHK(build_part(op->loc, rp, col, val, nullptr));
+    }
+    // remote part: CSC over the receive buffer -> CSR over the halo buffer on the rows that own remote entries
+    if (d->nnz_l_remote > 0) {
+        if (!d->nnzPerCol_remote || !d->row_remote || !d->val_remote) return fail(SGPU_ERR_ARG, "remote arrays are null");
+        std::vector<int> cnt((size_t)d->M, 0);
+        nnz_t tot = 0;
+        for (index_t j = 0; j < d->col_remote_size; ++j) tot += d->nnzPerCol_remote[j];
+        if (tot != d->nnz_l_remote) return fail(SGPU_ERR_ARG, "sum(nnzPerCol_remote) != nnz_l_remote");
+        for (nnz_t k = 0; k < d->nnz_l_remote; ++k) {
+            if (d->row_remote[k] < 0 || d->row_remote[k] >= d->M) return fail(SGPU_ERR_ARG, "row_remote out of range");
+            cnt[d->row_remote[k]]++;
+        }
+        std::vector<int> rows, slot((size_t)d->M, -1), rp(1, 0);
+        for (index_t i = 0; i < d->M; ++i)
+            if (cnt[i]) { slot[i] = (int)rows.size(); rows.push_back(i); rp.push_back(rp.back() + cnt[i]); }
+        std::vector<int> fillp(rp.begin(), rp.end() - 1), col((size_t)d->nnz_l_remote);
+        std::vector<double> val((size_t)d->nnz_l_remote);
+        nnz_t k = 0;
+        for (index_t j = 0; j < d->col_remote_size; ++j)
+            for (index_t t = 0; t < d->nnzPerCol_remote[j]; ++t, ++k) {
+                const int s = slot[d->row_remote[k]];
+                col[fillp[s]] = j; val[fillp[s]] = d->val_remote[k]; fillp[s]++;
+            }
+        CHK(build_part(op->rem, rp, col, val, &rows));
+        op->has_remote = true;
+    }
+    if (d->inv_diag) CHK(dev_upload(&op->inv_diag, d->inv_diag, (size_t)d->M));
+
+    // halo plan
+    op->vIndexSize = d->vIndexSize;
+    op->recvSize   = d->col_remote_size;
+    int sd = 0, rd = 0;
+    for (int i = 0; i < d->numSendProc; ++i) {
+        op->sendRank.push_back(d->sendProcRank[i]); op->sendCount.push_back(d->sendProcCount[i]); op->sendDispl.push_back(sd);
+        sd += d->sendProcCount[i];
+    }
+    for (int i = 0; i < d->numRecvProc; ++i) {
+        op->recvRank.push_back(d->recvProcRank[i]); op->recvCount.push_back(d->recvProcCount[i]); op->recvDispl.push_back(rd);
+        rd += d->recvProcCount[i];
+    }
+    if (sd != d->vIndexSize) return fail(SGPU_ERR_ARG, "sum(sendProcCount)=%d != vIndexSize=%d", sd, d->vIndexSize);
+    if (rd != d->col_remote_size) return fail(SGPU_ERR_ARG, "sum(recvProcCount)=%d != col_remote_size=%d", rd, d->col_remote_size);
+    if (g.nranks > 1) {   // (a 1-rank context may hold plans of a larger world for the single-GPU halo tests)
+        for (int r : op->sendRank) if (r < 0 || r >= g.nranks || r == g.rank) return fail(SGPU_ERR_ARG, "bad send rank %d", r);
+        for (int r : op->recvRank) if (r < 0 || r >= g.nranks || r == g.rank) return fail(SGPU_ERR_ARG, "bad recv rank %d", r);
+    }
+    if (d->vIndexSize) {
+        for (index_t i = 0; i < d->vIndexSize; ++i)
+            if (d->vIndex[i] < 0 || d->vIndex[i] >= d->N_local) return fail(SGPU_ERR_ARG, "vIndex out of range");
+        CHK(dev_upload(&op->vIndex, d->vIndex, (size_t)d->vIndexSize));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->send_buf), (size_t)d->vIndexSize * sizeof(double)));
+    }
+    if (op->recvSize) {
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->recv_buf), (size_t)op->recvSize * sizeof(double)));
+        HIPCHK(hipMemsetAsync(op->recv_buf, 0, (size_t)op->recvSize * sizeof(double), g.cs));
+    }
+    HIPCHK(hipEventCreateWithFlags(&op->ev_packed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&op->ev_halo, hipEventDisableTiming));
+    HIPCHK(hipStreamSynchronize(g.cs));
+    *out = op.release();
+    return SGPU_OK;
+}
+
+int sgpu_op_destroy(sgpu_op *op) {
+    if (!op) return SGPU_OK;
+    if (g.live) hipDeviceSynchronize();
+    op->loc.free_all(); op->rem.free_all();
+    hipFree(op->inv_diag); hipFree(op->tmp); hipFree(op->dvec); hipFree(op->vIndex); hipFree(op->send_buf); hipFree(op->recv_buf);
+    if (op->ev_packed) hipEventDestroy(op->ev_packed);
+    if (op->ev_halo) hipEventDestroy(op->ev_halo);
+    delete op;
+    return SGPU_OK;
+}
+
+int sgpu_op_info(const sgpu_op *op, index_t *M, index_t *N_local, nnz_t *nnz_local, nnz_t *nnz_remote, int *nblk, int *lanes) {
+    if (!op) return fail(SGPU_ERR_ARG, "null op");
+    if (M) *M = op->M;
+    if (N_local) *N_local = op->N_local;
+    if (nnz_local) *nnz_local = op->loc.nnz;
+    if (nnz_remote) *nnz_remote = op->rem.nnz;
+    if (nblk) *nblk = op->loc.nblk;
+    if (lanes) *lanes = op->loc.lanes;
+    return SGPU_OK;
+}
+
+int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
+    if (!op) return fail(SGPU_ERR_ARG, "null op");
+    if (lanes == 0) { op->loc.lanes = auto_lanes(op->loc.nrows, op->loc.nblk); return SGPU_OK; }
+    if (lanes < 1 || lanes > 64 || (lanes & (lanes - 1))) return fail(SGPU_ERR_ARG, "lanes_per_row must be a power of two in [1,64]");
+    op->loc.lanes = lanes;
+    return SGPU_OK;
+}
+
+int sgpu_spmv(sgpu_op *op, const value_t *v, value_t *w) {
+    CHK(need_ctx());
+    if (!op || !v || !w) return fail(SGPU_ERR_ARG, "null argument");
+    return apply(op, sk::EPI_SPMV, v, w, EpiArgs());
+}
+
+int sgpu_residual(sgpu_op *op, const value_t *u, const value_t *rhs, value_t *res) {
+    CHK(need_ctx());
+    if (!op || !u || !rhs || !res) return fail(SGPU_ERR_ARG, "null argument");
+    EpiArgs e; e.rhs = rhs;
+    return apply(op, sk::EPI_RESIDUAL, u, res, e);
+}
+
+int sgpu_jacobi(sgpu_op *op, int iter, value_t omega, value_t *u, const value_t *rhs) {
+    CHK(need_ctx());
+    if (!op || !u || !rhs || iter < 0) return fail(SGPU_ERR_ARG, "bad argument");
+    if (omega == 0.0) omega = JACOBI_OMEGA_REF;
+    CHK(ensure_tmp(op));
+    double *res = nullptr;
+    CHK(jacobi_pp(op, iter, omega, u, op->tmp, rhs, &res));
+    if (res != u) HIPCHK(hipMemcpyAsync(u, res, (size_t)op->M * sizeof(double), hipMemcpyDeviceToDevice, g.cs));
+    return SGPU_OK;
+}
+
+int sgpu_chebyshev(sgpu_op *op, int iter, value_t eig_max, value_t *u, const value_t *rhs) {
+    CHK(need_ctx());
+    if (!op || !u || !rhs || iter < 0) return fail(SGPU_ERR_ARG, "bad argument");
+    if (!(eig_max > 0.0)) return fail(SGPU_ERR_ARG, "chebyshev needs eig_max > 0");
+    CHK(ensure_tmp(op));
+    double *res = nullptr;
+    CHK(cheby_pp(op, iter, eig_max, u, op->tmp, rhs, &res));
+    if (res != u) HIPCHK(hipMemcpyAsync(u, res, (size_t)op->M * sizeof(double), hipMemcpyDeviceToDevice, g.cs));
+    return SGPU_OK;
+}
+
+int sgpu_prolong_correct(sgpu_op *P, const value_t *e_coarse, value_t *u) {
+    CHK(need_ctx());
+    if (!P || !e_coarse || !u) return fail(SGPU_ERR_ARG, "null argument");
+    return apply(P, sk::EPI_SUB, e_coarse, u, EpiArgs());
+}
+
+int sgpu_debug_pack(sgpu_op *op, const value_t *v, value_t *send_host) {
+    CHK(need_ctx());
+    if (!op || !v) return fail(SGPU_ERR_ARG, "null argument");
+    if (op->vIndexSize == 0) return SGPU_OK;
+    hipLaunchKernelGGL(sk::k_pack, dim3((op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
+                       v, op->vIndex, op->send_buf, op->vIndexSize, op->halo_fp32);
+    HIPCHK(hipGetLastError());
+    return sgpu_vec_download(send_host, op->send_buf, (size_t)op->vIndexSize);
+}
+
+int sgpu_debug_inject_halo(sgpu_op *op, const value_t *recv_host) {
+    CHK(need_ctx());
+    if (!op) return fail(SGPU_ERR_ARG, "null argument");
+    if (op->recvSize) CHK(sgpu_vec_upload(op->recv_buf, recv_host, (size_t)op->recvSize));
+    op->injected = true;
+    return SGPU_OK;
+}
+
+// ---- host-slice forms ----
+namespace {
+struct DevBuf {
+    double *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(1, n) * sizeof(double)) == hipSuccess ? SGPU_OK : fail(SGPU_ERR_NOMEM, "hipMalloc failed"); }
+};
+}
+
+int sgpu_spmv_host(sgpu_op *op, const value_t *v_host, value_t *w_host) {
+    CHK(need_ctx());
+    if (!op || !v_host || !w_host) return fail(SGPU_ERR_ARG, "null argument");
+    DevBuf v, w;
+    CHK(v.alloc(op->N_local)); CHK(w.alloc(op->M));
+    CHK(sgpu_vec_upload(v.p, v_host, op->N_local));
+    CHK(sgpu_spmv(op, v.p, w.p));
+    return sgpu_vec_download(w_host, w.p, op->M);
+}
+int sgpu_jacobi_host(sgpu_op *op, int iter, value_t omega, value_t *u_host, const value_t *rhs_host) {
+    CHK(need_ctx());
+    if (!op || !u_host || !rhs_host) return fail(SGPU_ERR_ARG, "null argument");
+    DevBuf u, r;
+    CHK(u.alloc(op->M)); CHK(r.alloc(op->M));
+    CHK(sgpu_vec_upload(u.p, u_host, op->M)); CHK(sgpu_vec_upload(r.p, rhs_host, op->M));
+    CHK(sgpu_jacobi(op, iter, omega, u.p, r.p));
+    return sgpu_vec_download(u_host, u.p, op->M);
+}
+int sgpu_chebyshev_host(sgpu_op *op, int iter, value_t eig_max, value_t *u_host, const value_t *rhs_host) {
+    CHK(need_ctx());
+    if (!op || !u_host || !rhs_host) return fail(SGPU_ERR_ARG, "null argument");
+    DevBuf u, r;
+    CHK(u.alloc(op->M)); CHK(r.alloc(op->M));
+    CHK(sgpu_vec_upload(u.p, u_host, op->M)); CHK(sgpu_vec_upload(r.p, rhs_host, op->M));
+    CHK(sgpu_chebyshev(op, iter, eig_max, u.p, r.p));
+    return sgpu_vec_download(u_host, u.p, op->M);
+}
+
+} // extern "C"
+
+// ===========================================================================
+// multigrid
+struct sgpu_amg {
+    int nlevels = 0;
+    std::vector<sgpu_op *> A, P, R;
+    std::vector<double> eig;
+    sgpu_amg_params prm;
+    // per level l < nlevels-1: res[l] (A[l].M); per level l >= 1: rhs_l / u_l / alt_l (A[l].M)
+    std::vector<double *> res, rhs, u, alt;
+    double *alt0 = nullptr;   // ping-pong partner of the caller's level-0 u
+    // solve work vectors (level 0)
+    double *r = nullptr, *rho = nullptr, *hh = nullptr, *p = nullptr;
+};
+
+namespace {
+
+int coarse_cg_single(sgpu_amg *h, sgpu_op *A, double *u, const double *rhs, int *iters) {
+    if (A->M > sk::CG_MAXN) return fail(SGPU_ERR_ARG, "coarsest level has %d rows; the LDS-resident CG supports <= %d", A->M, sk::CG_MAXN);
+    sk::CoarseCGArgs a;
+    a.row_ptr = A->loc.row_ptr; a.col = A->loc.col; a.val = A->loc.val; a.n = A->M;
+    a.rhs = rhs; a.u = u; a.max_iter = h->prm.CG_coarsest_max_iter; a.tol = h->prm.CG_coarsest_tol;
+    a.iters_out = iters ? g.dint + 1 : nullptr;
+    hipLaunchKernelGGL(sk::k_coarse_cg, dim3(1), dim3(sk::CG_BLOCK), 0, g.cs, a);
+    HIPCHK(hipGetLastError());
+    if (iters) {
+        HIPCHK(hipMemcpyAsync(g.hint + 1, g.dint + 1, sizeof(int), hipMemcpyDeviceToHost, g.cs));
+        HIPCHK(hipStreamSynchronize(g.cs));
+        *iters = g.hint[1];
+    }
+    return SGPU_OK;
+}
+
+// solve_coarsest_CG with a row-partitioned coarsest operator: host-driven loop
+// over the distributed kernels (src/saena_object_solve.cpp:14-114).
+int coarse_cg_dist(sgpu_amg *h, sgpu_op *A, double *u, const double *rhs, int *iters) {
+    const size_t n = (size_t)A->M;
+    DevBuf res, dir, mt;
+    CHK(res.alloc(n)); CHK(dir.alloc(n)); CHK(mt.alloc(n));
+    CHK(sgpu_vec_copy(res.p, rhs, n)); CHK(sgpu_vec_copy(dir.p, rhs, n));
+    const double tol = h->prm.CG_coarsest_tol;
+    double initial_dot = 0, dot = 0, factor = 0, dot_prev = 0;
+    CHK(sgpu_dot(res.p, res.p, n, &initial_dot));
+    const double thres = initial_dot * tol * tol;
+    dot = initial_dot;
+    int max_iter = h->prm.CG_coarsest_max_iter;
+    if (dot < tol * tol) max_iter = 0;
+    int i = 1;
+    while (i < max_iter) {
+        CHK(sgpu_spmv(A, dir.p, mt.p));
+        CHK(sgpu_dot(dir.p, mt.p, n, &factor));
+        factor = dot / factor;
+        CHK(sgpu_vec_axpby(factor, dir.p, 1.0, u, n));
+        CHK(sgpu_vec_axpby(-factor, mt.p, 1.0, res.p, n));
+        dot_prev = dot;
+        CHK(sgpu_dot(res.p, res.p, n, &dot));
+        if (dot < thres) break;
+        factor = dot / dot_prev;
+        CHK(sgpu_vec_axpby(1.0, res.p, factor, dir.p, n));
+        i++;
+    }
+    if (i == max_iter && max_iter != 0) i--;
+    if (iters) *iters = i;
+    CHK(sgpu_device_sync());
+    return SGPU_OK;
+}
+
+int coarse_solve(sgpu_amg *h, double *u, const double *rhs, int *iters) {
+    sgpu_op *A = h->A[h->nlevels - 1];
+    if (g.nranks == 1) return coarse_cg_single(h, A, u, rhs, iters);
+    return coarse_cg_dist(h, A, u, rhs, iters);
+}
+
+int smooth_pp(sgpu_amg *h, int l, int iter, double *u, double *alt, const double *rhs, double **out) {
+    if (h->prm.smoother == 0) {
+        const double om = h->prm.jacobi_omega != 0.0 ? h->prm.jacobi_omega : JACOBI_OMEGA_REF;
+        return jacobi_pp(h->A[l], iter, om, u, alt, rhs, out);
+    }
+    return cheby_pp(h->A[l], iter, h->eig[l], u, alt, rhs, out);
+}
+
+// saena_object::vcycle (src/saena_object_solve.cpp:961-1431).  u/alt are the two
+// ping-pong buffers of this level; *out names the one holding the result.
+int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, double **out) {
+    if (l == h->nlevels - 1) {                             // :991-1057
+        CHK(coarse_solve(h, u, rhs, nullptr));
+        *out = u;
+        return SGPU_OK;
+    }
+    double *cur = u, *oth = alt, *t = nullptr;
+    if (h->prm.preSmooth) {                                // :1105-1107
+        CHK(smooth_pp(h, l, h->prm.preSmooth, cur, oth, rhs, &t));
+        if (t != cur) std::swap(cur, oth);
+    }
+    {                                                      // :1140 residual
+        EpiArgs e; e.rhs = rhs;
+        CHK(apply(h->A[l], sk::EPI_RESIDUAL, cur, h->res[l], e));
+    }
+    CHK(apply(h->R[l], sk::EPI_SPMV, h->res[l], h->rhs[l + 1], EpiArgs()));   // :1175
+    CHK(sgpu_vec_fill(h->u[l + 1], 0.0, (size_t)h->A[l + 1]->M));             // :1249
+    double *uc = nullptr;
+    CHK(vcycle_level(h, l + 1, h->u[l + 1], h->alt[l + 1], h->rhs[l + 1], &uc));   // :1254
+    CHK(apply(h->P[l], sk::EPI_SUB, uc, cur, EpiArgs()));                     // :1325 + :1360-1361
+    if (h->prm.postSmooth) {                               // :1397-1399
+        CHK(smooth_pp(h, l, h->prm.postSmooth, cur, oth, rhs, &t));
+        if (t != cur) std::swap(cur, oth);
+    }
+    *out = cur;
+    return SGPU_OK;
+}
+
+int vcycle0(sgpu_amg *h, double *u, const double *rhs) {
+    double *out = nullptr;
+    CHK(vcycle_level(h, 0, u, h->alt0, rhs, &out));
+    if (out != u) HIPCHK(hipMemcpyAsync(u, out, (size_t)h->A[0]->M * sizeof(double), hipMemcpyDeviceToDevice, g.cs));
+    return SGPU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int sgpu_amg_default_params(sgpu_amg_params *p) {
+    if (!p) return fail(SGPU_ERR_ARG, "null params");
+    p->preSmooth = 3; p->postSmooth = 3; p->smoother = 1;          /* saena.hpp:151-155: "chebyshev", 3, 3 */
+    p->jacobi_omega = 0.0; p->coarse_solver = 0;
+    p->CG_coarsest_max_iter = 150; p->CG_coarsest_tol = 1e-12;    /* saena_object.h:155-156 */
+    p->solver_max_iter = 100; p->solver_tol = 1e-8; p->use_graph = 0;
+    return SGPU_OK;
+}
+
+int sgpu_amg_create(int nlevels, sgpu_op *const *A, sgpu_op *const *P, sgpu_op *const *R, const value_t *eig_max,
+                    const sgpu_amg_params *params, sgpu_amg **out) {
+    CHK(need_ctx());
+    if (nlevels < 1 || !A || !out) return fail(SGPU_ERR_ARG, "bad hierarchy");
+    std::unique_ptr<sgpu_amg> h(new sgpu_amg());
+    h->nlevels = nlevels;
+    if (params) h->prm = *params; else sgpu_amg_default_params(&h->prm);
+    for (int l = 0; l < nlevels; ++l) {
+        if (!A[l]) return fail(SGPU_ERR_ARG, "A[%d] is null", l);
+        if (A[l]->M != A[l]->N_local) return fail(SGPU_ERR_ARG, "A[%d] is not square on this rank", l);
+        h->A.push_back(A[l]);
+        h->eig.push_back(eig_max ? eig_max[l] : 0.0);
+        if (l < nlevels - 1) {
+            if (!P || !R || !P[l] || !R[l]) return fail(SGPU_ERR_ARG, "P[%d]/R[%d] is null", l, l);
+            if (P[l]->M != A[l]->M || P[l]->N_local != A[l + 1]->M) return fail(SGPU_ERR_ARG, "P[%d] shape mismatch", l);
+            if (R[l]->M != A[l + 1]->M || R[l]->N_local != A[l]->M) return fail(SGPU_ERR_ARG, "R[%d] shape mismatch", l);
+            h->P.push_back(P[l]); h->R.push_back(R[l]);
+            if (!A[l]->inv_diag) return fail(SGPU_ERR_ARG, "A[%d] has no inv_diag", l);
+            if (h->prm.smoother == 1 && !(h->eig[l] > 0.0)) return fail(SGPU_ERR_ARG, "chebyshev needs eig_max[%d] > 0", l);
+        }
+    }
+    h->res.assign(nlevels, nullptr); h->rhs.assign(nlevels, nullptr); h->u.assign(nlevels, nullptr); h->alt.assign(nlevels, nullptr);
+    auto alloc = [](double **p, size_t n) { return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(1, n) * sizeof(double)); };
+    for (int l = 0; l < nlevels; ++l) {
+        const size_t n = (size_t)A[l]->M;
+        if (l < nlevels - 1) HIPCHK(alloc(&h->res[l], n));
+        if (l >= 1) { HIPCHK(alloc(&h->rhs[l], n)); HIPCHK(alloc(&h->u[l], n)); HIPCHK(alloc(&h->alt[l], n)); }
+    }
+    const size_t n0 = (size_t)A[0]->M;
+    HIPCHK(alloc(&h->alt0, n0));
+    HIPCHK(alloc(&h->r, n0)); HIPCHK(alloc(&h->rho, n0)); HIPCHK(alloc(&h->hh, n0)); HIPCHK(alloc(&h->p, n0));
+    *out = h.release();
+    return SGPU_OK;
+}
+
+int sgpu_amg_destroy(sgpu_amg *h) {
+    if (!h) return SGPU_OK;
+    if (g.live) hipDeviceSynchronize();
+    for (auto p : h->res) hipFree(p);
+    for (auto p : h->rhs) hipFree(p);
+    for (auto p : h->u) hipFree(p);
+    for (auto p : h->alt) hipFree(p);
+    hipFree(h->alt0); hipFree(h->r); hipFree(h->rho); hipFree(h->hh); hipFree(h->p);
+    delete h;
+    return SGPU_OK;
+}
+
+int sgpu_vcycle(sgpu_amg *h, value_t *u, const value_t *rhs) {
+    CHK(need_ctx());
+    if (!h || !u || !rhs) return fail(SGPU_ERR_ARG, "null argument");
+    return vcycle0(h, u, rhs);
+}
+
+int sgpu_coarsest_solve(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters) {
+    CHK(need_ctx());
+    if (!h || !u || !rhs) return fail(SGPU_ERR_ARG, "null argument");
+    return coarse_solve(h, u, rhs, iters);
+}
+
+// saena_object::solve (src/saena_object_solve.cpp:1883-2014)
+int sgpu_solve(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *hist, int cap) {
+    CHK(need_ctx());
+    if (!h || !u || !rhs) return fail(SGPU_ERR_ARG, "null argument");
+    sgpu_op *A = h->A[0];
+    const size_t sz = (size_t)A->M;
+    CHK(sgpu_vec_fill(u, 0.0, sz));                                   // :1926
+    CHK(sgpu_residual(A, u, rhs, h->r));                              // :1942
+    double init_dot = 0, current_dot = 0;
+    CHK(sgpu_dot(h->r, h->r, sz, &init_dot));
+    if (hist && cap > 0) hist[0] = std::sqrt(init_dot);
+    const double THRSHLD = init_dot * h->prm.solver_tol * h->prm.solver_tol;
+    int i = 0;
+    for (; i < h->prm.solver_max_iter; ++i) {                         // :1957-1970
+        CHK(vcycle0(h, u, rhs));
+        CHK(sgpu_residual(A, u, rhs, h->r));
+        CHK(sgpu_dot(h->r, h->r, sz, &current_dot));
+        if (hist && i + 1 < cap) hist[i + 1] = std::sqrt(current_dot);
+        if (current_dot < THRSHLD) break;
+    }
+    const bool conv = current_dot < THRSHLD;
+    if (i == h->prm.solver_max_iter) --i;
+    if (iters) *iters = i + 1;
+    return conv ? SGPU_OK : SGPU_ERR_NOCONV;
+}
+
+// saena_object::solve_pCG (src/saena_object_solve.cpp:2389-2801)
+int sgpu_solve_pCG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *hist, int cap) {
+    CHK(need_ctx());
+    if (!h || !u || !rhs) return fail(SGPU_ERR_ARG, "null argument");
+    sgpu_op *A = h->A[0];
+    const size_t sz = (size_t)A->M;
+    double *r = h->r, *rho = h->rho, *hh = h->hh, *p = h->p;
+    CHK(sgpu_vec_fill(u, 0.0, sz));                                   // :2482
+    CHK(sgpu_residual(A, u, rhs, r));                                 // :2497
+    double init_dot = 0, current_dot = 0;
+    CHK(sgpu_dot(r, r, sz, &init_dot));
+    if (hist && cap > 0) hist[0] = std::sqrt(init_dot);
+    CHK(sgpu_vec_fill(rho, 0.0, sz));
+    CHK(vcycle0(h, rho, r));                                          // :2536-2537
+    CHK(sgpu_vec_copy(p, rho, sz));
+    const double THRSHLD = init_dot * h->prm.solver_tol * h->prm.solver_tol;
+    double rho_res = 0, pdoth = 0, alpha = 0, beta = 0;
+    current_dot = init_dot;
+    int i = 0;
+    for (i = 0; i < h->prm.solver_max_iter; i++) {                    // :2565
+        CHK(sgpu_spmv(A, p, hh));                                     // :2571
+        CHK(sgpu_dot(r, rho, sz, &rho_res));                          // :2580
+        CHK(sgpu_dot(p, hh, sz, &pdoth));                             // :2581
+        alpha = rho_res / pdoth;
+        hipLaunchKernelGGL(sk::k_pcg_update, dim3(grid_for(2 * sz)), dim3(sk::BLOCK), 0, g.cs, alpha, p, hh, u, r, sz);   // :2593-2596
+        HIPCHK(hipGetLastError());
+        CHK(sgpu_dot(r, r, sz, &current_dot));                        // :2603
+        if (hist && i + 1 < cap) hist[i + 1] = std::sqrt(current_dot);
+        if (current_dot < THRSHLD) break;                             // :2620
+        CHK(sgpu_vec_fill(rho, 0.0, sz));                             // :2640
+        CHK(vcycle0(h, rho, r));                                      // :2641
+        CHK(sgpu_dot(r, rho, sz, &beta));                             // :2655
+        beta /= rho_res;
+        CHK(sgpu_vec_axpby(1.0, rho, beta, p, sz));                   // :2665-2667  p = rho + beta p
+    }
+    const bool conv = current_dot < THRSHLD;
+    if (i == h->prm.solver_max_iter) i--;
+    if (iters) *iters = i + 1;
+    return conv ? SGPU_OK : SGPU_ERR_NOCONV;
+}
+
+// ---- measurement ----
+int sgpu_algorithmic_bytes(const sgpu_op *op, int kind, int64_t *bytes) {
+    if (!op || !bytes) return fail(SGPU_ERR_ARG, "null argument");
+    const int64_t M = op->M, N = op->N_local, nnz = op->loc.nnz + op->rem.nnz;
+    int64_t b = 12 * nnz + 4 * (M + 1) + 8 * N + 8 * M;     // B_spmv, BASELINE.md section 3
+    if (kind == 1) b += 16 * M;                             // jacobi: rhs, inv_diag
+    else if (kind == 2) b += 8 * M;                         // residual: rhs
+    else if (kind == 3) b += 32 * M;                        // chebyshev step: rhs, inv_diag, d r/w
+    *bytes = b;
+    return SGPU_OK;
+}
+
+int sgpu_time_kernel(sgpu_op *op, int kind, const value_t *x, const value_t *rhs, value_t *y, int reps, float *ms) {
+    CHK(need_ctx());
+    if (!op || !x || !y || !ms || reps < 1) return fail(SGPU_ERR_ARG, "bad argument");
+    if (kind != 0 && !rhs) return fail(SGPU_ERR_ARG, "rhs needed");
+    if ((kind == 1 || kind == 3) && !op->inv_diag) return fail(SGPU_ERR_ARG, "operator has no inv_diag");
+    if (kind == 3) CHK(ensure_d(op));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g.cs));
+    for (int i = 0; i < reps; ++i) {
+        EpiArgs e; e.rhs = rhs; e.inv_diag = op->inv_diag; e.u = x; e.d = op->dvec;
+        int epi = sk::EPI_SPMV;
+        if (kind == 1) { epi = sk::EPI_JACOBI; e.c0 = JACOBI_OMEGA_REF; }
+        else if (kind == 2) epi = sk::EPI_RESIDUAL;
+        else if (kind == 3) { epi = sk::EPI_CHEBYK; e.c0 = 0.5; e.c1 = 0.25; }
+        int s = apply(op, epi, x, y, e);
+        if (s != SGPU_OK) { hipEventDestroy(e0); hipEventDestroy(e1); return s; }
+    }
+    HIPCHK(hipEventRecord(e1, g.cs));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms = t / reps;
+    return SGPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,281 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and
+against the compiled-reference golden fixtures.  Run with `-m gpu` on an MI355X.
+
+Tolerances (fp64):
+  * SpMV / transfer, 1 lane per row: BIT-EXACT vs the oracle (same products,
+    same sequential sum, no FMA on either side);
+  * SpMV with G>1 lanes per row or a remote part: |y - y_ref| <= 1e-13 * (|A||x|);
+  * smoothers (k <= 4 sweeps): relative l2 <= 1e-12; bit-exact at 1 lane/row, 1 rank.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import inputs, util
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_SPMV = 1e-13
+TOL_SMOOTH = 1e-12
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from saena_amd import capi as c
+    c.init(0)
+    return c
+
+
+def abs_bound(entries, Mbig, x):
+    b = np.zeros(Mbig)
+    np.add.at(b, entries["row"], np.abs(entries["val"] * x[entries["col"]]))
+    return b
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def problems():
+    out = {}
+    for m in (8, 12, 20):
+        out[f"poisson{m}"] = orc.laplacian3d(m)
+    out["band300_7"] = (orc.band_matrix(300, 7), 300)
+    out["band64_63"] = (orc.band_matrix(64, 63), 64)
+    out["band3000_1400"] = (orc.band_matrix(3000, 1400), 3000)      # rows longer than the LDS tile: long-row path
+    rng = np.random.default_rng(7)
+    M = 5000                                                         # irregular: empty rows, 1..300 nnz/row
+    lens = rng.choice([0, 1, 2, 3, 5, 9, 17, 40, 120, 300], size=M)
+    rows = np.repeat(np.arange(M), lens)
+    cols = np.concatenate([rng.choice(M, size=k, replace=False) for k in lens]) if rows.size else np.zeros(0, int)
+    vals = rng.standard_normal(rows.size)
+    d = np.arange(M)
+    rows = np.concatenate([rows, d]); cols = np.concatenate([cols, d]); vals = np.concatenate([vals, 50 + rng.random(M)])
+    key = rows.astype(np.int64) * M + cols
+    _, first = np.unique(key, return_index=True)
+    out["irregular5000"] = (orc.coo_from_arrays(rows[first].astype(np.int32), cols[first].astype(np.int32), vals[first]), M)
+    return out
+
+
+PROBLEMS = None
+
+
+def get_problem(name):
+    global PROBLEMS
+    if PROBLEMS is None:
+        PROBLEMS = problems()
+    return PROBLEMS[name]
+
+
+NAMES = ["poisson8", "poisson12", "poisson20", "band300_7", "band64_63", "band3000_1400", "irregular5000"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_spmv_bitexact_one_lane(capi, name):
+    entries, M = get_problem(name)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    G.set_lanes_per_row(1)
+    x = inputs.v2(M)
+    want = A.matvec(x)
+    dx, dy = capi.DeviceVector(M, x), capi.DeviceVector(M)
+    G.spmv(dx, dy)
+    got = dy.download()
+    if name == "band3000_1400":        # long rows are tree-reduced by the whole workgroup
+        assert np.all(np.abs(got - want) <= TOL_SPMV * abs_bound(entries, M, x))
+    else:
+        np.testing.assert_array_equal(got, want)
+    # host-slice form of the reference seam (const value_t* v, value_t* w)
+    np.testing.assert_array_equal(G.spmv_host(x), got)
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("lanes", [0, 2, 4, 8, 16, 32, 64])
+def test_spmv_lane_variants(capi, name, lanes):
+    entries, M = get_problem(name)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    G.set_lanes_per_row(lanes)
+    x = inputs.v2(M)
+    want = A.matvec(x)
+    dx, dy = capi.DeviceVector(M, x), capi.DeviceVector(M)
+    G.spmv(dx, dy)
+    got = dy.download()
+    assert np.all(np.abs(got - want) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
+
+
+@pytest.mark.parametrize("name", ["poisson12", "poisson20", "band300_7", "irregular5000"])
+def test_residual_jacobi_chebyshev(capi, name):
+    entries, M = get_problem(name)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    G.set_lanes_per_row(1)
+    u0, rhs = inputs.v2(M), inputs.rhs2(M)
+    du, dr, dres = capi.DeviceVector(M, u0), capi.DeviceVector(M, rhs), capi.DeviceVector(M)
+    G.residual(du, dr, dres)
+    np.testing.assert_array_equal(dres.download(), A.residual(u0, rhs))
+    for it in (1, 2, 3, 4):
+        du.upload(u0)
+        G.jacobi(it, du, dr)
+        np.testing.assert_array_equal(du.download(), A.jacobi(it, u0, rhs))      # bit-exact at 1 lane/row
+    A.set_eig(1.9371)
+    for it in (1, 2, 3, 4):
+        du.upload(u0)
+        G.chebyshev(it, 1.9371, du, dr)
+        np.testing.assert_array_equal(du.download(), A.chebyshev(it, u0, rhs))
+    # auto lanes: rounding-level agreement
+    G.set_lanes_per_row(0)
+    du.upload(u0)
+    G.jacobi(3, du, dr)
+    assert rel(du.download(), A.jacobi(3, u0, rhs)) <= TOL_SMOOTH
+
+
+@pytest.mark.parametrize("fn", sorted(glob.glob(os.path.join(GOLDEN, "ref_*.np1.npz"))), ids=os.path.basename)
+def test_against_compiled_reference_golden(capi, fn):
+    """Same checks as tests/test_oracle_pins.py, with the GPU in the oracle's place."""
+    tag = os.path.basename(fn)[4:].split(".")[0]
+    ref = dict(np.load(fn))
+    if tag.startswith("poisson"):
+        entries, M = orc.laplacian3d(int(tag[7:]))
+    else:
+        m_, bw = tag[4:].split("_")
+        entries, M = orc.band_matrix(int(m_), int(bw)), int(m_)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    v, v2, rhs2 = inputs.v_sin(M), inputs.v2(M), inputs.rhs2(M)
+    dx, dy, dr = capi.DeviceVector(M, v), capi.DeviceVector(M), capi.DeviceVector(M, rhs2)
+    G.spmv(dx, dy)
+    assert np.all(np.abs(dy.download() - ref["Av"]) <= TOL_SPMV * abs_bound(entries, M, v))
+    dx.upload(v2)
+    G.spmv(dx, dy)
+    assert np.all(np.abs(dy.download() - ref["Av2"]) <= TOL_SPMV * abs_bound(entries, M, v2))
+    G.residual(dx, dr, dy)
+    assert rel(dy.download(), ref["residual_v2_rhs2"]) <= TOL_SMOOTH
+    du = capi.DeviceVector(M, np.zeros(M))
+    ones = capi.DeviceVector(M, np.ones(M))
+    G.jacobi(3, du, ones)
+    assert rel(du.download(), ref["jacobi3_rhs1"]) <= TOL_SMOOTH
+    du.upload(v2)
+    G.jacobi(2, du, dr)
+    assert rel(du.download(), ref["jacobi2_v2_rhs2"]) <= TOL_SMOOTH
+    du.fill(0.0)
+    G.chebyshev(3, 2.0, du, ones)
+    assert rel(du.download(), ref["cheby3_rhs1"]) <= TOL_SMOOTH
+    du.upload(v2)
+    G.chebyshev(4, 1.9371, du, dr)
+    assert rel(du.download(), ref["cheby4_v2_rhs2"]) <= TOL_SMOOTH
+    # grid transfers R v, P e and the fused u -= P e
+    pr, pc, pv, Nc = inputs.synthetic_P(M)
+    P = orc.OracleOp(orc.coo_from_arrays(pr, pc, pv), M, Nc, orc.split_even(M, 1), orc.split_even(Nc, 1), square=False)
+    R = orc.OracleOp(orc.coo_from_arrays(pc, pr, pv), Nc, M, orc.split_even(Nc, 1), orc.split_even(M, 1), square=False)
+    GP, GR = util.gpu_operator(P), util.gpu_operator(R)
+    ec = inputs.ec(Nc)
+    dec, dpf, drc = capi.DeviceVector(Nc, ec), capi.DeviceVector(M), capi.DeviceVector(Nc)
+    GP.spmv(dec, dpf)
+    assert rel(dpf.download(), ref["P_ec"]) <= 1e-14
+    GR.spmv(dx, drc)
+    assert rel(drc.download(), ref["R_v2"]) <= 1e-14
+    du.upload(v2)
+    GP.prolong_correct(dec, du)
+    assert rel(du.download(), v2 - ref["P_ec"]) <= 1e-14
+
+
+@pytest.mark.parametrize("name,nprocs", [("poisson12", 2), ("poisson12", 4), ("poisson20", 3), ("band300_7", 4),
+                                         ("band64_63", 2), ("irregular5000", 5)])
+@pytest.mark.parametrize("fp32", [False, True])
+def test_halo_path_emulated_ranks(capi, name, nprocs, fp32):
+    """pack kernel + remote-CSR kernel + remote epilogues, P simulated ranks on one GPU."""
+    entries, M = get_problem(name)
+    split = orc.split_nnz(entries, M, nprocs)
+    A = orc.OracleOp(entries, M, M, split)
+    A.set_use_double(not fp32)
+    W = util.EmulatedWorld(A, halo_fp32=fp32)
+    x, rhs = inputs.v2(M), inputs.rhs2(M)
+    bound = abs_bound(entries, M, x)
+    xs, ys, rs = W.slices(x, split), W.slices(np.zeros(M), split), W.slices(rhs, split)
+    W.exchange(xs)
+    for r in range(nprocs):
+        W.g[r].spmv(xs[r], ys[r])
+    assert np.all(np.abs(W.gather(ys) - A.matvec(x)) <= TOL_SPMV * bound + 1e-300)
+    for r in range(nprocs):
+        W.g[r].residual(xs[r], rs[r], ys[r])
+    assert rel(W.gather(ys), A.residual(x, rhs)) <= TOL_SMOOTH
+    # smoother sweeps, re-exchanging the halo before each sweep like the reference's matvec does
+    us = W.slices(x, split)
+    for sweep in range(2):
+        W.exchange(us)
+        for r in range(nprocs):
+            W.g[r].jacobi(1, us[r], rs[r])
+    assert rel(W.gather(us), A.jacobi(2, x, rhs)) <= TOL_SMOOTH
+    if not fp32:
+        A.set_eig(1.9371)
+        us = W.slices(x, split)
+        W.exchange(us)
+        for r in range(nprocs):
+            W.g[r].chebyshev(1, 1.9371, us[r], rs[r])
+        assert rel(W.gather(us), A.chebyshev(1, x, rhs)) <= TOL_SMOOTH
+
+
+def test_rectangular_transfer_emulated_ranks(capi):
+    """R (coarse rows, fine halo) and P (fine rows, coarse halo) with remote parts."""
+    M = 1000
+    pr, pc, pv, Nc = inputs.synthetic_P(M)
+    for nprocs in (2, 4):
+        split = orc.split_even(M, nprocs)
+        splitNew = (split // 2).astype(np.int32); splitNew[-1] = Nc
+        P = orc.OracleOp(orc.coo_from_arrays(pr, pc, pv), M, Nc, split, splitNew, square=False)
+        R = orc.OracleOp(orc.coo_from_arrays(pc, pr, pv), Nc, M, splitNew, split, square=False)
+        ec, res, u = inputs.ec(Nc), inputs.v2(M), inputs.rhs2(M)
+        WP, WR = util.EmulatedWorld(P), util.EmulatedWorld(R)
+        es, fs = WP.slices(ec, splitNew), WP.slices(np.zeros(M), split)
+        WP.exchange(es)
+        for r in range(nprocs):
+            WP.g[r].spmv(es[r], fs[r])
+        assert rel(WP.gather(fs), P.matvec(ec)) <= 1e-14
+        us = WP.slices(u, split)
+        for r in range(nprocs):
+            WP.g[r].prolong_correct(es[r], us[r])
+        assert rel(WP.gather(us), u - P.matvec(ec)) <= 1e-14
+        rs_, cs = WR.slices(res, split), WR.slices(np.zeros(Nc), splitNew)
+        WR.exchange(rs_)
+        for r in range(nprocs):
+            WR.g[r].spmv(rs_[r], cs[r])
+        assert rel(WR.gather(cs), R.matvec(res)) <= 1e-14
+
+
+def test_vector_kernels(capi):
+    n = 100003
+    x, y = inputs.v2(n), inputs.rhs2(n)
+    dx, dy = capi.DeviceVector(n, x), capi.DeviceVector(n, y)
+    d = capi.dot(dx, dy)
+    assert abs(d - np.dot(x, y)) <= 1e-12 * np.sum(np.abs(x * y))
+    capi.check(capi.lib().sgpu_vec_axpby(2.5, dx.ptr, -0.5, dy.ptr, n))
+    np.testing.assert_array_equal(dy.download(), 2.5 * x + -0.5 * y)
+    dy.fill(3.25)
+    assert np.all(dy.download() == 3.25)
+    # determinism: the dot is reduced in a fixed order
+    assert capi.dot(dx, dx) == capi.dot(dx, dx)
+
+
+def test_error_codes_not_exit(capi):
+    """The reference prints and exit()s on bad input; the C ABI returns codes."""
+    with pytest.raises(capi.SgpuError):
+        capi.Operator(M=3, N_local=3, col_offset=0, nnzPerRow_local=[1, 1, 1], col_local=[0, 1, 7], val_local=[1, 1, 1.0])
+    with pytest.raises(capi.SgpuError):
+        capi.Operator(M=3, N_local=3, col_offset=0, nnzPerRow_local=[1, 1, 2], col_local=[0, 1, 2], val_local=[1, 1, 1.0])
+    A = capi.Operator(M=2, N_local=2, col_offset=0, nnzPerRow_local=[1, 1], col_local=[0, 1], val_local=[2.0, 4.0])
+    v = capi.DeviceVector(2, [1.0, 1.0])
+    with pytest.raises(capi.SgpuError):
+        A.jacobi(1, v, v)               # no inv_diag
+    # empty operator / empty rows
+    E = capi.Operator(M=0, N_local=0, col_offset=0, nnzPerRow_local=[], col_local=[], val_local=[])
+    e = capi.DeviceVector(0)
+    E.spmv(e, e)
+    Z = capi.Operator(M=3, N_local=3, col_offset=0, nnzPerRow_local=[0, 2, 0], col_local=[0, 2], val_local=[1.5, -2.0])
+    dx, dy = capi.DeviceVector(3, [1.0, 2.0, 3.0]), capi.DeviceVector(3, [9.0, 9.0, 9.0])
+    Z.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), [0.0, -4.5, 0.0])
