@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- fine-level SpMV of the Saena V-cycle hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is
+launched by torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE/
+MASTER_* from the env).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): 3D 7-point Poisson 128^3 -> 126^3 = 2 000 376
+rows, 13 907 376 nnz, fp64 values / int32 indices, operator and vectors resident
+in HBM.  A step = one fine-level SpMV w = A v through sgpu_spmv (the HIP kernel
+k_csr_stream plus, for N>1, the RCCL halo exchange on the second stream).
+value = algorithmic bytes of all ranks' SpMVs / wall time.
+N>1 is weak scaling: every rank owns a 126-plane z-slab of a 128 x 128 x (126 N + 2)
+grid (2 000 376 rows per rank), neighbours exchange one 126^2 plane per side.
+
+Extra objects: `roofline` (HBM bound; kernel time from HIP events recorded on the
+compute stream around the timed launches) and `cpu_baseline` (the CPU restatement
+of the reference's matvec -- oracle/, test infrastructure -- timed on this box's
+cores, rank 0, N=1 only; never part of the measured path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--m", type=int, default=128, help="grid points per side (reference laplacian3D argument)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(m, seconds):
+    """Oracle (CPU restatement of saena_matrix::matvec) on this box's cores: P simulated MPI
+    ranks on P threads, the reference's default of one thread per rank."""
+    import numpy as np
+    from oracle import oracle as orc
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    entries, Mbig = orc.laplacian3d(m)
+    split = orc.split_nnz(entries, Mbig, cores)
+    A = orc.OracleOp(entries, Mbig, Mbig, split)
+    v = np.sin(0.001 * np.arange(Mbig))
+    t1 = A.time_matvec(v, 3, cores)
+    reps = max(5, int(seconds / max(t1, 1e-6)))
+    t = A.time_matvec(v, reps, cores)
+    nnz = len(entries)
+    B = 12 * nnz + 4 * (Mbig + 1) + 16 * Mbig
+    return {"value": round(B / t / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} matvecs of the same Poisson {m}^3 operator, {cores} simulated ranks on {cores} threads "
+                      f"(oracle/saena_oracle.c, -O2), {t * 1e3:.3f} ms each"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    dist = None
+    if world > 1 or os.environ.get("SAENA_BENCH_IMPORT_TORCH"):
+        # torch first: its bundled HIP/RCCL runtime must be the one both sides use
+        import torch  # noqa: F401
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)   # CPU rendezvous only; data rides RCCL
+
+    import numpy as np
+    from saena_amd import capi, host
+
+    uid = None
+    if world > 1:
+        box = [capi.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    capi.init(device=local_rank, rank=rank, nranks=world, unique_id=uid)
+
+    # ---- operator through the host mirror of saena::matrix (product path, no oracle) ----
+    m = args.m
+    comm = host.Comm("gpu", "rccl")
+    A = host.Matrix(comm)
+    if world == 1:
+        A.laplacian3D(m).assemble()                      # reference partitioner (trivial at one rank)
+    else:
+        n = m - 2
+        A.laplacian3D(m, m, n * world + 2)
+        split = np.array([r * n * n * n for r in range(world + 1)], np.int32)
+        A.assemble(split)                                # even z-slabs: 126 planes per rank
+    op = host.device_operator(A)
+    info = op.info()
+    M = info["M"]
+    g0 = int(A.split[rank])
+    x = capi.DeviceVector(M, np.sin(0.001 * (g0 + np.arange(M))))
+    y = capi.DeviceVector(M)
+    B_local = op.algorithmic_bytes(0)
+
+    def sync_all():
+        capi.check(capi.lib().sgpu_barrier())
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warm-up, then EXACTLY K timed steps between barriers ----
+    for _ in range(args.warmup):
+        op.spmv(x, y)
+    sync_all()
+    t0 = time.perf_counter()
+    ms_kernel = op.time_kernel(0, x, None, y, args.steps)   # K launches, HIP events on the compute stream
+    capi.check(capi.lib().sgpu_device_sync())
+    sync_all()
+    wall = time.perf_counter() - t0
+
+    B_total = B_local
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+        b = torch.tensor([float(B_local)], dtype=torch.float64)
+        dist.all_reduce(b)
+        B_total = float(b[0])
+
+    if rank == 0:
+        sec_per_step = wall / args.steps
+        achieved = B_local / (ms_kernel * 1e-3) / 1e9
+        out = {
+            "metric": "fine-level SpMV effective GB/s (3D 7-pt Poisson 128^3, fp64)",
+            "value": round(B_total / sec_per_step / 1e9, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(sec_per_step * 1e3, 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Poisson {m}^3 (Saena laplacian3D, boundary rows removed): SpMV w=Av, "
+                            f"{info['M']} rows x {info['nnz_local'] + info['nnz_remote']} nnz per GPU, int32 indices",
+                "rows_per_gpu": info["M"], "nnz_per_gpu": info["nnz_local"] + info["nnz_remote"],
+                "partition": "1 rank" if world == 1 else f"{world} even z-slabs, RCCL halo of {n * n} doubles per side",
+                "pct_of_hbm_peak": round(B_total / sec_per_step / 1e9 / (HBM_PEAK_GBS * world) * 100, 2),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_csr_stream<EPI_SPMV,1>",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "us_per_launch": round(ms_kernel * 1e3, 3), "algorithmic_bytes": B_local,
+                "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(m, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    capi.finalize()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+/*
+ * saena_c.h -- flat C view of the host-side mirror of Saena's public surface
+ * (include/saena.hpp in this repository; reference: include/saena.hpp:14-265).
+ *
+ * The reference's users write C++ (saena::matrix A(comm); A.set(...);
+ * A.assemble(); saena::amg s; s.set_matrix(&A,&opts); s.solve_pCG(u,&opts)).
+ * This header exposes the same steps with plain pointers so that ctypes / cgo
+ * style callers -- and this repository's tests and bench.py -- can drive them.
+ * Host-only functions live in libsaena_host.so (no GPU needed) and again in
+ * libsaena_amd.so; functions marked [GPU] exist only in libsaena_amd.so.
+ * All return 0 on success, negative on error (saena_last_error() has the text).
+ */
+#ifndef SAENA_C_H
+#define SAENA_C_H
+
+#include "saena_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *saena_last_error(void);
+
+/* ---- communicator for the setup-time exchanges (the reference: MPI_Comm) ---- */
+typedef struct saena_comm saena_comm;
+typedef int (*saena_cb_allgather)(void *user, const void *send, void *recv, size_t bytes);
+typedef int (*saena_cb_alltoallv)(void *user, const void *send, const size_t *scounts, const size_t *sdispls,
+                                  void *recv, const size_t *rcounts, const size_t *rdispls);
+typedef int (*saena_cb_allreduce_i64)(void *user, long *v, int n);
+typedef int (*saena_cb_allreduce_f64)(void *user, double *v, int n);
+
+saena_comm *saena_comm_self(void);
+saena_comm *saena_comm_callbacks(int rank, int nranks, void *user, saena_cb_allgather, saena_cb_alltoallv,
+                                 saena_cb_allreduce_i64, saena_cb_allreduce_f64);
+saena_comm *saena_comm_rccl(void);            /* [GPU] the sgpu_init() communicator */
+void        saena_comm_free(saena_comm *);
+
+/* ---- saena::matrix (reference include/saena.hpp:14-73) ---- */
+typedef struct saena_matrix_h saena_matrix_h;
+saena_matrix_h *saena_matrix_new(saena_comm *comm);
+void  saena_matrix_free(saena_matrix_h *A);
+int   saena_matrix_set(saena_matrix_h *A, index_t i, index_t j, value_t val);                       /* saena.hpp:29 */
+int   saena_matrix_set_many(saena_matrix_h *A, const index_t *row, const index_t *col, const value_t *val, nnz_t n); /* :30 */
+int   saena_matrix_set_remove_boundary(saena_matrix_h *A, int remove_bound);                        /* :44 */
+int   saena_matrix_add_duplicates(saena_matrix_h *A, int add);                                      /* :47 */
+int   saena_matrix_set_eig(saena_matrix_h *A, double eig);                                          /* :38 (value form) */
+int   saena_matrix_assemble(saena_matrix_h *A);                                                     /* :49 */
+int   saena_matrix_assemble_with_split(saena_matrix_h *A, const index_t *split);
+index_t saena_matrix_get_num_rows(saena_matrix_h *A);                                               /* :57 */
+index_t saena_matrix_get_num_local_rows(saena_matrix_h *A);                                         /* :58 */
+nnz_t   saena_matrix_get_nnz(saena_matrix_h *A);                                                    /* :59 */
+nnz_t   saena_matrix_get_local_nnz(saena_matrix_h *A);                                              /* :60 */
+int   saena_matrix_get_split(saena_matrix_h *A, index_t *split_out /* nranks+1 */);
+/* this rank's arrays in the reference's storage layout; pointers stay valid while A lives */
+int   saena_matrix_get_desc(saena_matrix_h *A, sgpu_op_desc *out);
+/* remaining layout arrays not part of sgpu_op_desc, for layout tests: col_remote[nnz_l_remote], nnzPerProcScan[nranks+1] */
+int   saena_matrix_get_layout_extra(saena_matrix_h *A, const index_t **col_remote, const nnz_t **nnzPerProcScan);
+
+/* generators (reference src/aux_functions2.cpp:254-373, :629-700, :1296-1381) */
+int   saena_laplacian3D(saena_matrix_h *A, index_t mx, index_t my, index_t mz);
+/* rhs of the assembled interior system, this rank's slice (length get_num_local_rows) */
+int   saena_laplacian3D_set_rhs(saena_matrix_h *A, index_t mx, index_t my, index_t mz, value_t *rhs_local);
+int   saena_band_matrix(saena_matrix_h *A, index_t M, unsigned int bandwidth);
+
+/* ---- transfer operators (prolong_matrix / restrict_matrix) ---- */
+typedef struct saena_transfer_h saena_transfer_h;
+/* rows/cols are GLOBAL ids of this rank's fine rows; split_row = fine partition, split_col = coarse partition */
+saena_transfer_h *saena_prolong_new(saena_comm *comm, index_t Mbig, index_t Nbig, const index_t *split_row,
+                                    const index_t *split_col, const index_t *row, const index_t *col,
+                                    const value_t *val, nnz_t n);
+saena_transfer_h *saena_restrict_from_prolong(saena_transfer_h *P);       /* restrict_matrix::transposeP */
+void  saena_transfer_free(saena_transfer_h *T);
+int   saena_transfer_get_desc(saena_transfer_h *T, sgpu_op_desc *out);
+nnz_t saena_transfer_get_local_nnz(saena_transfer_h *T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,403 @@
+// saena_matrix.cpp -- host-side assembly of the distributed operators.
+// Restates, with our own data structures, what the reference does between
+// saena::matrix::set() and the first matvec (citations: file:line in paralab/Saena).
+#include "saena_matrix.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace saena_host {
+
+long lower_bound2(const index_t *left, const index_t *right, index_t val) {
+    // aux_functions.h:39-58: position p with split[p] <= val < split[p+1]
+    const index_t *first = left;
+    const index_t *it = std::upper_bound(left, right + 1, val);   // first element > val
+    return (it - first) - 1;
+}
+
+static int owner_of(const std::vector<index_t> &split, index_t id) {
+    const int np = (int)split.size() - 1;
+    long p = lower_bound2(split.data(), split.data() + np, id);
+    // empty blocks share a boundary value: settle on the block that really contains id
+    while (p < np - 1 && split[p + 1] <= id) ++p;
+    while (p > 0 && split[p] > id) --p;
+    return (int)p;
+}
+
+// send each record to the rank owning key(record); returns what this rank receives
+template <class T, class KeyFn>
+static std::vector<T> route(Comm &comm, const std::vector<T> &recs, const std::vector<index_t> &split, KeyFn key) {
+    const int np = comm.nranks;
+    if (np == 1) return recs;
+    std::vector<int> cnt((size_t)np, 0), dest(recs.size());
+    for (size_t i = 0; i < recs.size(); ++i) { dest[i] = owner_of(split, key(recs[i])); cnt[dest[i]]++; }
+    std::vector<size_t> off((size_t)np + 1, 0);
+    for (int p = 0; p < np; ++p) off[p + 1] = off[p] + cnt[p];
+    std::vector<T> send(recs.size());
+    std::vector<size_t> fill(off.begin(), off.end() - 1);
+    for (size_t i = 0; i < recs.size(); ++i) send[fill[dest[i]]++] = recs[i];
+    return comm.alltoallv_records(send, cnt);
+}
+
+// every rank's list, concatenated in rank order, on every rank
+template <class T>
+static std::vector<T> allgatherv(Comm &comm, const std::vector<T> &mine) {
+    const int np = comm.nranks;
+    if (np == 1) return mine;
+    std::vector<int> counts = comm.allgather_one((int)mine.size());
+    std::vector<size_t> sc((size_t)np, mine.size() * sizeof(T)), sd((size_t)np, 0), rc((size_t)np), rd((size_t)np);
+    size_t tot = 0;
+    for (int p = 0; p < np; ++p) { rc[p] = (size_t)counts[p] * sizeof(T); rd[p] = tot; tot += rc[p]; }
+    std::vector<T> all(tot / sizeof(T));
+    comm.alltoallv(mine.data(), sc.data(), sd.data(), all.data(), rc.data(), rd.data());
+    return all;
+}
+
+// ---------------------------------------------------------------------------
+int saena_matrix::set(index_t row, index_t col, value_t val) {
+    data_in.emplace_back(row, col, val);
+    return 0;
+}
+int saena_matrix::set(const index_t *row, const index_t *col, const value_t *val, nnz_t n) {
+    data_in.reserve(data_in.size() + (size_t)n);
+    for (nnz_t i = 0; i < n; ++i) data_in.emplace_back(row[i], col[i], val[i]);
+    return 0;
+}
+
+// setup_initial_data (saena_matrix_setup.cpp:62-116): remove_duplicates (:118-200)
+// then remove_boundary_nodes (:281-365).
+void saena_matrix::setup_initial_data() {
+    Comm &c = *comm;
+    const int np = c.nranks;
+    // global row count = largest row index + 1 (:126-128)
+    long mx = -1;
+    for (const auto &e : data_in) mx = std::max<long>(mx, std::max(e.row, e.col));
+    Mbig_with_bound = (index_t)(c.max_(mx) + 1);
+    if (Mbig_with_bound <= 0) throw std::runtime_error("saena_matrix: no entries were set");
+    // even row split (:130-135) and exchange so every rank holds whole rows
+    std::vector<index_t> split0((size_t)np + 1);
+    const index_t ofst = Mbig_with_bound / np;
+    for (int i = 0; i < np; ++i) split0[i] = i * ofst;
+    split0[np] = Mbig_with_bound;
+    std::vector<cooEntry> mine = route(c, data_in, split0, [](const cooEntry &e) { return e.row; });
+    data_in.clear(); data_in.shrink_to_fit();
+    std::stable_sort(mine.begin(), mine.end(), row_major);
+    // duplicates: add or keep the last one; drop |val| <= ALMOST_ZERO (:147-165)
+    std::vector<cooEntry> wb;
+    wb.reserve(mine.size());
+    for (size_t i = 0; i < mine.size(); ++i) {
+        value_t tmp = mine[i].val;
+        while (i + 1 < mine.size() && mine[i + 1].row == mine[i].row && mine[i + 1].col == mine[i].col) {
+            ++i;
+            tmp = add_duplicates ? tmp + mine[i].val : mine[i].val;
+        }
+        if (std::fabs(tmp) > SAENA_ALMOST_ZERO) wb.emplace_back(mine[i].row, mine[i].col, tmp);
+    }
+    mine.clear(); mine.shrink_to_fit();
+
+    bound_row_global.clear();
+    Mbig = Mbig_with_bound;
+    if (remove_boundary) {
+        // a row with a single entry is a boundary node (:300-330)
+        std::vector<index_t> bnd;
+        for (size_t i = 0; i < wb.size();) {
+            size_t j = i + 1;
+            while (j < wb.size() && wb[j].row == wb[i].row) ++j;
+            if (j - i == 1) {
+                if (wb[i].row != wb[i].col) throw std::runtime_error("saena_matrix: single-entry row is not diagonal (boundary removal)");
+                bnd.push_back(wb[i].row);
+            }
+            i = j;
+        }
+        bound_row_global = allgatherv(c, bnd);          // rank order == ascending row order
+        if (bound_row_global.empty()) {
+            remove_boundary = false;                     // :332-335
+        } else {
+            const auto &B = bound_row_global;
+            auto new_idx = [&B](index_t x) { return x - (index_t)(std::lower_bound(B.begin(), B.end(), x) - B.begin()); };
+            auto is_bnd = [&B](index_t x) { return std::binary_search(B.begin(), B.end(), x); };
+            std::vector<cooEntry> in;
+            in.reserve(wb.size());
+            for (const auto &e : wb) {
+                if (is_bnd(e.row)) continue;
+                if (is_bnd(e.col)) throw std::runtime_error("saena_matrix: interior row couples to a removed boundary node");
+                in.emplace_back(new_idx(e.row), new_idx(e.col), e.val);
+            }
+            wb.swap(in);
+            Mbig = Mbig_with_bound - (index_t)B.size();
+        }
+    }
+    entry.swap(wb);      // row-major, whole rows, global (renumbered) ids; ownership still by split0
+    nnz_l = (nnz_t)entry.size();
+    nnz_g = c.sum(nnz_l);
+}
+
+// repartition_nnz_initial (saena_matrix_repart.cpp:43-170): nprocs^2 near-equal
+// row buckets, merged left to right until a rank holds ~nnz_g/nprocs entries.
+void saena_matrix::repartition_nnz_initial() {
+    Comm &c = *comm;
+    const int nprocs = c.nranks;
+    split.assign((size_t)nprocs + 1, 0);
+    if (nprocs == 1) {
+        split[1] = Mbig;
+    } else {
+        int n_buckets;
+        if (Mbig > nprocs * nprocs) n_buckets = nprocs < 1000 ? nprocs * nprocs : 1000 * nprocs;
+        else if (nprocs <= Mbig) n_buckets = Mbig;
+        else throw std::runtime_error("number of tasks cannot be greater than the number of rows of the matrix.");
+        std::vector<index_t> splitOffset((size_t)n_buckets, 0);
+        const index_t baseOffset = (index_t)std::floor(1.0 * Mbig / n_buckets);
+        const float offsetRes = float(1.0 * Mbig / n_buckets) - baseOffset;
+        float offsetResSum = 0;
+        for (index_t i = 1; i < n_buckets; ++i) {
+            splitOffset[i] = baseOffset;
+            offsetResSum += offsetRes;
+            if (offsetResSum >= 1) { splitOffset[i]++; offsetResSum -= 1; }
+        }
+        std::vector<index_t> firstSplit((size_t)n_buckets + 1, 0);
+        for (index_t i = 1; i < n_buckets; ++i) firstSplit[i] = firstSplit[i - 1] + splitOffset[i];
+        firstSplit[n_buckets] = Mbig;
+        std::vector<long> H((size_t)n_buckets, 0);
+        for (const auto &e : entry) H[lower_bound2(firstSplit.data(), firstSplit.data() + n_buckets, e.row)]++;
+        c.allreduce_sum_i64(H.data(), n_buckets);
+        for (int i = 1; i < n_buckets; ++i) H[i] += H[i - 1];
+        const nnz_t NNZ_PROC = nnz_g / nprocs;
+        index_t procNum = 0;
+        for (nnz_t i = 1; i < n_buckets; ++i) {
+            if (Mbig - firstSplit[i + 1] < nprocs - (procNum + 1)) {
+                for (; i < n_buckets; ++i) { procNum++; split[procNum] = firstSplit[i]; }
+                break;
+            }
+            if (H[i] > (procNum + 1) * NNZ_PROC) { ++procNum; split[procNum] = firstSplit[i]; }
+        }
+        split[nprocs] = Mbig;
+    }
+    // move the entries to their owners (saena_matrix_repart.cpp:293 MPI_Alltoallv) and sort column-major
+    entry = route(c, entry, split, [](const cooEntry &e) { return e.row; });
+    std::sort(entry.begin(), entry.end(), col_major);
+    M = split[c.rank + 1] - split[c.rank];
+    nnz_l = (nnz_t)entry.size();
+}
+
+// inverse_diag (saena_matrix_setup.cpp:1562-1600)
+void saena_matrix::inverse_diag() {
+    inv_diag.assign((size_t)M, 1.0);
+    const index_t ofs = split[comm->rank];
+    for (const auto &e : entry)
+        if (e.row == e.col) {
+            if (std::fabs(e.val) < SAENA_ALMOST_ZERO)
+                throw std::runtime_error("there is a zero diagonal element at row index = " + std::to_string(e.row));
+            inv_diag[e.row - ofs] = 1.0 / e.val;
+        }
+}
+
+void saena_matrix::matrix_setup() {            // saena_matrix_setup.cpp:507-560
+    inverse_diag();
+    L.build(*comm, entry, split, split);
+    assembled = true;
+}
+
+int saena_matrix::assemble() {                 // saena_matrix_setup.cpp:4-17
+    setup_initial_data();
+    repartition_nnz_initial();
+    matrix_setup();
+    return 0;
+}
+
+int saena_matrix::assemble_with_split(const std::vector<index_t> &split_in) {
+    Comm &c = *comm;
+    if ((int)split_in.size() != c.nranks + 1) throw std::runtime_error("assemble_with_split: split has the wrong length");
+    setup_initial_data();
+    if (split_in.back() != Mbig) throw std::runtime_error("assemble_with_split: split does not cover the matrix");
+    split = split_in;
+    entry = route(c, entry, split, [](const cooEntry &e) { return e.row; });
+    std::sort(entry.begin(), entry.end(), col_major);
+    M = split[c.rank + 1] - split[c.rank];
+    nnz_l = (nnz_t)entry.size();
+    matrix_setup();
+    return 0;
+}
+
+std::vector<value_t> saena_matrix::remove_boundary_rhs(const std::vector<value_t> &v, index_t lo) const {
+    // remove_boundary_rhs (saena_object.cpp:699-730): boundary rows are dropped, the rest keeps its order
+    if (bound_row_global.empty()) return v;
+    std::vector<value_t> out;
+    out.reserve(v.size());
+    const auto &B = bound_row_global;
+    auto it = std::lower_bound(B.begin(), B.end(), lo);
+    for (size_t i = 0; i < v.size(); ++i) {
+        const index_t g = lo + (index_t)i;
+        if (it != B.end() && *it == g) { ++it; continue; }
+        out.push_back(v[i]);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// set_off_on_diagonal (saena_matrix_setup.cpp:793-1098)
+void DistLayout::build(Comm &c, const std::vector<cooEntry> &entry, const std::vector<index_t> &split_row,
+                       const std::vector<index_t> &split_col) {
+    const int nprocs = c.nranks, rank = c.rank;
+    *this = DistLayout();
+    M = split_row[rank + 1] - split_row[rank];
+    N_local = split_col[rank + 1] - split_col[rank];
+    col_offset = split_col[rank];
+    const nnz_t nnz_l = (nnz_t)entry.size();
+    nnzPerRow_local.assign((size_t)M, 0);
+    recvCount.assign((size_t)nprocs, 0);
+    nnzPerProcScan.assign((size_t)nprocs + 1, 0);
+    std::vector<cooEntry> ent_loc_row;
+    nnz_t i = 0;
+    while (i < nnz_l) {                                                  // :828-859
+        const long procNum = owner_of(split_col, entry[i].col);
+        if (procNum == rank) {
+            while (i < nnz_l && entry[i].col < split_col[procNum + 1]) {
+                ++nnzPerRow_local[entry[i].row - split_row[rank]];
+                ent_loc_row.emplace_back(entry[i].row - split_row[rank], entry[i].col, entry[i].val);
+                ++i;
+            }
+        } else {
+            const nnz_t tmp = i;
+            while (i < nnz_l && entry[i].col < split_col[procNum + 1]) {
+                vElement_remote.push_back(entry[i].col);
+                ++recvCount[procNum];
+                nnzPerCol_remote.push_back(0);
+                do {
+                    col_remote.push_back((index_t)vElement_remote.size() - 1);
+                    col_remote2.push_back(entry[i].col);
+                    row_remote.push_back(entry[i].row - split_row[rank]);
+                    val_remote.push_back(entry[i].val);
+                    ++nnzPerCol_remote.back();
+                } while (++i < nnz_l && entry[i].col == entry[i - 1].col);
+            }
+            nnzPerProcScan[procNum + 1] = i - tmp;
+        }
+    }
+    nnz_l_local = (nnz_t)ent_loc_row.size();
+    nnz_l_remote = (nnz_t)row_remote.size();
+    col_remote_size = (index_t)vElement_remote.size();
+    recvCount[rank] = 0;
+    std::sort(ent_loc_row.begin(), ent_loc_row.end(), row_major);        // :905
+    row_local.resize((size_t)nnz_l_local); col_local.resize((size_t)nnz_l_local); val_local.resize((size_t)nnz_l_local);
+    for (nnz_t k = 0; k < nnz_l_local; ++k) {
+        row_local[k] = ent_loc_row[k].row; col_local[k] = ent_loc_row[k].col; val_local[k] = ent_loc_row[k].val;
+    }
+    for (int p = 1; p < nprocs + 1; ++p) nnzPerProcScan[p] += nnzPerProcScan[p - 1];   // :948-950
+
+    sendCount = c.alltoall_one(recvCount);                               // :953 MPI_Alltoall
+    for (int p = 0; p < nprocs; ++p) {                                   // :958-967
+        if (recvCount[p] != 0) { recvProcRank.push_back(p); recvProcCount.push_back(recvCount[p]); }
+        if (sendCount[p] != 0) { sendProcRank.push_back(p); sendProcCount.push_back(sendCount[p]); }
+    }
+    numRecvProc = (int)recvProcRank.size();
+    numSendProc = (int)sendProcRank.size();
+    vdispls.assign((size_t)nprocs, 0); rdispls.assign((size_t)nprocs, 0);
+    for (int p = 1; p < nprocs; ++p) {                                   // :984-989
+        vdispls[p] = vdispls[p - 1] + sendCount[p - 1];
+        rdispls[p] = rdispls[p - 1] + recvCount[p - 1];
+    }
+    vIndexSize = vdispls[nprocs - 1] + sendCount[nprocs - 1];
+    recvSize   = rdispls[nprocs - 1] + recvCount[nprocs - 1];
+    vIndex = c.alltoallv_records(vElement_remote, recvCount);            // :1030 MPI_Alltoallv
+    for (auto &x : vIndex) x -= split_col[rank];                         // :1044-1046
+}
+
+// ---------------------------------------------------------------------------
+void transpose_transfer(const transfer_matrix &P, transfer_matrix &R) {
+    Comm &c = *P.comm;
+    R.comm = P.comm;
+    R.Mbig = P.Nbig; R.Nbig = P.Mbig;
+    R.split_row = P.split_col; R.split_col = P.split_row;
+    std::vector<cooEntry> t;
+    t.reserve(P.entry.size());
+    for (const auto &e : P.entry) t.emplace_back(e.col, e.row, e.val);
+    R.entry = route(c, t, R.split_row, [](const cooEntry &e) { return e.row; });
+    std::sort(R.entry.begin(), R.entry.end(), col_major);
+    R.M = R.split_row[c.rank + 1] - R.split_row[c.rank];
+    R.nnz_l = (nnz_t)R.entry.size();
+    R.nnz_g = c.sum(R.nnz_l);
+    R.build_layout();
+}
+
+// ---------------------------------------------------------------------------
+// generators
+
+static void z_slab(Comm &c, index_t mz, index_t *zs, index_t *zm) {   // aux_functions2.cpp:292-301
+    const int nprocs = c.nranks, rank = c.rank;
+    if (mz > nprocs) {
+        *zm = mz / nprocs;
+        *zs = rank * *zm;
+        if (rank == nprocs - 1) *zm = mz - (nprocs - 1) * *zm;
+    } else {
+        *zm = 1;
+        *zs = rank;
+    }
+}
+
+int laplacian3D(saena_matrix *A, index_t mx, index_t my, index_t mz) {
+    Comm &c = *A->comm;
+    if (c.rank >= mz) return 0;
+    const value_t Hx = 1.0 / (mx - 1), Hy = 1.0 / (my - 1), Hz = 1.0 / (mz - 1);
+    const value_t HyHzdHx = 1.0 / (Hx * Hx), HxHzdHy = 1.0 / (Hy * Hy), HxHydHz = 1.0 / (Hz * Hz);
+    index_t zs, zm;
+    z_slab(c, mz, &zs, &zm);
+    const index_t XMAX = mx - 1, YMAX = my - 1, ZMAX = mz - 1;
+    for (index_t k = zs; k < zs + zm; ++k)
+        for (index_t j = 0; j < my; ++j)
+            for (index_t i = 0; i < mx; ++i) {
+                const index_t node = mx * my * k + mx * j + i;
+                if (i == 0 || j == 0 || k == 0 || i == XMAX || j == YMAX || k == ZMAX) {
+                    A->set(node, node, 1.0);
+                } else {
+                    if (k - 1 != 0) A->set(node, node - mx * my, -HxHydHz);
+                    if (j - 1 != 0) A->set(node, node - mx, -HxHzdHy);
+                    if (i - 1 != 0) A->set(node, node - 1, -HyHzdHx);
+                    A->set(node, node, 2.0 * (HxHydHz + HxHzdHy + HyHzdHx));
+                    if (i + 1 != XMAX) A->set(node, node + 1, -HyHzdHx);
+                    if (j + 1 != YMAX) A->set(node, node + mx, -HxHzdHy);
+                    if (k + 1 != ZMAX) A->set(node, node + mx * my, -HxHydHz);
+                }
+            }
+    return 0;
+}
+
+std::vector<value_t> laplacian3D_set_rhs(Comm &c, index_t mx, index_t my, index_t mz, index_t *lo) {
+    std::vector<value_t> rhs;
+    *lo = 0;
+    if (c.rank >= mz) return rhs;
+    const value_t Hx = 1.0 / (mx - 1), Hy = 1.0 / (my - 1), Hz = 1.0 / (mz - 1);
+    index_t zs, zm;
+    z_slab(c, mz, &zs, &zm);
+    const double PI = 3.1415926535897932384626433832795029;      // data_struct.h:44
+    const double TWOPI = 2 * PI, TWOELVEPISQ = 12 * PI * PI;
+    rhs.reserve((size_t)mx * my * zm);
+    for (index_t k = zs; k < zs + zm; ++k)
+        for (index_t j = 0; j < my; ++j)
+            for (index_t i = 0; i < mx; ++i)
+                rhs.push_back(TWOELVEPISQ * std::sin(TWOPI * i * Hx) * std::sin(TWOPI * j * Hy) * std::sin(TWOPI * k * Hz));
+    *lo = mx * my * zs;
+    return rhs;
+}
+
+int band_matrix(saena_matrix *A, index_t M, unsigned int bandwidth) {   // aux_functions2.cpp:1296-1330
+    Comm &c = *A->comm;
+    const index_t Mbig = M * c.nranks;
+    if ((index_t)bandwidth >= Mbig) throw std::runtime_error("Error: bandwidth is greater than the size of the matrix");
+    for (index_t i = c.rank * M; i < (c.rank + 1) * M; ++i) {
+        index_t d = 0;
+        for (index_t j = i; j <= i + (index_t)bandwidth; ++j) {
+            const value_t val = 1.0 / (i + j + 1);
+            if (i == j) {
+                A->set(i, j, val);
+            } else {
+                if (j < Mbig) A->set(i, j, val);
+                if (j >= 2 * d) A->set(i, j - 2 * d, 1.0 / (i + j - 2 * d + 1));
+            }
+            d++;
+        }
+    }
+    return 0;
+}
+
+} // namespace saena_host

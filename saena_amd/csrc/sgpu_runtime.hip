@@ -6,6 +6,7 @@
 // MPI_Isend/Irecv with its local loop (src/saena_matrix_matvec.cpp:32-80).
 #include "../../include/saena_gpu.h"
 #include "kernels.hip.h"
+#include "host/comm.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -926,3 +927,75 @@ int sgpu_time_kernel(sgpu_op *op, int kind, const value_t *x, const value_t *rhs
 }
 
 } // extern "C"
+
+// ===========================================================================
+// Setup-time collectives of the host layer over the same RCCL communicator
+// (the reference: MPI_Alltoall/Alltoallv/Allreduce/Allgather during assemble).
+namespace {
+struct RcclHostComm : saena_host::Comm {
+    static void ok(int s, const char *what) { if (s != SGPU_OK) throw std::runtime_error(std::string(what) + ": " + g_err); }
+    struct Buf {
+        void *p = nullptr;
+        explicit Buf(size_t n) { if (hipMalloc(&p, std::max<size_t>(n, 8)) != hipSuccess) throw std::runtime_error("hipMalloc failed in RcclHostComm"); }
+        ~Buf() { hipFree(p); }
+    };
+    static int h2d(void *d, const void *h, size_t n) { if (n) HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g.cs)); return SGPU_OK; }
+    static int d2h(void *h, const void *d, size_t n) {
+        if (n) HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g.cs));
+        HIPCHK(hipStreamSynchronize(g.cs));
+        return SGPU_OK;
+    }
+    static int do_allgather(const void *ds, void *dr, size_t bytes) { NCCLCHK(ncclAllGather(ds, dr, bytes, ncclChar, g.comm, g.cs)); return SGPU_OK; }
+    int do_alltoallv(const char *ds, const size_t *sc, const size_t *sd, char *dr, const size_t *rc, const size_t *rd) {
+        NCCLCHK(ncclGroupStart());
+        for (int p = 0; p < nranks; ++p) {
+            if (p == rank) continue;
+            if (sc[p]) NCCLCHK(ncclSend(ds + sd[p], sc[p], ncclChar, p, g.comm, g.cs));
+            if (rc[p]) NCCLCHK(ncclRecv(dr + rd[p], rc[p], ncclChar, p, g.comm, g.cs));
+        }
+        NCCLCHK(ncclGroupEnd());
+        if (sc[rank]) HIPCHK(hipMemcpyAsync(dr + rd[rank], ds + sd[rank], sc[rank], hipMemcpyDeviceToDevice, g.cs));
+        return SGPU_OK;
+    }
+    template <class T>
+    static int do_allreduce(T *d, int n, ncclDataType_t t) { NCCLCHK(ncclAllReduce(d, d, (size_t)n, t, ncclSum, g.comm, g.cs)); return SGPU_OK; }
+
+    void allgather(const void *send, void *recv, size_t bytes) override {
+        if (nranks == 1) { memcpy(recv, send, bytes); return; }
+        Buf s(bytes), r(bytes * nranks);
+        ok(h2d(s.p, send, bytes), "allgather h2d");
+        ok(do_allgather(s.p, r.p, bytes), "ncclAllGather");
+        ok(d2h(recv, r.p, bytes * nranks), "allgather d2h");
+    }
+    void alltoallv(const void *send, const size_t *sc, const size_t *sd, void *recv, const size_t *rc, const size_t *rd) override {
+        size_t sbytes = 0, rbytes = 0;
+        for (int p = 0; p < nranks; ++p) { sbytes = std::max(sbytes, sd[p] + sc[p]); rbytes = std::max(rbytes, rd[p] + rc[p]); }
+        if (nranks == 1) { memcpy(static_cast<char *>(recv) + rd[0], static_cast<const char *>(send) + sd[0], sc[0]); return; }
+        Buf s(sbytes), r(rbytes);
+        ok(h2d(s.p, send, sbytes), "alltoallv h2d");
+        ok(do_alltoallv(static_cast<const char *>(s.p), sc, sd, static_cast<char *>(r.p), rc, rd), "alltoallv send/recv");
+        ok(d2h(recv, r.p, rbytes), "alltoallv d2h");
+    }
+    void allreduce_sum_i64(long *v, int n) override {
+        if (nranks == 1 || n == 0) return;
+        Buf b(sizeof(long) * n);
+        ok(h2d(b.p, v, sizeof(long) * n), "allreduce h2d");
+        ok(do_allreduce(static_cast<long *>(b.p), n, ncclInt64), "ncclAllReduce");
+        ok(d2h(v, b.p, sizeof(long) * n), "allreduce d2h");
+    }
+    void allreduce_sum_f64(double *v, int n) override {
+        if (nranks == 1 || n == 0) return;
+        Buf b(sizeof(double) * n);
+        ok(h2d(b.p, v, sizeof(double) * n), "allreduce h2d");
+        ok(do_allreduce(static_cast<double *>(b.p), n, ncclDouble), "ncclAllReduce");
+        ok(d2h(v, b.p, sizeof(double) * n), "allreduce d2h");
+    }
+};
+} // namespace
+
+extern "C" saena_host::Comm *sgpu_new_host_comm() {
+    if (!g.live) return nullptr;
+    auto *c = new RcclHostComm();
+    c->rank = g.rank; c->nranks = g.nranks;
+    return c;
+}

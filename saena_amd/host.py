@@ -1,0 +1,311 @@
+"""ctypes binding of the host-side mirror (include/saena_c.h).
+
+`HostLib("host")` loads libsaena_host.so (g++, no GPU: partition, layout,
+generators); `HostLib("gpu")` loads libsaena_amd.so, which carries the same host
+code plus the HIP path.  Both fail loudly when the shared object is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .capi import OpDesc, SgpuError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_VP = C.c_void_p
+_PI = C.POINTER(C.c_int)
+_PD = C.POINTER(C.c_double)
+_PS = C.POINTER(C.c_size_t)
+
+CB_ALLGATHER = C.CFUNCTYPE(C.c_int, _VP, _VP, _VP, C.c_size_t)
+CB_ALLTOALLV = C.CFUNCTYPE(C.c_int, _VP, _VP, _PS, _PS, _VP, _PS, _PS)
+CB_I64 = C.CFUNCTYPE(C.c_int, _VP, C.POINTER(C.c_long), C.c_int)
+CB_F64 = C.CFUNCTYPE(C.c_int, _VP, _PD, C.c_int)
+
+HOST_SYMBOLS = {
+    "saena_last_error": (C.c_char_p, []),
+    "saena_comm_self": (_VP, []),
+    "saena_comm_callbacks": (_VP, [C.c_int, C.c_int, _VP, CB_ALLGATHER, CB_ALLTOALLV, CB_I64, CB_F64]),
+    "saena_comm_rccl": (_VP, []),
+    "saena_comm_free": (None, [_VP]),
+    "saena_matrix_new": (_VP, [_VP]),
+    "saena_matrix_free": (None, [_VP]),
+    "saena_matrix_set": (C.c_int, [_VP, C.c_int, C.c_int, C.c_double]),
+    "saena_matrix_set_many": (C.c_int, [_VP, _PI, _PI, _PD, C.c_long]),
+    "saena_matrix_set_remove_boundary": (C.c_int, [_VP, C.c_int]),
+    "saena_matrix_add_duplicates": (C.c_int, [_VP, C.c_int]),
+    "saena_matrix_set_eig": (C.c_int, [_VP, C.c_double]),
+    "saena_matrix_assemble": (C.c_int, [_VP]),
+    "saena_matrix_assemble_with_split": (C.c_int, [_VP, _PI]),
+    "saena_matrix_get_num_rows": (C.c_int, [_VP]),
+    "saena_matrix_get_num_local_rows": (C.c_int, [_VP]),
+    "saena_matrix_get_nnz": (C.c_long, [_VP]),
+    "saena_matrix_get_local_nnz": (C.c_long, [_VP]),
+    "saena_matrix_get_split": (C.c_int, [_VP, _PI]),
+    "saena_matrix_get_desc": (C.c_int, [_VP, C.POINTER(OpDesc)]),
+    "saena_matrix_get_layout_extra": (C.c_int, [_VP, C.POINTER(_PI), C.POINTER(C.POINTER(C.c_long))]),
+    "saena_laplacian3D": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
+    "saena_laplacian3D_set_rhs": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _PD]),
+    "saena_band_matrix": (C.c_int, [_VP, C.c_int, C.c_uint]),
+    "saena_prolong_new": (_VP, [_VP, C.c_int, C.c_int, _PI, _PI, _PI, _PI, _PD, C.c_long]),
+    "saena_restrict_from_prolong": (_VP, [_VP]),
+    "saena_transfer_free": (None, [_VP]),
+    "saena_transfer_get_desc": (C.c_int, [_VP, C.POINTER(OpDesc)]),
+    "saena_transfer_get_local_nnz": (C.c_long, [_VP]),
+}
+
+_libs = {}
+
+
+def load(which="host"):
+    """which: 'host' -> libsaena_host.so, 'gpu' -> libsaena_amd.so"""
+    if which not in _libs:
+        path = os.path.join(_HERE, "libsaena_host.so" if which == "host" else "libsaena_amd.so")
+        if not os.path.exists(path):
+            raise SgpuError(f"{path} is missing: run __graft_entry__.build()")
+        L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in HOST_SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _libs[which] = L
+    return _libs[which]
+
+
+def _ai(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def _ad(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+class Comm:
+    """Setup-time communicator: self, the GPU runtime's RCCL communicator, or
+    torch.distributed (any backend that moves CPU tensors, e.g. gloo) through callbacks."""
+
+    def __init__(self, which="host", kind="self", dist=None):
+        self.L = load(which)
+        self.kind = kind
+        self.rank, self.nranks = 0, 1
+        self._cbs = None
+        if kind == "self":
+            self.h = self.L.saena_comm_self()
+        elif kind == "rccl":
+            self.h = self.L.saena_comm_rccl()
+            if not self.h:
+                raise SgpuError(self.L.saena_last_error().decode())
+        elif kind == "dist":
+            self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+            self._make_dist_callbacks(dist)
+            self.h = self.L.saena_comm_callbacks(self.rank, self.nranks, None, *self._cbs)
+        else:
+            raise ValueError(kind)
+
+    def _make_dist_callbacks(self, dist):
+        import torch
+        np_ = self.nranks
+
+        def buf(ptr, n):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,)) if n else np.zeros(0, np.uint8)
+
+        def allgather(user, send, recv, nbytes):
+            try:
+                s = torch.from_numpy(buf(send, nbytes).copy())
+                outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(np_)]
+                dist.all_gather(outs, s)
+                r = buf(recv, nbytes * np_)
+                for q in range(np_):
+                    r[q * nbytes:(q + 1) * nbytes] = outs[q].numpy()
+                return 0
+            except Exception as e:      # pragma: no cover
+                print("allgather callback failed:", e)
+                return 1
+
+        def alltoallv(user, send, sc, sd, recv, rc, rd):
+            try:
+                ins = [torch.from_numpy(buf(send + sd[q] if send else None, sc[q]).copy()) if sc[q] else torch.empty(0, dtype=torch.uint8)
+                       for q in range(np_)]
+                outs = [torch.empty(rc[q], dtype=torch.uint8) for q in range(np_)]
+                # pairwise exchange (works on every backend that has send/recv)
+                me = self.rank
+                outs[me] = ins[me].clone()
+                for step in range(1, np_):
+                    to, frm = (me + step) % np_, (me - step) % np_
+                    reqs = []
+                    if sc[to]:
+                        reqs.append(dist.isend(ins[to], to))
+                    if rc[frm]:
+                        reqs.append(dist.irecv(outs[frm], frm))
+                    for rq in reqs:
+                        rq.wait()
+                for q in range(np_):
+                    if rc[q]:
+                        buf(recv + rd[q], rc[q])[:] = outs[q].numpy()
+                return 0
+            except Exception as e:      # pragma: no cover
+                print("alltoallv callback failed:", e)
+                return 1
+
+        def ar_i64(user, v, n):
+            t = torch.from_numpy(np.ctypeslib.as_array(v, shape=(n,)).copy())
+            dist.all_reduce(t)
+            np.ctypeslib.as_array(v, shape=(n,))[:] = t.numpy()
+            return 0
+
+        def ar_f64(user, v, n):
+            t = torch.from_numpy(np.ctypeslib.as_array(v, shape=(n,)).copy())
+            dist.all_reduce(t)
+            np.ctypeslib.as_array(v, shape=(n,))[:] = t.numpy()
+            return 0
+
+        self._cbs = (CB_ALLGATHER(allgather), CB_ALLTOALLV(alltoallv), CB_I64(ar_i64), CB_F64(ar_f64))
+
+
+def _check(L, status):
+    if status != 0:
+        raise SgpuError("saena host: " + L.saena_last_error().decode(errors="replace"))
+
+
+def desc_arrays(d: OpDesc, nranks_for_scan=None):
+    """Copy every array an sgpu_op_desc points at into numpy (for layout tests)."""
+    def ai(p, n):
+        return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+
+    def ad(p, n):
+        return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.float64)
+
+    return dict(
+        M=d.M, N_local=d.N_local, col_offset=d.col_offset,
+        nnzPerRow_local=ai(d.nnzPerRow_local, d.M), col_local=ai(d.col_local, d.nnz_l_local), val_local=ad(d.val_local, d.nnz_l_local),
+        nnzPerCol_remote=ai(d.nnzPerCol_remote, d.col_remote_size), row_remote=ai(d.row_remote, d.nnz_l_remote),
+        val_remote=ad(d.val_remote, d.nnz_l_remote),
+        recvProcRank=ai(d.recvProcRank, d.numRecvProc), recvProcCount=ai(d.recvProcCount, d.numRecvProc),
+        sendProcRank=ai(d.sendProcRank, d.numSendProc), sendProcCount=ai(d.sendProcCount, d.numSendProc),
+        vIndex=ai(d.vIndex, d.vIndexSize), inv_diag=ad(d.inv_diag, d.M) if d.inv_diag else None,
+    )
+
+
+class Matrix:
+    """saena::matrix mirror (reference include/saena.hpp:14-73)."""
+
+    def __init__(self, comm: Comm):
+        self.comm, self.L = comm, comm.L
+        self.h = self.L.saena_matrix_new(comm.h)
+
+    def set(self, i, j, v):
+        _check(self.L, self.L.saena_matrix_set(self.h, int(i), int(j), float(v)))
+
+    def set_many(self, rows, cols, vals):
+        r, c, v = _ai(rows), _ai(cols), _ad(vals)
+        _check(self.L, self.L.saena_matrix_set_many(self.h, r.ctypes.data_as(_PI), c.ctypes.data_as(_PI), v.ctypes.data_as(_PD), len(r)))
+
+    def set_remove_boundary(self, flag):
+        self.L.saena_matrix_set_remove_boundary(self.h, 1 if flag else 0)
+
+    def laplacian3D(self, mx, my=None, mz=None):
+        my = mx if my is None else my
+        mz = mx if mz is None else mz
+        self._grid = (mx, my, mz)
+        _check(self.L, self.L.saena_laplacian3D(self.h, mx, my, mz))
+        return self
+
+    def band_matrix(self, M, bw):
+        _check(self.L, self.L.saena_band_matrix(self.h, M, bw))
+        return self
+
+    def assemble(self, split=None):
+        if split is None:
+            _check(self.L, self.L.saena_matrix_assemble(self.h))
+        else:
+            s = _ai(split)
+            _check(self.L, self.L.saena_matrix_assemble_with_split(self.h, s.ctypes.data_as(_PI)))
+        return self
+
+    def laplacian3D_rhs(self):
+        mx, my, mz = self._grid
+        out = np.empty(self.num_local_rows)
+        _check(self.L, self.L.saena_laplacian3D_set_rhs(self.h, mx, my, mz, out.ctypes.data_as(_PD)))
+        return out
+
+    @property
+    def num_rows(self):
+        return self.L.saena_matrix_get_num_rows(self.h)
+
+    @property
+    def num_local_rows(self):
+        return self.L.saena_matrix_get_num_local_rows(self.h)
+
+    @property
+    def nnz(self):
+        return self.L.saena_matrix_get_nnz(self.h)
+
+    @property
+    def local_nnz(self):
+        return self.L.saena_matrix_get_local_nnz(self.h)
+
+    @property
+    def split(self):
+        s = np.zeros(self.comm.nranks + 1, np.int32)
+        _check(self.L, self.L.saena_matrix_get_split(self.h, s.ctypes.data_as(_PI)))
+        return s
+
+    def desc(self):
+        d = OpDesc()
+        _check(self.L, self.L.saena_matrix_get_desc(self.h, C.byref(d)))
+        return d
+
+    def layout(self):
+        d = self.desc()
+        out = desc_arrays(d)
+        cr, sc = _PI(), C.POINTER(C.c_long)()
+        self.L.saena_matrix_get_layout_extra(self.h, C.byref(cr), C.byref(sc))
+        out["col_remote"] = np.ctypeslib.as_array(cr, shape=(d.nnz_l_remote,)).copy() if d.nnz_l_remote else np.zeros(0, np.int32)
+        out["nnzPerProcScan"] = np.ctypeslib.as_array(sc, shape=(self.comm.nranks + 1,)).copy()
+        return out
+
+    def free(self):
+        if self.h:
+            self.L.saena_matrix_free(self.h)
+            self.h = None
+
+
+class Transfer:
+    """prolong_matrix / restrict_matrix mirror."""
+
+    def __init__(self, comm, h):
+        self.comm, self.L, self.h = comm, comm.L, h
+
+    @classmethod
+    def prolong(cls, comm, Mbig, Nbig, split_row, split_col, rows, cols, vals):
+        sr, sc, r, c, v = _ai(split_row), _ai(split_col), _ai(rows), _ai(cols), _ad(vals)
+        h = comm.L.saena_prolong_new(comm.h, Mbig, Nbig, sr.ctypes.data_as(_PI), sc.ctypes.data_as(_PI),
+                                     r.ctypes.data_as(_PI), c.ctypes.data_as(_PI), v.ctypes.data_as(_PD), len(r))
+        if not h:
+            raise SgpuError(comm.L.saena_last_error().decode())
+        return cls(comm, h)
+
+    def transpose(self):
+        h = self.L.saena_restrict_from_prolong(self.h)
+        if not h:
+            raise SgpuError(self.L.saena_last_error().decode())
+        return Transfer(self.comm, h)
+
+    def desc(self):
+        d = OpDesc()
+        _check(self.L, self.L.saena_transfer_get_desc(self.h, C.byref(d)))
+        return d
+
+    def layout(self):
+        return desc_arrays(self.desc())
+
+
+def device_operator(obj, halo_fp32=False):
+    """sgpu_op_create from a host Matrix/Transfer (GPU library only)."""
+    from . import capi
+    d = obj.desc()
+    d.halo_fp32 = 1 if halo_fp32 else 0
+    op = capi.Operator.__new__(capi.Operator)
+    h = _VP()
+    capi.check(capi.lib().sgpu_op_create(C.byref(d), C.byref(h)))
+    op.h, op.M, op.N_local, op._keep = h, d.M, d.N_local, None
+    return op
