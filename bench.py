@@ -61,6 +61,16 @@ def cpu_baseline(m, seconds):
                       f"(oracle/saena_oracle.c, -O2), {t * 1e3:.3f} ms each"}
 
 
+def pmc_traffic(m, world):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (PMC counters cannot be read from inside the process); None for other configurations."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_spmv_128.json")
+    if m == 128 and world == 1 and os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)["traffic_bytes_per_launch"], "profiles/r01_pmc_spmv_128.json"
+    return None, None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -160,7 +170,7 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "us_per_launch": round(ms_kernel * 1e3, 3), "algorithmic_bytes": B_local,
-                "traffic": None,
+                "traffic": pmc_traffic(m, world)[0], "traffic_source": pmc_traffic(m, world)[1],
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,113 @@
+"""GPU V-cycle / solve / pCG parity against the oracle's restatement of
+saena_object::vcycle, solve and solve_pCG on identical hierarchies.
+
+Tolerances: V-cycle output rel l2 <= 1e-11; residual histories:
+same iteration count and every ||r_k|| within 1e-10 of the CPU path RELATIVE TO
+||r_0|| (the residual r = A u - rhs is itself only computed to ~1e-16 |A||u|, i.e.
+~1e-13 absolute here, so a residual that has dropped 8 orders of magnitude cannot
+agree to 1e-10 of its own size between two summation orders; each entry must
+still agree to 1e-6 of its own size).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import hierarchy, inputs, util
+
+pytestmark = pytest.mark.gpu
+
+TOL_VCYCLE = 1e-11
+TOL_HIST = 1e-10
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from saena_amd import capi as c
+    c.init(0)
+    return c
+
+
+@pytest.fixture(scope="module")
+def hier():
+    As, Ps, Rs = hierarchy.poisson_hierarchy(18, 4)      # 4096 -> 512 -> 64 -> 8 rows
+    return As, Ps, Rs
+
+
+def build(capi, hier, smoother, pre=3, post=3, max_iter=60, tol=1e-8):
+    As, Ps, Rs = hier
+    OA, OP, OR = hierarchy.oracle_hierarchy(As, Ps, Rs)
+    eig = hierarchy.eig_estimates(As)
+    for a, e in zip(OA, eig):
+        a.set_eig(e)
+    O = orc.OracleAmg(OA, OP, OR, pre=pre, post=post, smoother=smoother, max_iter=max_iter, tol=tol)
+    GA = [util.gpu_operator(a) for a in OA]
+    GP = [util.gpu_operator(p) for p in OP]
+    GR = [util.gpu_operator(r) for r in OR]
+    G = capi.Amg(GA, GP, GR, eig_max=eig, pre=pre, post=post, smoother=smoother, max_iter=max_iter, tol=tol)
+    return O, G, (OA, OP, OR), (GA, GP, GR)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def test_coarsest_cg(capi, hier):
+    O, G, (OA, _, _), _ = build(capi, hier, "jacobi")
+    n = OA[-1].Mbig
+    rhs = inputs.rhs2(n)
+    want, it_o = O.coarsest_cg(rhs)
+    du, dr = capi.DeviceVector(n, np.zeros(n)), capi.DeviceVector(n, rhs)
+    it_g = G.coarsest_solve(du, dr)
+    assert rel(du.download(), want) <= 1e-11
+    assert abs(it_g - it_o) <= 1
+
+
+@pytest.mark.parametrize("smoother", ["jacobi", "chebyshev"])
+@pytest.mark.parametrize("pre,post", [(3, 3), (2, 1), (0, 2), (1, 0)])
+def test_vcycle(capi, hier, smoother, pre, post):
+    O, G, (OA, _, _), _ = build(capi, hier, smoother, pre, post)
+    n = OA[0].Mbig
+    rhs, u0 = inputs.rhs2(n), inputs.v2(n) * 0.01
+    want = O.vcycle(u0, rhs)
+    du, dr = capi.DeviceVector(n, u0), capi.DeviceVector(n, rhs)
+    G.vcycle(du, dr)
+    assert rel(du.download(), want) <= TOL_VCYCLE
+    # run-to-run determinism (no atomics anywhere on the path)
+    du2 = capi.DeviceVector(n, u0)
+    G.vcycle(du2, dr)
+    np.testing.assert_array_equal(du2.download(), du.download())
+
+
+@pytest.mark.parametrize("smoother", ["jacobi", "chebyshev"])
+def test_solve_and_pcg_histories(capi, hier, smoother):
+    O, G, (OA, _, _), _ = build(capi, hier, smoother)
+    n = OA[0].Mbig
+    rhs = orc.laplacian3d_rhs(18)
+    du, dr = capi.DeviceVector(n), capi.DeviceVector(n, rhs)
+    for name in ("solve", "solve_pCG"):
+        u_o, it_o, hist_o = getattr(O, name)(rhs)
+        it_g, hist_g, conv = getattr(G, name)(du, dr)
+        assert conv and it_g == it_o, (name, it_g, it_o)
+        assert len(hist_g) == len(hist_o)
+        assert np.all(np.abs(hist_g - hist_o) <= TOL_HIST * hist_o[0]), (name, hist_g, hist_o)
+        assert np.all(np.abs(hist_g - hist_o) <= 1e-6 * hist_o), (name, hist_g, hist_o)
+        assert hist_g[-1] <= 1e-8 * hist_g[0]
+        assert rel(du.download(), u_o) <= 1e-9
+
+
+def test_two_level_and_single_level(capi):
+    """max_level = 1 and max_level = 0 (`only using the direct solver`, saena_object_solve.cpp:2504-2520)"""
+    As, Ps, Rs = hierarchy.poisson_hierarchy(8, 2)       # 216 -> 27
+    O, G, (OA, _, _), _ = build(capi, (As, Ps, Rs), "jacobi")
+    n = OA[0].Mbig
+    rhs = inputs.rhs2(n)
+    du, dr = capi.DeviceVector(n, np.zeros(n)), capi.DeviceVector(n, rhs)
+    G.vcycle(du, dr)
+    assert rel(du.download(), O.vcycle(np.zeros(n), rhs)) <= TOL_VCYCLE
+    As1 = [As[1]]                                        # a lone coarsest level: vcycle == coarsest CG
+    O1, G1, (OA1, _, _), _ = build(capi, (As1, [], []), "jacobi")
+    n1 = OA1[0].Mbig
+    rhs1 = inputs.rhs2(n1)
+    du1, dr1 = capi.DeviceVector(n1, np.zeros(n1)), capi.DeviceVector(n1, rhs1)
+    G1.vcycle(du1, dr1)
+    assert rel(du1.download(), O1.vcycle(np.zeros(n1), rhs1)) <= TOL_VCYCLE
