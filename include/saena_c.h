@@ -73,6 +73,39 @@ void  saena_transfer_free(saena_transfer_h *T);
 int   saena_transfer_get_desc(saena_transfer_h *T, sgpu_op_desc *out);
 nnz_t saena_transfer_get_local_nnz(saena_transfer_h *T);
 
+/* ---- saena::options + saena::amg (reference include/saena.hpp:127-265) ---- */
+typedef struct {
+    int    solver_max_iter;      /* saena.hpp:151-155 defaults: 100, 1e-8, "chebyshev", 3, 3, "jacobi", 0.3, true, 10, 3, */
+    double relative_tol;         /*                             1e-14, 1e-8, 1, 2, false, 0.1, 5000                       */
+    int    smoother;             /* 0 "jacobi", 1 "chebyshev" */
+    int    preSmooth, postSmooth;
+    float  connStrength;
+    int    dynamic_levels;
+    int    max_level;
+    int    float_level;
+    double filter_thre, filter_max;
+    int    filter_start, filter_rate;
+} saena_options_c;
+int saena_options_default(saena_options_c *o);
+int saena_options_from_file(const char *xml_name, saena_options_c *o);   /* saena::options(const string&), saena.cpp:444-546 */
+
+typedef struct saena_amg_h saena_amg_h;
+saena_amg_h *saena_amg_new(void);
+void  saena_amg_free(saena_amg_h *S);
+/* saena::amg::set_matrix (saena.hpp:202): smoothed-aggregation setup on the host */
+int   saena_amg_set_matrix(saena_amg_h *S, saena_matrix_h *A, const saena_options_c *opts);
+int   saena_amg_num_levels(saena_amg_h *S);                               /* max_level + 1 */
+int   saena_amg_level_info(saena_amg_h *S, int level, index_t *rows, nnz_t *nnzA, nnz_t *nnzP, double *eig_max);
+/* which: 0 = A_l, 1 = P_l, 2 = R_l */
+int   saena_amg_level_desc(saena_amg_h *S, int level, int which, sgpu_op_desc *out);
+/* [GPU] upload every level (sgpu_op_create) and build the device hierarchy (sgpu_amg_create) */
+int   saena_amg_to_device(saena_amg_h *S);
+sgpu_amg *saena_amg_device_handle(saena_amg_h *S);                        /* [GPU] valid after to_device */
+sgpu_op  *saena_amg_device_op(saena_amg_h *S, int level, int which);      /* [GPU] */
+/* [GPU] saena::amg::solve / solve_pCG (saena.hpp:220,224) on HOST slices of this rank: rhs in, u out */
+int   saena_amg_solve(saena_amg_h *S, const value_t *rhs_host, value_t *u_host, int *iters, value_t *res_hist, int hist_cap);
+int   saena_amg_solve_pCG(saena_amg_h *S, const value_t *rhs_host, value_t *u_host, int *iters, value_t *res_hist, int hist_cap);
+
 #ifdef __cplusplus
 }
 #endif

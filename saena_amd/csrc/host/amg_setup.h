@@ -1,0 +1,74 @@
+// amg_setup.h -- host-side smoothed-aggregation setup.
+//
+// Restates saena_object::setup / coarsen / SA / compute_coarsen of the reference
+// so that a hierarchy exists on the GPU box (where the reference does not): the
+// V-cycle kernels consume its output (A_l, P_l, R_l per level).  Like the
+// reference, setup is host code that runs once; it is not on the timed path.
+#pragma once
+#include "saena_matrix.h"
+
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace saena_host {
+
+// saena::options (reference include/saena.hpp:127-193; defaults :151-155)
+struct amg_options {
+    int         solver_max_iter = 100;
+    double      relative_tol    = 1e-8;
+    std::string smoother        = "chebyshev";
+    int         preSmooth       = 3;
+    int         postSmooth      = 3;
+    std::string PSmoother       = "jacobi";
+    float       connStrength    = 0.3f;
+    bool        dynamic_levels  = true;
+    int         max_level       = 10;
+    int         float_level     = 3;
+    double      filter_thre     = 1e-14;
+    double      filter_max      = 1e-8;
+    int         filter_start    = 1;
+    int         filter_rate     = 2;
+    bool        switch_to_dense = false;
+    float       dense_thre      = 0.1f;
+    int         dense_sz_thre   = 5000;
+    // parse the positional attributes of <SAENA><OPTIONS .../> (saena.cpp:444-546)
+    void set_from_file(const std::string &name);
+};
+
+struct amg_level {
+    saena_matrix *A = nullptr;                   // level 0: the caller's matrix; l > 0: owned by `Ac_store` of level l-1
+    transfer_matrix P, R;                        // empty on the coarsest level
+    std::unique_ptr<saena_matrix> Ac_store;      // A of level l+1
+};
+
+class amg_hierarchy {
+public:
+    amg_options opts;
+    std::vector<amg_level> levels;               // levels.size() == max_level + 1 after setup
+    int max_level = 0;
+    // thresholds of saena_object.h:43-46
+    unsigned int least_row_threshold = 100;
+    double row_reduction_up_thrshld = 0.90;
+
+    // saena_object::setup (saena_object.cpp:175-406)
+    int setup(saena_matrix *A, const amg_options &o);
+
+    // pieces, public for tests ------------------------------------------------
+    // create_strength_matrix + strength_matrix::setup_matrix (setup1:520-719, strength_matrix.cpp:233-453):
+    // CSR of the strong connections (local rows, global columns), diagonal included
+    static void strength_graph(const saena_matrix &A, float connStrength, std::vector<nnz_t> &ptr, std::vector<index_t> &col);
+    // aggregation_1_dist + aggregate_index_update (setup1:724-995, :2103-2260); returns the number of aggregates
+    static index_t aggregate(const saena_matrix &A, const std::vector<nnz_t> &ptr, const std::vector<index_t> &col,
+                             std::vector<index_t> &agg);
+    // find_eig (saena_object.cpp:572-592, lamlan_saena.h): largest eigenvalue of D^-1 A by 20 Lanczos steps, x 1.0001
+    static double find_eig(const saena_matrix &A);
+
+private:
+    double filter_thre_cur = 0;
+    int    filter_it = 0;
+    int  coarsen(int l);                          // saena_object::coarsen (saena_object.cpp:409-452)
+    void filter(std::vector<cooEntry> &v, index_t sz, index_t ofst);   // setup2:852-916
+};
+
+} // namespace saena_host

@@ -1,6 +1,7 @@
 // saena_c_api.cpp -- flat C view (include/saena_c.h) of the host-side mirror.
 #include "../../../include/saena_c.h"
 #include "saena_matrix.h"
+#include "amg_setup.h"
 
 #include <algorithm>
 #include <memory>
@@ -11,6 +12,13 @@ using namespace saena_host;
 struct saena_comm { std::unique_ptr<Comm> c; };
 struct saena_matrix_h { saena_matrix A; explicit saena_matrix_h(Comm *c) : A(c) {} };
 struct saena_transfer_h { transfer_matrix T; };
+struct saena_amg_h {
+    amg_hierarchy H;
+    bool set = false;
+    // device side (libsaena_amd.so only)
+    std::vector<sgpu_op *> dA, dP, dR;
+    sgpu_amg *damg = nullptr;
+};
 
 namespace {
 thread_local std::string h_err;
@@ -168,5 +176,128 @@ saena_transfer_h *saena_restrict_from_prolong(saena_transfer_h *P) {
 void saena_transfer_free(saena_transfer_h *T) { delete T; }
 int saena_transfer_get_desc(saena_transfer_h *T, sgpu_op_desc *out) { return guard([&] { fill_desc(T->T.L, nullptr, out); }); }
 nnz_t saena_transfer_get_local_nnz(saena_transfer_h *T) { return T->T.nnz_l; }
+
+
+int saena_options_default(saena_options_c *o) {
+    amg_options d;
+    o->solver_max_iter = d.solver_max_iter; o->relative_tol = d.relative_tol; o->smoother = d.smoother == "jacobi" ? 0 : 1;
+    o->preSmooth = d.preSmooth; o->postSmooth = d.postSmooth; o->connStrength = d.connStrength;
+    o->dynamic_levels = d.dynamic_levels; o->max_level = d.max_level; o->float_level = d.float_level;
+    o->filter_thre = d.filter_thre; o->filter_max = d.filter_max; o->filter_start = d.filter_start; o->filter_rate = d.filter_rate;
+    return 0;
+}
+
+int saena_options_from_file(const char *name, saena_options_c *o) {
+    return guard([&] {
+        amg_options d;
+        d.set_from_file(name);
+        o->solver_max_iter = d.solver_max_iter; o->relative_tol = d.relative_tol; o->smoother = d.smoother == "jacobi" ? 0 : 1;
+        o->preSmooth = d.preSmooth; o->postSmooth = d.postSmooth; o->connStrength = d.connStrength;
+        o->dynamic_levels = d.dynamic_levels; o->max_level = d.max_level; o->float_level = d.float_level;
+        o->filter_thre = d.filter_thre; o->filter_max = d.filter_max; o->filter_start = d.filter_start; o->filter_rate = d.filter_rate;
+    });
+}
+
+saena_amg_h *saena_amg_new(void) { return new saena_amg_h(); }
+
+int saena_amg_set_matrix(saena_amg_h *S, saena_matrix_h *A, const saena_options_c *o) {
+    return guard([&] {
+        amg_options d;
+        if (o) {
+            d.solver_max_iter = o->solver_max_iter; d.relative_tol = o->relative_tol; d.smoother = o->smoother == 0 ? "jacobi" : "chebyshev";
+            d.preSmooth = o->preSmooth; d.postSmooth = o->postSmooth; d.connStrength = o->connStrength;
+            d.dynamic_levels = o->dynamic_levels != 0; d.max_level = o->max_level; d.float_level = o->float_level;
+            d.filter_thre = o->filter_thre; d.filter_max = o->filter_max; d.filter_start = o->filter_start; d.filter_rate = o->filter_rate;
+        }
+        S->H.setup(&A->A, d);
+        S->set = true;
+    });
+}
+
+int saena_amg_num_levels(saena_amg_h *S) { return S->set ? S->H.max_level + 1 : 0; }
+
+int saena_amg_level_info(saena_amg_h *S, int l, index_t *rows, nnz_t *nnzA, nnz_t *nnzP, double *eig) {
+    return guard([&] {
+        if (!S->set || l < 0 || l > S->H.max_level) throw std::runtime_error("bad level");
+        const amg_level &g = S->H.levels[l];
+        if (rows) *rows = g.A->Mbig;
+        if (nnzA) *nnzA = g.A->nnz_g;
+        if (nnzP) *nnzP = l < S->H.max_level ? g.P.nnz_g : 0;
+        if (eig) *eig = g.A->eig_max_of_invdiagXA;
+    });
+}
+
+int saena_amg_level_desc(saena_amg_h *S, int l, int which, sgpu_op_desc *out) {
+    return guard([&] {
+        if (!S->set || l < 0 || l > S->H.max_level) throw std::runtime_error("bad level");
+        const amg_level &g = S->H.levels[l];
+        if (which == 0) fill_desc(g.A->L, &g.A->inv_diag, out);
+        else if (l == S->H.max_level) throw std::runtime_error("the coarsest level has no P/R");
+        else fill_desc(which == 1 ? g.P.L : g.R.L, nullptr, out);
+    });
+}
+
+#ifndef SAENA_WITH_GPU
+static int no_gpu() { h_err = "this entry point needs libsaena_amd.so (the GPU library); there is no CPU fallback"; return -1; }
+void saena_amg_free(saena_amg_h *S) { delete S; }
+int saena_amg_to_device(saena_amg_h *) { return no_gpu(); }
+sgpu_amg *saena_amg_device_handle(saena_amg_h *) { no_gpu(); return nullptr; }
+sgpu_op *saena_amg_device_op(saena_amg_h *, int, int) { no_gpu(); return nullptr; }
+int saena_amg_solve(saena_amg_h *, const value_t *, value_t *, int *, value_t *, int) { return no_gpu(); }
+int saena_amg_solve_pCG(saena_amg_h *, const value_t *, value_t *, int *, value_t *, int) { return no_gpu(); }
+#else
+static int gchk(int s) { if (s != 0) { h_err = sgpu_last_error(); } return s; }
+static void drop_device(saena_amg_h *S) {
+    if (S->damg) { sgpu_amg_destroy(S->damg); S->damg = nullptr; }
+    for (auto *v : {&S->dA, &S->dP, &S->dR}) { for (sgpu_op *o : *v) sgpu_op_destroy(o); v->clear(); }
+}
+void saena_amg_free(saena_amg_h *S) { if (S) { drop_device(S); delete S; } }
+
+int saena_amg_to_device(saena_amg_h *S) {
+    if (!S->set) { h_err = "set_matrix has not been called"; return -1; }
+    drop_device(S);
+    const int n = S->H.max_level + 1;
+    std::vector<double> eig;
+    for (int l = 0; l < n; ++l) {
+        sgpu_op_desc d; sgpu_op *o = nullptr;
+        const amg_level &g = S->H.levels[l];
+        const int fp32 = 0;      // halo precision per level: float_level semantics are a later row
+        fill_desc(g.A->L, &g.A->inv_diag, &d); d.halo_fp32 = fp32;
+        if (gchk(sgpu_op_create(&d, &o))) return -2;
+        S->dA.push_back(o);
+        eig.push_back(g.A->eig_max_of_invdiagXA);
+        if (l < n - 1) {
+            fill_desc(g.P.L, nullptr, &d); if (gchk(sgpu_op_create(&d, &o))) return -2; S->dP.push_back(o);
+            fill_desc(g.R.L, nullptr, &d); if (gchk(sgpu_op_create(&d, &o))) return -2; S->dR.push_back(o);
+        }
+    }
+    sgpu_amg_params p;
+    sgpu_amg_default_params(&p);
+    const amg_options &o = S->H.opts;
+    p.preSmooth = o.preSmooth; p.postSmooth = o.postSmooth; p.smoother = o.smoother == "jacobi" ? 0 : 1;
+    p.solver_max_iter = o.solver_max_iter; p.solver_tol = o.relative_tol;
+    return gchk(sgpu_amg_create(n, S->dA.data(), S->dP.data(), S->dR.data(), eig.data(), &p, &S->damg));
+}
+
+sgpu_amg *saena_amg_device_handle(saena_amg_h *S) { return S->damg; }
+sgpu_op *saena_amg_device_op(saena_amg_h *S, int l, int which) {
+    auto &v = which == 0 ? S->dA : which == 1 ? S->dP : S->dR;
+    return l >= 0 && l < (int)v.size() ? v[l] : nullptr;
+}
+
+static int solve_host(saena_amg_h *S, bool pcg, const value_t *rhs_host, value_t *u_host, int *iters, value_t *hist, int cap) {
+    if (!S->damg) { h_err = "saena_amg_to_device has not been called"; return -1; }
+    const size_t n = (size_t)S->H.levels[0].A->M;
+    value_t *u = nullptr, *rhs = nullptr;
+    if (gchk(sgpu_vec_alloc(&u, n)) || gchk(sgpu_vec_alloc(&rhs, n))) return -2;
+    int s = gchk(sgpu_vec_upload(rhs, rhs_host, n));
+    if (!s) s = gchk(pcg ? sgpu_solve_pCG(S->damg, u, rhs, iters, hist, cap) : sgpu_solve(S->damg, u, rhs, iters, hist, cap));
+    const int s2 = gchk(sgpu_vec_download(u_host, u, n));
+    sgpu_vec_free(u); sgpu_vec_free(rhs);
+    return s ? s : s2;
+}
+int saena_amg_solve(saena_amg_h *S, const value_t *rhs, value_t *u, int *it, value_t *hist, int cap) { return solve_host(S, false, rhs, u, it, hist, cap); }
+int saena_amg_solve_pCG(saena_amg_h *S, const value_t *rhs, value_t *u, int *it, value_t *hist, int cap) { return solve_host(S, true, rhs, u, it, hist, cap); }
+#endif
 
 } // extern "C"

@@ -54,6 +54,32 @@ HOST_SYMBOLS = {
     "saena_transfer_get_local_nnz": (C.c_long, [_VP]),
 }
 
+
+
+class OptionsC(C.Structure):
+    """saena_options_c"""
+    _fields_ = [("solver_max_iter", C.c_int), ("relative_tol", C.c_double), ("smoother", C.c_int),
+                ("preSmooth", C.c_int), ("postSmooth", C.c_int), ("connStrength", C.c_float),
+                ("dynamic_levels", C.c_int), ("max_level", C.c_int), ("float_level", C.c_int),
+                ("filter_thre", C.c_double), ("filter_max", C.c_double), ("filter_start", C.c_int), ("filter_rate", C.c_int)]
+
+
+HOST_SYMBOLS.update({
+    "saena_options_default": (C.c_int, [C.POINTER(OptionsC)]),
+    "saena_options_from_file": (C.c_int, [C.c_char_p, C.POINTER(OptionsC)]),
+    "saena_amg_new": (_VP, []),
+    "saena_amg_free": (None, [_VP]),
+    "saena_amg_set_matrix": (C.c_int, [_VP, _VP, C.POINTER(OptionsC)]),
+    "saena_amg_num_levels": (C.c_int, [_VP]),
+    "saena_amg_level_info": (C.c_int, [_VP, C.c_int, _PI, C.POINTER(C.c_long), C.POINTER(C.c_long), _PD]),
+    "saena_amg_level_desc": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(OpDesc)]),
+    "saena_amg_to_device": (C.c_int, [_VP]),
+    "saena_amg_device_handle": (_VP, [_VP]),
+    "saena_amg_device_op": (_VP, [_VP, C.c_int, C.c_int]),
+    "saena_amg_solve": (C.c_int, [_VP, _PD, _PD, _PI, _PD, C.c_int]),
+    "saena_amg_solve_pCG": (C.c_int, [_VP, _PD, _PD, _PI, _PD, C.c_int]),
+})
+
 _libs = {}
 
 
@@ -309,3 +335,84 @@ def device_operator(obj, halo_fp32=False):
     capi.check(capi.lib().sgpu_op_create(C.byref(d), C.byref(h)))
     op.h, op.M, op.N_local, op._keep = h, d.M, d.N_local, None
     return op
+
+
+def options(L, xml=None, **kw):
+    """saena::options: defaults (saena.hpp:151-155), an options XML of the reference's format, then overrides"""
+    o = OptionsC()
+    L.saena_options_default(C.byref(o))
+    if xml is not None:
+        _check(L, L.saena_options_from_file(os.fsencode(xml), C.byref(o)))
+    for k, v in kw.items():
+        if k == "smoother":
+            v = 0 if v == "jacobi" else 1
+        setattr(o, k, v)
+    return o
+
+
+# the reference's data/options001.xml (Jacobi 3+3, tol 1e-8, conn_str 0.2, filter 1e-14 -> 1e-8 rate 2)
+OPTIONS001 = dict(solver_max_iter=50, relative_tol=1e-8, smoother="jacobi", preSmooth=3, postSmooth=3, connStrength=0.2,
+                  dynamic_levels=1, max_level=20, float_level=3, filter_thre=1e-14, filter_max=1e-8, filter_start=1, filter_rate=2)
+
+
+class AmgSolver:
+    """saena::amg mirror (reference include/saena.hpp:195-265): set_matrix on the host, solve on the GPU."""
+
+    def __init__(self, A: Matrix, opts: OptionsC):
+        self.A, self.L = A, A.L
+        self.h = self.L.saena_amg_new()
+        _check(self.L, self.L.saena_amg_set_matrix(self.h, A.h, C.byref(opts)))
+        self.opts = opts
+
+    @property
+    def num_levels(self):
+        return self.L.saena_amg_num_levels(self.h)
+
+    def level_info(self, l):
+        rows, na, npp, eig = C.c_int(), C.c_long(), C.c_long(), C.c_double()
+        _check(self.L, self.L.saena_amg_level_info(self.h, l, C.byref(rows), C.byref(na), C.byref(npp), C.byref(eig)))
+        return dict(rows=rows.value, nnzA=na.value, nnzP=npp.value, eig_max=eig.value)
+
+    def level_layout(self, l, which):
+        d = OpDesc()
+        _check(self.L, self.L.saena_amg_level_desc(self.h, l, which, C.byref(d)))
+        return desc_arrays(d)
+
+    def to_device(self):
+        _check(self.L, self.L.saena_amg_to_device(self.h))
+        return self
+
+    def device_handle(self):
+        return self.L.saena_amg_device_handle(self.h)
+
+    def device_op(self, l, which=0):
+        from . import capi
+        op = capi.Operator.__new__(capi.Operator)
+        op.h = _VP(self.L.saena_amg_device_op(self.h, l, which))
+        info = None
+        op._keep = None
+        op.destroy = lambda: None          # owned by the solver
+        info = op.info()
+        op.M, op.N_local = info["M"], info["N_local"]
+        return op
+
+    def _solve(self, fn, rhs, cap=256):
+        rhs = _ad(rhs)
+        u = np.zeros_like(rhs)
+        it = C.c_int()
+        hist = np.full(cap, np.nan)
+        st = fn(self.h, rhs.ctypes.data_as(_PD), u.ctypes.data_as(_PD), C.byref(it), hist.ctypes.data_as(_PD), cap)
+        if st not in (0, -6):
+            _check(self.L, st)
+        return u, it.value, hist[~np.isnan(hist)], st == 0
+
+    def solve(self, rhs):
+        return self._solve(self.L.saena_amg_solve, rhs)
+
+    def solve_pCG(self, rhs):
+        return self._solve(self.L.saena_amg_solve_pCG, rhs)
+
+    def free(self):
+        if self.h:
+            self.L.saena_amg_free(self.h)
+            self.h = None

@@ -1,0 +1,88 @@
+"""Host AMG setup (smoothed aggregation restatement) against numbers printed by the
+reference itself (SURVEY.md 6 / BASELINE.md 2, `mpirun ./poisson 32 data/options001.xml`):
+
+  hierarchy 32^3: rows 27000/13500/1420/253/69, nnz 183600/833962/257610/60479/4761
+  solve_pCG (Jacobi 3+3): ||r0|| = 7.227341e+03 -> 2.246251e-05 (rel 3.107991e-09), 7 iterations
+
+The second pin runs the ORACLE's V-cycle/pCG restatement on the hierarchy built by the product's
+host setup, which ties both to the reference's own output.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from saena_amd import host
+
+
+def coo_from_layout(L, row_ofs=0):
+    """entries (global ids) of a 1-rank operator from its reference-layout arrays"""
+    rows = np.repeat(np.arange(L["M"], dtype=np.int32), L["nnzPerRow_local"]) + row_ofs
+    return orc.coo_from_arrays(rows, L["col_local"], L["val_local"])
+
+
+def oracle_amg_from_host(S, smoother="jacobi", **kw):
+    n = S.num_levels
+    OA, OP, OR = [], [], []
+    for l in range(n):
+        LA = S.level_layout(l, 0)
+        M = LA["M"]
+        OA.append(orc.OracleOp(coo_from_layout(LA), M, M, orc.split_even(M, 1)))
+        OA[-1].set_eig(S.level_info(l)["eig_max"])
+        if l < n - 1:
+            LP, LR = S.level_layout(l, 1), S.level_layout(l, 2)
+            Nc = LR["M"]
+            OP.append(orc.OracleOp(coo_from_layout(LP), M, Nc, orc.split_even(M, 1), orc.split_even(Nc, 1), square=False))
+            OR.append(orc.OracleOp(coo_from_layout(LR), Nc, M, orc.split_even(Nc, 1), orc.split_even(M, 1), square=False))
+    return orc.OracleAmg(OA, OP, OR, smoother=smoother, **kw), OA
+
+
+@pytest.fixture(scope="module")
+def solver32():
+    L = host.load("host")
+    A = host.Matrix(host.Comm("host", "self")).laplacian3D(32).assemble()
+    return A, host.AmgSolver(A, host.options(L, **host.OPTIONS001))
+
+
+def test_hierarchy_sizes_32(solver32):
+    _, S = solver32
+    assert S.num_levels == 5
+    info = [S.level_info(l) for l in range(5)]
+    assert [i["rows"] for i in info] == [27000, 13500, 1420, 253, 69]
+    assert [i["nnzA"] for i in info] == [183600, 833962, 257610, 60479, 4761]
+
+
+def test_reference_convergence_pin_32(solver32):
+    A, S = solver32
+    amg, OA = oracle_amg_from_host(S, "jacobi", pre=3, post=3, max_iter=50, tol=1e-8)
+    rhs = A.laplacian3D_rhs()
+    u, it, hist = amg.solve_pCG(rhs)
+    assert it == 7
+    assert abs(hist[0] - 7.227341e+03) <= 0.5e-3 * 1e0 + 1e-6 * hist[0]        # printed with 7 digits
+    assert abs(hist[0] / 7.227341e+03 - 1) < 1e-6
+    assert abs(hist[-1] / 2.246251e-05 - 1) < 2e-6, hist[-1]
+    assert abs(hist[-1] / hist[0] / 3.107991e-09 - 1) < 2e-6
+
+
+def test_options_xml(tmp_path):
+    L = host.load("host")
+    xml = tmp_path / "o.xml"
+    xml.write_text('<?xml version="1.0"?>\n<SAENA>\n <OPTIONS solver_max_iter="50" solver_tol="1e-8" smoother="jacobi" '
+                   'preSmooth="3" postSmooth="2" PSmoother="jacobi" conn_str="0.2" dynamic_levels="1" max_level="20" '
+                   'float_level="3" filter_thre="1e-14" filter_max="1e-8" filter_start="1" filter_rate="2" '
+                   'switch_to_dense="0" dense_thre="0.1" dense_sz_thre="5000" petsc=""/>\n</SAENA>\n')
+    o = host.options(L, xml=str(xml))
+    assert (o.solver_max_iter, o.smoother, o.preSmooth, o.postSmooth, o.max_level) == (50, 0, 3, 2, 20)
+    assert abs(o.connStrength - 0.2) < 1e-7 and o.filter_thre == 1e-14 and o.filter_rate == 2
+    d = host.options(L)                   # saena.hpp:151-155 defaults
+    assert (d.solver_max_iter, d.smoother, d.max_level, d.float_level) == (100, 1, 10, 3)
+
+
+def test_chebyshev_eig_estimate():
+    """find_eig: the Lanczos estimate bounds lambda_max(D^-1 A) of Poisson (< 2) from within 1%"""
+    L = host.load("host")
+    A = host.Matrix(host.Comm("host", "self")).laplacian3D(16).assemble()
+    S = host.AmgSolver(A, host.options(L, **dict(host.OPTIONS001, smoother="chebyshev")))
+    e = S.level_info(0)["eig_max"]
+    n = 14
+    exact = 1 + np.cos(np.pi / (n + 1))        # lambda_max(D^-1 A) of the n^3 Dirichlet Laplacian
+    assert 0.97 * exact < e <= 1.0002 * exact

@@ -111,3 +111,27 @@ def test_two_level_and_single_level(capi):
     du1, dr1 = capi.DeviceVector(n1, np.zeros(n1)), capi.DeviceVector(n1, rhs1)
     G1.vcycle(du1, dr1)
     assert rel(du1.download(), O1.vcycle(np.zeros(n1), rhs1)) <= TOL_VCYCLE
+
+
+def test_full_pipeline_poisson32_matches_reference_pins(capi):
+    """saena::matrix -> saena::amg::set_matrix (host SA setup) -> solve_pCG on the GPU, Poisson 32^3,
+    options001: the reference prints ||r0|| = 7.227341e+03 -> 2.246251e-05, 7 iterations."""
+    from saena_amd import host
+    from tests.test_amg_setup import oracle_amg_from_host
+    L = host.load("gpu")
+    A = host.Matrix(host.Comm("gpu", "rccl")).laplacian3D(32).assemble()
+    S = host.AmgSolver(A, host.options(L, **host.OPTIONS001)).to_device()
+    rhs = A.laplacian3D_rhs()
+    u, it, hist, conv = S.solve_pCG(rhs)
+    assert conv and it == 7
+    assert abs(hist[0] / 7.227341e+03 - 1) < 1e-6
+    assert abs(hist[-1] / 2.246251e-05 - 1) < 2e-6
+    amg, OA = oracle_amg_from_host(S, "jacobi", pre=3, post=3, max_iter=50, tol=1e-8)
+    u_o, it_o, hist_o = amg.solve_pCG(rhs)
+    assert it_o == it
+    assert np.all(np.abs(hist - hist_o) <= TOL_HIST * hist_o[0])
+    assert rel(u, u_o) <= 1e-9
+    # stationary V-cycle iteration (saena::amg::solve)
+    u2, it2, hist2, conv2 = S.solve(rhs)
+    u2_o, it2_o, hist2_o = amg.solve(rhs)
+    assert conv2 and it2 == it2_o and np.all(np.abs(hist2 - hist2_o) <= TOL_HIST * hist2_o[0])
