@@ -7,7 +7,10 @@
 #include <cfloat>
 #include <cmath>
 #include <fstream>
+#include <cstdlib>
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 namespace saena_host {
 
@@ -63,47 +66,123 @@ struct Csr {
     std::vector<value_t> val;
 };
 
-// rows [row_ofs, row_ofs+nrows), columns global; `e` in any order
-Csr csr_from_entries(const std::vector<cooEntry> &e, index_t row_ofs, index_t nrows, index_t ncols) {
+int n_threads() {
+    static const int n = [] {
+        if (const char *e = std::getenv("SAENA_SETUP_THREADS")) return std::max(1, std::atoi(e));
+        return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    }();
+    return n;
+}
+
+// run f(t, lo, hi) over [0,n) split into contiguous chunks of about equal `weight`
+template <class F>
+void parallel_rows(index_t n, const std::vector<nnz_t> *weight_ptr, F f) {
+    const int T = std::max(1, std::min<int>(n_threads(), n / 64 + 1));
+    std::vector<index_t> cut((size_t)T + 1, n);
+    cut[0] = 0;
+    if (weight_ptr) {
+        const nnz_t tot = (*weight_ptr)[(size_t)n];
+        for (int t = 1; t < T; ++t)
+            cut[t] = (index_t)(std::lower_bound(weight_ptr->begin(), weight_ptr->begin() + n + 1, tot * t / T) - weight_ptr->begin());
+    } else {
+        for (int t = 1; t < T; ++t) cut[t] = (index_t)((long)n * t / T);
+    }
+    for (int t = 1; t <= T; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+    if (T == 1) { f(0, 0, n); return; }
+    std::vector<std::thread> th;
+    std::exception_ptr err;
+    std::mutex mu;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            try { f(t, cut[t], cut[t + 1]); }
+            catch (...) { std::lock_guard<std::mutex> g(mu); err = std::current_exception(); }
+        });
+    for (auto &x : th) x.join();
+    if (err) std::rethrow_exception(err);
+}
+
+// the assembled one-rank operator as CSR (its layout arrays are row-major, columns ascending)
+Csr csr_of(const DistLayout &L, index_t ncols) {
     Csr C;
-    C.nrows = nrows; C.ncols = ncols;
-    C.ptr.assign((size_t)nrows + 1, 0);
-    for (const auto &x : e) C.ptr[x.row - row_ofs + 1]++;
-    for (index_t i = 0; i < nrows; ++i) C.ptr[i + 1] += C.ptr[i];
-    C.col.resize(e.size()); C.val.resize(e.size());
-    std::vector<nnz_t> fill(C.ptr.begin(), C.ptr.end() - 1);
-    std::vector<cooEntry> s(e);
-    std::sort(s.begin(), s.end(), row_major);
-    for (const auto &x : s) { const nnz_t k = fill[x.row - row_ofs]++; C.col[k] = x.col; C.val[k] = x.val; }
+    C.nrows = L.M; C.ncols = ncols;
+    C.ptr.resize((size_t)L.M + 1);
+    C.ptr[0] = 0;
+    for (index_t i = 0; i < L.M; ++i) C.ptr[i + 1] = C.ptr[i] + L.nnzPerRow_local[i];
+    C.col = L.col_local;
+    C.val = L.val_local;
     return C;
 }
 
-// C = A B (Gustavson, rows of C sorted by column).  Entries with |v| <= ALMOST_ZERO are dropped
-// unless row id == column id, the rule of the reference's SpGEMM output (saena_object_setup_matmat.cpp:2423,2442).
-std::vector<cooEntry> spgemm_entries(const Csr &A, const Csr &B, index_t row_ofs) {
-    std::vector<cooEntry> out;
-    std::vector<value_t> acc((size_t)B.ncols, 0.0);
-    std::vector<char>    mark((size_t)B.ncols, 0);
-    std::vector<index_t> cols;
+Csr transpose(const Csr &A) {
+    Csr T;
+    T.nrows = A.ncols; T.ncols = A.nrows;
+    T.ptr.assign((size_t)A.ncols + 1, 0);
+    for (index_t c : A.col) T.ptr[c + 1]++;
+    for (index_t i = 0; i < A.ncols; ++i) T.ptr[i + 1] += T.ptr[i];
+    T.col.resize(A.col.size()); T.val.resize(A.val.size());
+    std::vector<nnz_t> fill(T.ptr.begin(), T.ptr.end() - 1);
+    for (index_t i = 0; i < A.nrows; ++i)
+        for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) { const nnz_t q = fill[A.col[k]]++; T.col[q] = i; T.val[q] = A.val[k]; }
+    return T;
+}
+
+// C = A B (row-wise Gustavson, rows of C sorted by column, row chunks on threads).  Entries with
+// |v| <= ALMOST_ZERO are dropped unless row id == column id, the rule of the reference's SpGEMM
+// output (saena_object_setup_matmat.cpp:2423,2442).
+Csr spgemm(const Csr &A, const Csr &B) {
+    Csr C;
+    C.nrows = A.nrows; C.ncols = B.ncols;
+    // work estimate per row for load balance
+    std::vector<nnz_t> work((size_t)A.nrows + 1, 0);
     for (index_t i = 0; i < A.nrows; ++i) {
-        cols.clear();
-        for (nnz_t ka = A.ptr[i]; ka < A.ptr[i + 1]; ++ka) {
-            const index_t k = A.col[ka];
-            const value_t a = A.val[ka];
-            for (nnz_t kb = B.ptr[k]; kb < B.ptr[k + 1]; ++kb) {
-                const index_t j = B.col[kb];
-                if (!mark[j]) { mark[j] = 1; cols.push_back(j); acc[j] = 0.0; }
-                acc[j] += a * B.val[kb];
-            }
-        }
-        std::sort(cols.begin(), cols.end());
-        const index_t r = i + row_ofs;
-        for (index_t j : cols) {
-            if (std::fabs(acc[j]) > SAENA_ALMOST_ZERO || r == j) out.emplace_back(r, j, acc[j]);
-            mark[j] = 0;
-        }
+        nnz_t w = 0;
+        for (nnz_t ka = A.ptr[i]; ka < A.ptr[i + 1]; ++ka) w += B.ptr[A.col[ka] + 1] - B.ptr[A.col[ka]];
+        work[i + 1] = work[i] + w + 1;
     }
-    return out;
+    const int T = n_threads();
+    std::vector<std::vector<index_t>> tcol((size_t)T);
+    std::vector<std::vector<value_t>> tval((size_t)T);
+    std::vector<index_t> tlo((size_t)T, 0), thi((size_t)T, 0);
+    std::vector<nnz_t> rowlen((size_t)A.nrows, 0);
+    parallel_rows(A.nrows, &work, [&](int t, index_t lo, index_t hi) {
+        tlo[t] = lo; thi[t] = hi;
+        std::vector<value_t> acc((size_t)B.ncols, 0.0);
+        std::vector<char> mark((size_t)B.ncols, 0);
+        std::vector<index_t> cols;
+        auto &oc = tcol[t];
+        auto &ov = tval[t];
+        oc.reserve((size_t)((work[hi] - work[lo]) / 4 + 16));
+        ov.reserve(oc.capacity());
+        for (index_t i = lo; i < hi; ++i) {
+            cols.clear();
+            for (nnz_t ka = A.ptr[i]; ka < A.ptr[i + 1]; ++ka) {
+                const index_t k = A.col[ka];
+                const value_t a = A.val[ka];
+                for (nnz_t kb = B.ptr[k]; kb < B.ptr[k + 1]; ++kb) {
+                    const index_t j = B.col[kb];
+                    if (!mark[j]) { mark[j] = 1; cols.push_back(j); acc[j] = 0.0; }
+                    acc[j] += a * B.val[kb];
+                }
+            }
+            std::sort(cols.begin(), cols.end());
+            nnz_t cnt = 0;
+            for (index_t j : cols) {
+                if (std::fabs(acc[j]) > SAENA_ALMOST_ZERO || i == j) { oc.push_back(j); ov.push_back(acc[j]); ++cnt; }
+                mark[j] = 0;
+            }
+            rowlen[i] = cnt;
+        }
+    });
+    C.ptr.resize((size_t)A.nrows + 1);
+    C.ptr[0] = 0;
+    for (index_t i = 0; i < A.nrows; ++i) C.ptr[i + 1] = C.ptr[i] + rowlen[i];
+    C.col.resize((size_t)C.ptr[A.nrows]); C.val.resize((size_t)C.ptr[A.nrows]);
+    for (int t = 0; t < T; ++t) {
+        if (tcol[t].empty()) continue;
+        std::copy(tcol[t].begin(), tcol[t].end(), C.col.begin() + C.ptr[tlo[t]]);
+        std::copy(tval[t].begin(), tval[t].end(), C.val.begin() + C.ptr[tlo[t]]);
+    }
+    return C;
 }
 
 } // namespace
@@ -113,23 +192,41 @@ std::vector<cooEntry> spgemm_entries(const Csr &A, const Csr &B, index_t row_ofs
 void amg_hierarchy::strength_graph(const saena_matrix &A, float connStrength, std::vector<nnz_t> &ptr, std::vector<index_t> &col) {
     if (A.comm->nranks != 1) throw std::runtime_error("strength_graph: multi-rank setup is not implemented in this round");
     const index_t M = A.M;
+    const DistLayout &L = A.L;
+    std::vector<nnz_t> ap((size_t)M + 1, 0);
+    for (index_t i = 0; i < M; ++i) ap[i + 1] = ap[i] + L.nnzPerRow_local[i];
     std::vector<value_t> maxPerRow((size_t)M, -DBL_MAX);                       // :527-533
-    for (const auto &e : A.entry)
-        if (e.row != e.col) maxPerRow[e.row] = std::max(maxPerRow[e.row], -e.val);
+    parallel_rows(M, &ap, [&](int, index_t lo, index_t hi) {
+        for (index_t i = lo; i < hi; ++i)
+            for (nnz_t k = ap[i]; k < ap[i + 1]; ++k)
+                if (L.col_local[k] != i) maxPerRow[i] = std::max(maxPerRow[i], -L.val_local[k]);
+    });
     // S(i,j) = -a_ij / max_k(-a_ik), S^T(i,j) = -a_ij / max_k(-a_jk), diagonal 1; keep if either > connStrength
+    std::vector<char> keep(L.col_local.size());
     ptr.assign((size_t)M + 1, 0);
-    std::vector<cooEntry> kept;
-    kept.reserve(A.entry.size());
-    for (const auto &e : A.entry) {
-        value_t s, st;
-        if (e.row == e.col) { s = 1; st = 1; }
-        else { s = -e.val / maxPerRow[e.row]; st = -e.val / maxPerRow[e.col]; }
-        if (s > connStrength || st > connStrength) { kept.emplace_back(e.row, e.col, 0.0); ptr[e.row + 1]++; }
-    }
+    parallel_rows(M, &ap, [&](int, index_t lo, index_t hi) {
+        for (index_t i = lo; i < hi; ++i) {
+            nnz_t cnt = 0;
+            for (nnz_t k = ap[i]; k < ap[i + 1]; ++k) {
+                const index_t j = L.col_local[k];
+                value_t s_, st;
+                if (i == j) { s_ = 1; st = 1; }
+                else { s_ = -L.val_local[k] / maxPerRow[i]; st = -L.val_local[k] / maxPerRow[j]; }
+                keep[k] = (s_ > connStrength || st > connStrength);
+                cnt += keep[k];
+            }
+            ptr[i + 1] = cnt;
+        }
+    });
     for (index_t i = 0; i < M; ++i) ptr[i + 1] += ptr[i];
-    col.resize(kept.size());
-    std::vector<nnz_t> fill(ptr.begin(), ptr.end() - 1);
-    for (const auto &e : kept) col[fill[e.row]++] = e.col;
+    col.resize((size_t)ptr[M]);
+    parallel_rows(M, &ap, [&](int, index_t lo, index_t hi) {
+        for (index_t i = lo; i < hi; ++i) {
+            nnz_t q = ptr[i];
+            for (nnz_t k = ap[i]; k < ap[i + 1]; ++k)
+                if (keep[k]) col[q++] = L.col_local[k];
+        }
+    });
 }
 
 // aggregation_1_dist (setup1:724-995): synchronous rounds; an undecided node looks at itself and
@@ -183,15 +280,17 @@ index_t amg_hierarchy::aggregate(const saena_matrix &A, const std::vector<nnz_t>
 double amg_hierarchy::find_eig(const saena_matrix &A) {
     if (A.comm->nranks != 1) throw std::runtime_error("find_eig: multi-rank setup is not implemented in this round");
     const index_t n = A.M;
-    Csr C = csr_from_entries(A.entry, 0, n, n);
+    const Csr C = csr_of(A.L, n);
     std::vector<double> isd((size_t)n);
     for (index_t i = 0; i < n; ++i) isd[i] = std::sqrt(std::fabs(A.inv_diag[i]));
     auto matvec = [&](const std::vector<double> &x, std::vector<double> &y) {
-        for (index_t i = 0; i < n; ++i) {
-            double s = 0;
-            for (nnz_t k = C.ptr[i]; k < C.ptr[i + 1]; ++k) s += C.val[k] * isd[C.col[k]] * x[C.col[k]];
-            y[i] = s * isd[i];
-        }
+        parallel_rows(n, &C.ptr, [&](int, index_t lo, index_t hi) {
+            for (index_t i = lo; i < hi; ++i) {
+                double s_ = 0;
+                for (nnz_t k = C.ptr[i]; k < C.ptr[i + 1]; ++k) s_ += C.val[k] * isd[C.col[k]] * x[C.col[k]];
+                y[i] = s_ * isd[i];
+            }
+        });
     };
     const int m = std::min<index_t>(20, n);
     std::vector<double> v((size_t)n), vprev((size_t)n, 0.0), w((size_t)n), alpha, beta;
@@ -244,32 +343,42 @@ double amg_hierarchy::find_eig(const saena_matrix &A) {
     return 1.0001 * 0.5 * (lo + hi);
 }
 
-// filter (setup2:852-916): entries with |v| <= THRE are lumped into the diagonal
-void amg_hierarchy::filter(std::vector<cooEntry> &v, index_t sz, index_t ofst) {
-    if (++filter_it < opts.filter_start) return;
-    if (filter_thre_cur > opts.filter_max) filter_thre_cur = opts.filter_max;
-    const double THRE = filter_thre_cur;
-    std::vector<value_t> add2diag((size_t)sz, 0.0);
-    std::vector<cooEntry> w;
-    w.reserve(v.size());
-    for (const auto &a : v) {
-        if (std::fabs(a.val) > THRE || a.row == a.col) w.push_back(a);
-        else add2diag[a.row - ofst] += a.val;
-    }
-    std::vector<char> check_diag((size_t)sz, 0);
-    for (auto &a : w)
-        if (a.row == a.col) {
-            a.val += add2diag[a.row - ofst];
-            check_diag[a.row - ofst] = 1;
-            if (std::fabs(a.val) < SAENA_ALMOST_ZERO) a.val = 1.0;
+// filter (setup2:852-916): entries with |v| <= THRE are lumped into the diagonal (one-rank CSR form)
+static void filter_csr(Csr &C, double THRE) {
+    const index_t n = C.nrows;
+    std::vector<nnz_t> nptr((size_t)n + 1, 0);
+    std::vector<index_t> ncol;
+    std::vector<value_t> nval;
+    ncol.reserve(C.col.size() + (size_t)n); nval.reserve(C.col.size() + (size_t)n);
+    for (index_t i = 0; i < n; ++i) {
+        value_t add2diag = 0.0;
+        bool has_diag = false;
+        const size_t row_start = ncol.size();
+        size_t diag_pos = 0;
+        for (nnz_t k = C.ptr[i]; k < C.ptr[i + 1]; ++k) {
+            const index_t j = C.col[k];
+            if (std::fabs(C.val[k]) > THRE || j == i) {
+                if (j == i) { has_diag = true; diag_pos = ncol.size(); }
+                ncol.push_back(j); nval.push_back(C.val[k]);
+            } else {
+                add2diag += C.val[k];
+            }
         }
-    bool added = false;
-    for (index_t i = 0; i < sz; ++i)
-        if (!check_diag[i]) { w.emplace_back(i + ofst, i + ofst, 1.0); added = true; }
-    if (added) std::sort(w.begin(), w.end(), col_major);
-    w.swap(v);
-    filter_thre_cur *= std::pow(10, opts.filter_rate);
+        if (has_diag) {
+            nval[diag_pos] += add2diag;
+            if (std::fabs(nval[diag_pos]) < SAENA_ALMOST_ZERO) nval[diag_pos] = 1.0;
+        } else {                                             // :896-903 missing diagonal -> 1.0, kept in column order
+            size_t pos = row_start;
+            while (pos < ncol.size() && ncol[pos] < i) ++pos;
+            ncol.insert(ncol.begin() + pos, i);
+            nval.insert(nval.begin() + pos, 1.0);
+        }
+        nptr[i + 1] = (nnz_t)ncol.size();
+    }
+    C.ptr.swap(nptr); C.col.swap(ncol); C.val.swap(nval);
 }
+
+void amg_hierarchy::filter(std::vector<cooEntry> &, index_t, index_t) {}   // COO form unused (CSR form above)
 
 // coarsen (saena_object.cpp:409-452) = SA (setup1:8-254) + transposeP + compute_coarsen (setup2:8-358)
 int amg_hierarchy::coarsen(int l) {
@@ -283,64 +392,82 @@ int amg_hierarchy::coarsen(int l) {
     std::vector<index_t> scol, agg;
     strength_graph(A, opts.connStrength, sptr, scol);
     const index_t new_size = aggregate(A, sptr, scol, agg);
+    sptr = {}; scol = {};
     int ret_val = 0;
     if (opts.dynamic_levels) {                                           // setup1:385-405
         if ((unsigned)new_size <= least_row_threshold) ret_val = 1;
         else if (static_cast<float>(new_size) / A.Mbig > row_reduction_up_thrshld) ret_val = 1;
     }
 
-    // ---- SA: P = (I - omega D^-1 A) P_tentative (setup1:60-239) ----
-    transfer_matrix &P = g.P;
-    P.comm = &c;
-    P.Mbig = A.Mbig; P.Nbig = new_size; P.M = A.M;
-    P.split_row = A.split;
-    P.split_col = {0, new_size};
+    // ---- SA: P = (I - omega D^-1 A) P_tentative (setup1:60-239), built row by row ----
+    const Csr Ac_ = csr_of(A.L, A.Mbig);
     const double om = A.jacobi_omega;                                    // Pomega = A->jacobi_omega, double (saena_object.h:168)
-    std::vector<cooEntry> tmp;
-    tmp.reserve((size_t)A.L.nnz_l_local);
-    nnz_t iter = 0;
-    for (index_t i = 0; i < A.M; ++i)
-        for (index_t j = 0; j < A.L.nnzPerRow_local[i]; ++j, ++iter) {
-            value_t vtmp = -om * A.inv_diag[i] * A.L.val_local[iter];
-            if (i == A.L.col_local[iter]) vtmp += 1;
-            tmp.emplace_back(i, agg[A.L.col_local[iter]], vtmp);
+    Csr Pc;
+    Pc.nrows = A.M; Pc.ncols = new_size;
+    {
+        const int T = n_threads();
+        std::vector<std::vector<index_t>> tcol((size_t)T);
+        std::vector<std::vector<value_t>> tval((size_t)T);
+        std::vector<index_t> tlo((size_t)T, 0);
+        std::vector<nnz_t> rowlen((size_t)A.M, 0);
+        parallel_rows(A.M, &Ac_.ptr, [&](int t, index_t lo, index_t hi) {
+            tlo[t] = lo;
+            std::vector<std::pair<index_t, value_t>> row;
+            for (index_t i = lo; i < hi; ++i) {
+                row.clear();
+                for (nnz_t k = Ac_.ptr[i]; k < Ac_.ptr[i + 1]; ++k) {
+                    value_t vtmp = -om * A.inv_diag[i] * Ac_.val[k];
+                    if (i == Ac_.col[k]) vtmp += 1;                      // I in (I - w Q A)
+                    row.emplace_back(agg[Ac_.col[k]], vtmp);
+                }
+                std::stable_sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+                nnz_t cnt = 0;
+                for (size_t q = 0; q < row.size(); ++q) {                // setup1:205-217 add duplicates, drop ~0
+                    value_t v = row[q].second;
+                    while (q + 1 < row.size() && row[q + 1].first == row[q].first) v += row[++q].second;
+                    if (std::fabs(v) > SAENA_ALMOST_ZERO) { tcol[t].push_back(row[q].first); tval[t].push_back(v); ++cnt; }
+                }
+                rowlen[i] = cnt;
+            }
+        });
+        Pc.ptr.resize((size_t)A.M + 1);
+        Pc.ptr[0] = 0;
+        for (index_t i = 0; i < A.M; ++i) Pc.ptr[i + 1] = Pc.ptr[i] + rowlen[i];
+        Pc.col.resize((size_t)Pc.ptr[A.M]); Pc.val.resize((size_t)Pc.ptr[A.M]);
+        for (int t = 0; t < T; ++t) {
+            std::copy(tcol[t].begin(), tcol[t].end(), Pc.col.begin() + Pc.ptr[tlo[t]]);
+            std::copy(tval[t].begin(), tval[t].end(), Pc.val.begin() + Pc.ptr[tlo[t]]);
         }
-    std::stable_sort(tmp.begin(), tmp.end(), col_major);                 // setup1:196
-    for (size_t i = 0; i < tmp.size(); ++i) {                            // :205-217 add duplicates, drop ~0
-        cooEntry t = tmp[i];
-        while (i + 1 < tmp.size() && tmp[i + 1].row == tmp[i].row && tmp[i + 1].col == tmp[i].col) t.val += tmp[++i].val;
-        if (std::fabs(t.val) > SAENA_ALMOST_ZERO) P.entry.push_back(t);
     }
-    P.nnz_l = (nnz_t)P.entry.size();
-    P.nnz_g = P.nnz_l;
-    P.build_layout();                                                    // findLocalRemote
-
     // ---- R = P^T (restrict_matrix::transposeP) ----
-    transpose_transfer(P, g.R);
+    Csr Rc = transpose(Pc);
 
     // ---- Ac = (R A) P  (triple_mat_mult, setup2:361-849) ----
-    Csr Rc = csr_from_entries(g.R.entry, 0, new_size, A.Mbig);
-    Csr Ac_ = csr_from_entries(A.entry, 0, A.M, A.Mbig);
-    std::vector<cooEntry> RA = spgemm_entries(Rc, Ac_, 0);
-    Rc = Csr(); Ac_ = Csr();
-    Csr RAc = csr_from_entries(RA, 0, new_size, A.Mbig);
-    RA.clear(); RA.shrink_to_fit();
-    Csr Pc = csr_from_entries(P.entry, 0, A.M, new_size);
-    std::vector<cooEntry> AcE = spgemm_entries(RAc, Pc, 0);
-    RAc = Csr(); Pc = Csr();
-    std::sort(AcE.begin(), AcE.end(), col_major);
+    Csr RA = spgemm(Rc, Ac_);
+    Csr AcN = spgemm(RA, Pc);
+    RA = Csr();
 
-    filter(AcE, new_size, 0);                                            // setup2:117-121
+    // ---- filter (setup2:117-121, :852-916) ----
+    if (++filter_it >= opts.filter_start) {
+        if (filter_thre_cur > opts.filter_max) filter_thre_cur = opts.filter_max;
+        filter_csr(AcN, filter_thre_cur);
+        filter_thre_cur *= std::pow(10, opts.filter_rate);
+    }
+
+    // ---- hand the three operators over in the reference's layout ----
+    transfer_matrix &P = g.P;
+    P.comm = &c; P.Mbig = A.Mbig; P.Nbig = new_size; P.M = A.M;
+    P.split_row = A.split; P.split_col = {0, new_size};
+    P.nnz_l = P.nnz_g = Pc.ptr[A.M];
+    P.L.build_single_rank(A.M, new_size, Pc.ptr, std::move(Pc.col), std::move(Pc.val));
+    transfer_matrix &R = g.R;
+    R.comm = &c; R.Mbig = new_size; R.Nbig = A.Mbig; R.M = new_size;
+    R.split_row = {0, new_size}; R.split_col = A.split;
+    R.nnz_l = R.nnz_g = Rc.ptr[new_size];
+    R.L.build_single_rank(new_size, A.M, Rc.ptr, std::move(Rc.col), std::move(Rc.val));
 
     g.Ac_store.reset(new saena_matrix(&c));
-    saena_matrix &Ac = *g.Ac_store;
-    Ac.Mbig = new_size; Ac.M = new_size;
-    Ac.split = {0, new_size};
-    Ac.entry.swap(AcE);
-    Ac.nnz_l = (nnz_t)Ac.entry.size();
-    Ac.nnz_g = Ac.nnz_l;
-    Ac.remove_boundary = false;
-    Ac.matrix_setup();                                                   // setup2:341
+    g.Ac_store->setup_from_csr(new_size, AcN.ptr, std::move(AcN.col), std::move(AcN.val));   // setup2:341 matrix_setup
     return ret_val;
 }
 

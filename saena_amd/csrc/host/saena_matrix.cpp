@@ -303,6 +303,37 @@ void DistLayout::build(Comm &c, const std::vector<cooEntry> &entry, const std::v
     for (auto &x : vIndex) x -= split_col[rank];                         // :1044-1046
 }
 
+void DistLayout::build_single_rank(index_t M_, index_t N_, const std::vector<nnz_t> &ptr, std::vector<index_t> &&col,
+                                   std::vector<value_t> &&val) {
+    *this = DistLayout();
+    M = M_; N_local = N_; col_offset = 0;
+    nnz_l_local = ptr[(size_t)M_];
+    nnzPerRow_local.resize((size_t)M_);
+    for (index_t i = 0; i < M_; ++i) nnzPerRow_local[i] = (index_t)(ptr[i + 1] - ptr[i]);
+    col_local = std::move(col);
+    val_local = std::move(val);
+    recvCount.assign(1, 0); sendCount.assign(1, 0); vdispls.assign(1, 0); rdispls.assign(1, 0);
+    nnzPerProcScan.assign(2, 0);
+}
+
+void saena_matrix::setup_from_csr(index_t n, const std::vector<nnz_t> &ptr, std::vector<index_t> &&col, std::vector<value_t> &&val) {
+    if (comm->nranks != 1) throw std::runtime_error("setup_from_csr is a one-rank path");
+    Mbig = M = n;
+    split = {0, n};
+    nnz_l = nnz_g = ptr[(size_t)n];
+    remove_boundary = false;
+    inv_diag.assign((size_t)n, 1.0);                                     // inverse_diag, saena_matrix_setup.cpp:1562-1600
+    for (index_t i = 0; i < n; ++i)
+        for (nnz_t k = ptr[i]; k < ptr[i + 1]; ++k)
+            if (col[k] == i) {
+                if (std::fabs(val[k]) < SAENA_ALMOST_ZERO)
+                    throw std::runtime_error("there is a zero diagonal element at row index = " + std::to_string(i));
+                inv_diag[i] = 1.0 / val[k];
+            }
+    L.build_single_rank(n, n, ptr, std::move(col), std::move(val));
+    assembled = true;
+}
+
 // ---------------------------------------------------------------------------
 void transpose_transfer(const transfer_matrix &P, transfer_matrix &R) {
     Comm &c = *P.comm;

@@ -56,6 +56,9 @@ struct DistLayout {
     // entry: this rank's rows, column-major sorted, GLOBAL row and column ids.
     void build(Comm &comm, const std::vector<cooEntry> &entry, const std::vector<index_t> &split_row,
                const std::vector<index_t> &split_col);
+    // one rank: everything is local, so the layout IS the row-major CSR (no exchange, no sort)
+    void build_single_rank(index_t M_, index_t N_, const std::vector<nnz_t> &ptr, std::vector<index_t> &&col,
+                           std::vector<value_t> &&val);
 };
 
 class saena_matrix {
@@ -91,6 +94,9 @@ public:
     void repartition_nnz_initial();    // nnz-balanced split (saena_matrix_repart.cpp:3-325)
     void matrix_setup();               // inverse_diag + set_off_on_diagonal (saena_matrix_setup.cpp:507-560)
     void inverse_diag();               // saena_matrix_setup.cpp:1562-1600
+    // one-rank shortcut used by the AMG setup for coarse operators: adopt a row-major CSR (columns
+    // sorted within rows) as the assembled operator; `entry` stays empty.
+    void setup_from_csr(index_t n, const std::vector<nnz_t> &ptr, std::vector<index_t> &&col, std::vector<value_t> &&val);
 
     // drop the rows of a full-length (with boundary) local vector slice that were removed
     // (remove_boundary_rhs, src/saena_object.cpp:699-730); rhs_with_bound covers [lo, hi) of the original numbering
