@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--m", type=int, default=128, help="grid points per side (reference laplacian3D argument)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -59,6 +60,50 @@ def cpu_baseline(m, seconds):
     return {"value": round(B / t / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
             "sample": f"{reps} matvecs of the same Poisson {m}^3 operator, {cores} simulated ranks on {cores} threads "
                       f"(oracle/saena_oracle.c, -O2), {t * 1e3:.3f} ms each"}
+
+
+def vcycle_leg(capi, host, A, m):
+    """Second half of BASELINE.json's metric: V-cycle iterations/s of solve_pCG (options001: Jacobi 3+3,
+    tol 1e-8) on the same operator, hierarchy from the host SA setup, everything device-resident."""
+    import ctypes as C
+    import numpy as np
+    L = host.load("gpu")
+    t0 = time.perf_counter()
+    S = host.AmgSolver(A, host.options(L, **host.OPTIONS001)).to_device()
+    t_setup = time.perf_counter() - t0
+    M = A.num_local_rows
+    du, dr = capi.DeviceVector(M), capi.DeviceVector(M, A.laplacian3D_rhs())
+    h = S.device_handle()
+    it = C.c_int()
+    hist = np.full(64, np.nan)
+    lib = capi.lib()
+    PD = C.POINTER(C.c_double)
+    best = None
+    for _ in range(3):                                   # first pass warms up; keep the best of the rest
+        capi.check(lib.sgpu_device_sync())
+        t0 = time.perf_counter()
+        st = lib.sgpu_solve_pCG(h, du.ptr, dr.ptr, C.byref(it), hist.ctypes.data_as(PD), 64)
+        capi.check(lib.sgpu_device_sync())
+        dt = time.perf_counter() - t0
+        if st != 0:
+            capi.check(st)
+        best = dt if best is None else min(best, dt)
+    hh = hist[~np.isnan(hist)]
+    for _ in range(3):
+        capi.check(lib.sgpu_vcycle(h, du.ptr, dr.ptr))
+    capi.check(lib.sgpu_device_sync())
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        capi.check(lib.sgpu_vcycle(h, du.ptr, dr.ptr))
+    capi.check(lib.sgpu_device_sync())
+    t_v = (time.perf_counter() - t0) / n
+    levels = [S.level_info(l) for l in range(S.num_levels)]
+    return {"levels": S.num_levels, "rows": [x["rows"] for x in levels], "nnz": [x["nnzA"] for x in levels],
+            "pcg_iterations": it.value, "pcg_iterations_per_s": round(it.value / best, 2), "pcg_solve_ms": round(best * 1e3, 3),
+            "vcycles_per_s": round(1.0 / t_v, 2), "vcycle_ms": round(t_v * 1e3, 4),
+            "initial_residual": float(hh[0]), "final_residual": float(hh[-1]), "relative_residual": float(hh[-1] / hh[0]),
+            "options": "data/options001.xml values: jacobi 3+3, tol 1e-8, conn_str 0.2", "host_setup_s": round(t_setup, 2)}
 
 
 def pmc_traffic(m, world):
@@ -173,6 +218,8 @@ def main():
                 "traffic": pmc_traffic(m, world)[0], "traffic_source": pmc_traffic(m, world)[1],
             },
         }
+        if world == 1 and not args.no_vcycle:
+            out["vcycle"] = vcycle_leg(capi, host, A, m)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, args.cpu_seconds)
         print(json.dumps(out), flush=True)

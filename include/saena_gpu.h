@@ -116,6 +116,11 @@ int sgpu_op_info(const sgpu_op *op, index_t *M, index_t *N_local, nnz_t *nnz_loc
                  int *n_row_blocks, int *lanes_per_row);
 /* kernel variant override (tuning/tests): lanes_per_row in {0=auto,1,2,4,...,64} */
 int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
+/* kernel variant of the local part (tuning): 0 stream/16 KiB LDS, 1 = 0 with all loads hoisted,
+ * 2 = 1 with 32 KiB LDS blocks, 3 vector CSR (no LDS staging) */
+int sgpu_op_set_variant(sgpu_op *op, int variant);
+/* time a few (variant, lanes) candidates on this operator and keep the fastest (plan-time autotune) */
+int sgpu_op_autotune(sgpu_op *op);
 
 /* All vector arguments below are DEVICE pointers to this rank's slices.
  * Calls enqueue on the context's compute stream and return without waiting
@@ -161,12 +166,15 @@ typedef struct {
     int     preSmooth, postSmooth;        /* saena.hpp:151-155 */
     int     smoother;                     /* 0 "jacobi", 1 "chebyshev" (saena_object.tpp:5-16) */
     value_t jacobi_omega;                 /* 0 => float(2.0/3) */
-    int     coarse_solver;                /* 0 CG (solve_coarsest_CG, saena_object_solve.cpp:14-114) */
+    int     coarse_solver;                /* 1 (default) direct: dense inverse factored once on the host, like the reference's
+                                             default direct_solver "SuperLU" (saena_object.h:165, saena_object_solve.cpp:793-958);
+                                             0 CG (solve_coarsest_CG, saena_object_solve.cpp:14-114) */
     int     CG_coarsest_max_iter;         /* 150   saena_object.h:156 */
     value_t CG_coarsest_tol;              /* 1e-12 saena_object.h:155 */
     int     solver_max_iter;              /* saena::options */
     value_t solver_tol;
-    int     use_graph;                    /* 1: replay the V-cycle as a hipGraph when single-rank */
+    int     use_graph;                    /* 1 (default): capture the V-cycle once per (u, rhs) pair and replay it as a
+                                             hipGraph (single rank; with RCCL halos the launches stay eager) */
 } sgpu_amg_params;
 
 typedef struct sgpu_amg sgpu_amg;         /* opaque */

@@ -65,6 +65,8 @@ SYMBOLS = {
     "sgpu_op_destroy": (C.c_int, [_VP]),
     "sgpu_op_info": (C.c_int, [_VP, _PI, _PI, C.POINTER(C.c_long), C.POINTER(C.c_long), _PI, _PI]),
     "sgpu_op_set_lanes_per_row": (C.c_int, [_VP, C.c_int]),
+    "sgpu_op_set_variant": (C.c_int, [_VP, C.c_int]),
+    "sgpu_op_autotune": (C.c_int, [_VP]),
     "sgpu_spmv": (C.c_int, [_VP, _VP, _VP]),
     "sgpu_residual": (C.c_int, [_VP, _VP, _VP, _VP]),
     "sgpu_jacobi": (C.c_int, [_VP, C.c_int, C.c_double, _VP, _VP]),
@@ -234,6 +236,12 @@ class Operator:
     def set_lanes_per_row(self, lanes):
         check(lib().sgpu_op_set_lanes_per_row(self.h, int(lanes)))
 
+    def autotune(self):
+        check(lib().sgpu_op_autotune(self.h))
+
+    def set_variant(self, variant):
+        check(lib().sgpu_op_set_variant(self.h, int(variant)))
+
     def spmv(self, v, w):
         check(lib().sgpu_spmv(self.h, v.ptr, w.ptr))
 
@@ -290,7 +298,7 @@ class Operator:
 class Amg:
     """sgpu_amg over Operators A[l], P[l], R[l]."""
 
-    def __init__(self, A, P, R, eig_max=None, pre=3, post=3, smoother="jacobi", max_iter=100, tol=1e-8):
+    def __init__(self, A, P, R, eig_max=None, pre=3, post=3, smoother="jacobi", max_iter=100, tol=1e-8, use_graph=True, coarse_solver="direct"):
         self.A, self.P, self.R = list(A), list(P), list(R)
         n = len(A)
         prm = AmgParams()
@@ -298,6 +306,8 @@ class Amg:
         prm.preSmooth, prm.postSmooth = pre, post
         prm.smoother = 0 if smoother == "jacobi" else 1
         prm.solver_max_iter, prm.solver_tol = max_iter, tol
+        prm.use_graph = 1 if use_graph else 0
+        prm.coarse_solver = 1 if coarse_solver == "direct" else 0
         HA = (_VP * n)(*[a.h for a in A])
         HP = (_VP * n)(*([p.h for p in P] + [None] * (n - len(P))))
         HR = (_VP * n)(*([r.h for r in R] + [None] * (n - len(R))))

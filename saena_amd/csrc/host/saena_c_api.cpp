@@ -4,6 +4,7 @@
 #include "amg_setup.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <memory>
 #include <string>
 
@@ -271,6 +272,10 @@ int saena_amg_to_device(saena_amg_h *S) {
             fill_desc(g.R.L, nullptr, &d); if (gchk(sgpu_op_create(&d, &o))) return -2; S->dR.push_back(o);
         }
     }
+    if (!std::getenv("SAENA_NO_AUTOTUNE"))
+        for (auto *v : {&S->dA, &S->dP, &S->dR})
+            for (sgpu_op *o : *v)
+                if (gchk(sgpu_op_autotune(o))) return -2;
     sgpu_amg_params p;
     sgpu_amg_default_params(&p);
     const amg_options &o = S->H.opts;

@@ -29,7 +29,7 @@ namespace sk {
 
 constexpr int BLOCK   = 256;    // 4 waves
 constexpr int CAP     = 2048;   // products staged per row block (16 KiB of LDS)
-constexpr int LDS_N   = CAP + 8;
+constexpr int CAP_BIG = 4096;   // alternative plan: 32 KiB of LDS, half the blocks
 constexpr int MAXROWS = 256;    // rows per row block (one pass at 1 lane/row)
 constexpr int NXCD    = 8;
 
@@ -127,16 +127,22 @@ __device__ __forceinline__ double group_sum(double v) {
 //   phase 2: G lanes per row add the row's products in column order (G = 1
 //            reproduces the reference's sequential sum bit for bit) and the
 //            group leader applies the epilogue.
-// A row block with a single row longer than CAP takes the long-row path.
-template <int EPI, int G>
+// A row block with a single row longer than CAPV takes the long-row path.
+// CAPV = products staged per block (LDS = 8 CAPV bytes); P1 = phase-1 flavour:
+//   0  one quad at a time (load, gather, store per iteration)
+//   1  every val/col load of the block is issued before the first gather, then all
+//      gathers, then the LDS stores: 3x the bytes in flight per wave, which is what
+//      an operator larger than the 256 MiB Infinity Cache needs to cover HBM latency.
+template <int EPI, int G, int CAPV, int P1>
 __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
-    __shared__ __attribute__((aligned(16))) double lds[LDS_N];
+    constexpr int LDSN = CAPV + 8;
+    __shared__ __attribute__((aligned(16))) double lds[LDSN];
     const int tid = threadIdx.x;
     const int b   = xcd_remap(blockIdx.x, a.nblk);
     const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
     const int p0 = a.row_ptr[r0], p1 = a.row_ptr[r1];
 
-    if (r1 - r0 == 1 && p1 - p0 > CAP) {              // ---- one long row
+    if (r1 - r0 == 1 && p1 - p0 > CAPV) {             // ---- one long row
         double s = 0.0;
         for (int k = p0 + tid; k < p1; k += BLOCK) s += a.val[k] * a.x[a.col[k]];
         s = group_sum<64>(s);
@@ -152,26 +158,90 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
         return;
     }
 
-    // ---- phase 1: coalesced 16-B loads of val/col, gather x, products to LDS
-    const int a0 = p0 & ~3;
-    const int nq = (p1 - a0 + 3) >> 2;                // quads of 4 nnz
-    constexpr int ITER = (LDS_N / 4 + BLOCK - 1) / BLOCK;
+    // ---- phase 1: coalesced loads of val/col, gather x, products to LDS
+    // P1 = 0/1: a lane owns 4 consecutive nnz (16-B val/col loads);  P1 = 2: 2 consecutive nnz
+    // (16-B val, 8-B col);  P1 = 3: 1 nnz, lane-stride 1.  Narrower ownership makes the 64
+    // lanes of one x-gather instruction touch consecutive nnz = neighbouring columns = few
+    // cache lines, which is what bounds operators with scattered columns (the TA walks one
+    // line per clock); wide ownership minimises load instructions for band-like rows.
+    constexpr int OWN = (P1 == 2) ? 2 : (P1 == 3) ? 1 : 4;
+    const int a0 = p0 & ~(OWN - 1);
+    if constexpr (P1 == 2 || P1 == 3) {
+        const int nu = (p1 - a0 + OWN - 1) / OWN;    // units of OWN nnz
+        constexpr int ITER = (LDSN / OWN + BLOCK - 1) / BLOCK;
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int q = tid + it * BLOCK;
-        if (q < nq) {
-            const int idx = a0 + 4 * q;
-            const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
-            const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
-            const int4    c   = *reinterpret_cast<const int4 *>(a.col + idx);
-            double2 o01, o23;
-            o01.x = v01.x * a.x[c.x];
-            o01.y = v01.y * a.x[c.y];
-            o23.x = v23.x * a.x[c.z];
-            o23.y = v23.y * a.x[c.w];
-            *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
-            *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
+        for (int it = 0; it < ITER; ++it) {
+            const int q = tid + it * BLOCK;
+            if (q < nu) {
+                const int idx = a0 + OWN * q;
+                if constexpr (OWN == 2) {
+                    const double2 v = *reinterpret_cast<const double2 *>(a.val + idx);
+                    const int2    c = *reinterpret_cast<const int2 *>(a.col + idx);
+                    double2 o;
+                    o.x = v.x * a.x[c.x];
+                    o.y = v.y * a.x[c.y];
+                    *reinterpret_cast<double2 *>(&lds[2 * q]) = o;
+                } else {
+                    lds[q] = a.val[idx] * a.x[a.col[idx]];
+                }
+            }
         }
+    } else {
+    const int nq = (p1 - a0 + 3) >> 2;                // quads of 4 nnz
+    constexpr int ITER = (LDSN / 4 + BLOCK - 1) / BLOCK;
+    if constexpr (P1 == 0) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int q = tid + it * BLOCK;
+            if (q < nq) {
+                const int idx = a0 + 4 * q;
+                const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
+                const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
+                const int4    c   = *reinterpret_cast<const int4 *>(a.col + idx);
+                double2 o01, o23;
+                o01.x = v01.x * a.x[c.x];
+                o01.y = v01.y * a.x[c.y];
+                o23.x = v23.x * a.x[c.z];
+                o23.y = v23.y * a.x[c.w];
+                *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
+                *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
+            }
+        }
+    } else {
+        double2 v01[ITER], v23[ITER];
+        int4    c[ITER];
+        const int qlast = nq > 0 ? nq - 1 : 0;        // clamp: out-of-range lanes re-read the last quad (padded arrays)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            int q = tid + it * BLOCK;
+            q = q < qlast ? q : qlast;
+            const int idx = a0 + 4 * q;
+            v01[it] = *reinterpret_cast<const double2 *>(a.val + idx);
+            v23[it] = *reinterpret_cast<const double2 *>(a.val + idx + 2);
+            c[it]   = *reinterpret_cast<const int4 *>(a.col + idx);
+        }
+        double2 o01[ITER], o23[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            o01[it].x = a.x[c[it].x];
+            o01[it].y = a.x[c[it].y];
+            o23[it].x = a.x[c[it].z];
+            o23[it].y = a.x[c[it].w];
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int q = tid + it * BLOCK;
+            if (q < nq) {
+                double2 w01, w23;
+                w01.x = v01[it].x * o01[it].x;
+                w01.y = v01[it].y * o01[it].y;
+                w23.x = v23[it].x * o23[it].x;
+                w23.y = v23[it].y * o23[it].y;
+                *reinterpret_cast<double2 *>(&lds[4 * q])     = w01;
+                *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = w23;
+            }
+        }
+    }
     }
     __syncthreads();
 
@@ -186,6 +256,35 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
         if (l == 0) {
             if (a.rows) epilogue_remote<EPI>(a, a.rows[r], sum); else epilogue<EPI>(a, r, sum);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1b: vector CSR (no LDS staging): G lanes own one row and stream it straight from
+// global memory, 256/G rows per workgroup.  Rows are contiguous in val/col, so a
+// wave still reads whole 128-B lines; there is no barrier and no LDS round trip.
+template <int EPI, int G>
+__global__ __launch_bounds__(BLOCK) void k_csr_vector(const SpmvArgs a, int nrows) {
+    constexpr int RPB = BLOCK / G;
+    const int nb = (nrows + RPB - 1) / RPB;
+    const int b = xcd_remap(blockIdx.x, nb);
+    const int tid = threadIdx.x;
+    const int r = b * RPB + tid / G, l = tid % G;
+    double sum = 0.0;
+    if (r < nrows) {
+        const int p0 = a.row_ptr[r], p1 = a.row_ptr[r + 1];
+        int k = p0 + l;
+        for (; k + G < p1; k += 2 * G) {              // two independent loads in flight per lane
+            const double v0 = a.val[k], v1 = a.val[k + G];
+            const int c0 = a.col[k], c1 = a.col[k + G];
+            sum += v0 * a.x[c0];
+            sum += v1 * a.x[c1];
+        }
+        if (k < p1) sum += a.val[k] * a.x[a.col[k]];
+    }
+    sum = group_sum<G>(sum);
+    if (r < nrows && l == 0) {
+        if (a.rows) epilogue_remote<EPI>(a, a.rows[r], sum); else epilogue<EPI>(a, r, sum);
     }
 }
 
@@ -339,6 +438,23 @@ __global__ __launch_bounds__(CG_BLOCK) void k_coarse_cg(const CoarseCGArgs a) {
     for (int j = tid; j < n; j += CG_BLOCK) a.u[j] = uu[j];
     if (i == max_iter && max_iter != 0) i--;
     if (tid == 0 && a.iters_out) *a.iters_out = i;
+}
+
+// Coarsest-level direct solve: u = Ainv rhs with the dense inverse computed once on the host
+// (the reference factors the coarsest operator with SuperLU_DIST at setup and solves every V-cycle,
+// src/saena_object_solve.cpp:793-958).  One workgroup; a wave per row, lanes over columns.
+__global__ __launch_bounds__(CG_BLOCK) void k_dense_solve(const double *__restrict__ Ainv, const double *__restrict__ rhs,
+                                                          double *__restrict__ u, int n) {
+    __shared__ double r[CG_MAXN];
+    for (int i = threadIdx.x; i < n; i += CG_BLOCK) r[i] = rhs[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = wave; i < n; i += CG_BLOCK / 64) {
+        double s = 0.0;
+        for (int j = lane; j < n; j += 64) s += Ainv[(size_t)i * n + j] * r[j];
+        s = group_sum<64>(s);
+        if (lane == 0) u[i] = s;
+    }
 }
 
 } // namespace sk

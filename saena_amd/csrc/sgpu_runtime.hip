@@ -66,6 +66,12 @@ Ctx g;
 
 int need_ctx() { return g.live ? SGPU_OK : fail(SGPU_ERR_STATE, "sgpu_init has not been called"); }
 
+struct DevBuf {
+    double *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(1, n) * sizeof(double)) == hipSuccess ? SGPU_OK : fail(SGPU_ERR_NOMEM, "hipMalloc failed"); }
+};
+
 template <class T>
 int dev_upload(T **dst, const T *src, size_t n, size_t pad = 0) {
     *dst = nullptr;
@@ -82,13 +88,15 @@ int dev_upload(T **dst, const T *src, size_t n, size_t pad = 0) {
 struct CsrPart {
     int     nrows = 0;            // rows covered by row_ptr (M, or number of remote rows)
     int64_t nnz = 0;
-    int    *row_ptr = nullptr, *col = nullptr, *blk_row = nullptr, *rows = nullptr;
+    int    *row_ptr = nullptr, *col = nullptr, *blk_row = nullptr, *blk_row_big = nullptr, *rows = nullptr;
     double *val = nullptr;
-    int     nblk = 0;
+    int     nblk = 0, nblk_big = 0;
     int     lanes = 1;            // G
+    int     variant = 0;          // 0 stream CAP/quad, 1 quad+hoist, 2 CAP_BIG quad+hoist, 3 vector CSR,
+                                  // 4 CAP/pair, 5 CAP/single, 6 CAP_BIG/pair, 7 CAP_BIG/single
     void free_all() {
-        hipFree(row_ptr); hipFree(col); hipFree(blk_row); hipFree(rows); hipFree(val);
-        row_ptr = col = blk_row = rows = nullptr; val = nullptr;
+        hipFree(row_ptr); hipFree(col); hipFree(blk_row); hipFree(blk_row_big); hipFree(rows); hipFree(val);
+        row_ptr = col = blk_row = blk_row_big = rows = nullptr; val = nullptr;
     }
 };
 
@@ -96,7 +104,7 @@ int pow2floor(int x) { int p = 1; while (2 * p <= x) p *= 2; return p; }
 
 // Row-block plan: consecutive rows while the block holds <= CAP products and
 // <= MAXROWS rows; a row longer than CAP gets a block of its own.
-void plan_blocks(const std::vector<int> &rp, std::vector<int> &blk) {
+void plan_blocks(const std::vector<int> &rp, std::vector<int> &blk, int cap, int maxrows) {
     const int M = (int)rp.size() - 1;
     blk.clear();
     blk.push_back(0);
@@ -104,7 +112,7 @@ void plan_blocks(const std::vector<int> &rp, std::vector<int> &blk) {
     while (r < M) {
         const int start = r;
         const int p0 = rp[r];
-        while (r < M && r - start < sk::MAXROWS && rp[r + 1] - p0 <= sk::CAP) ++r;
+        while (r < M && r - start < maxrows && rp[r + 1] - p0 <= cap) ++r;
         if (r == start) ++r;      // long row
         blk.push_back(r);
     }
@@ -120,10 +128,13 @@ int build_part(CsrPart &P, const std::vector<int> &rp, const std::vector<int> &c
                const std::vector<int> *rows) {
     P.nrows = (int)rp.size() - 1;
     P.nnz   = rp.back();
-    std::vector<int> blk;
-    plan_blocks(rp, blk);
+    std::vector<int> blk, blk_big;
+    plan_blocks(rp, blk, sk::CAP, sk::MAXROWS);
+    plan_blocks(rp, blk_big, sk::CAP_BIG, 2 * sk::MAXROWS);
     P.nblk  = (int)blk.size() - 1;
+    P.nblk_big = (int)blk_big.size() - 1;
     P.lanes = auto_lanes(P.nrows, P.nblk);
+    CHK(dev_upload(&P.blk_row_big, blk_big.data(), blk_big.size()));
     CHK(dev_upload(&P.row_ptr, rp.data(), rp.size()));
     CHK(dev_upload(&P.col, col.data(), col.size(), 8));
     CHK(dev_upload(&P.val, val.data(), val.size(), 8));
@@ -148,34 +159,69 @@ struct sgpu_op {
     std::vector<int> sendRank, sendCount, sendDispl, recvRank, recvCount, recvDispl;
     int     halo_fp32 = 0;
     bool    injected = false;     // test hook: halo supplied by sgpu_debug_inject_halo
+    std::vector<int> h_rp, h_col; std::vector<double> h_val;   // host copy of small local parts (coarsest-level factorisation)
     hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
 };
 
 namespace {
 
 using KernelFn = void (*)(const sk::SpmvArgs);
+using VecKernelFn = void (*)(const sk::SpmvArgs, int);
 
-template <int EPI>
+template <int EPI, int CAPV, int P1>
 KernelFn pick_g(int lanes) {
     switch (lanes) {
-        case 1:  return sk::k_csr_stream<EPI, 1>;
-        case 2:  return sk::k_csr_stream<EPI, 2>;
-        case 4:  return sk::k_csr_stream<EPI, 4>;
-        case 8:  return sk::k_csr_stream<EPI, 8>;
-        case 16: return sk::k_csr_stream<EPI, 16>;
-        case 32: return sk::k_csr_stream<EPI, 32>;
-        default: return sk::k_csr_stream<EPI, 64>;
+        case 1:  return sk::k_csr_stream<EPI, 1, CAPV, P1>;
+        case 2:  return sk::k_csr_stream<EPI, 2, CAPV, P1>;
+        case 4:  return sk::k_csr_stream<EPI, 4, CAPV, P1>;
+        case 8:  return sk::k_csr_stream<EPI, 8, CAPV, P1>;
+        case 16: return sk::k_csr_stream<EPI, 16, CAPV, P1>;
+        case 32: return sk::k_csr_stream<EPI, 32, CAPV, P1>;
+        default: return sk::k_csr_stream<EPI, 64, CAPV, P1>;
     }
 }
-
-KernelFn pick(int epi, int lanes) {
+template <int EPI>
+KernelFn pick_v(int lanes, int variant) {
+    switch (variant) {
+        case 1:  return pick_g<EPI, sk::CAP, 1>(lanes);
+        case 2:  return pick_g<EPI, sk::CAP_BIG, 1>(lanes);
+        case 4:  return pick_g<EPI, sk::CAP, 2>(lanes);
+        case 5:  return pick_g<EPI, sk::CAP, 3>(lanes);
+        case 6:  return pick_g<EPI, sk::CAP_BIG, 2>(lanes);
+        case 7:  return pick_g<EPI, sk::CAP_BIG, 3>(lanes);
+        default: return pick_g<EPI, sk::CAP, 0>(lanes);
+    }
+}
+KernelFn pick(int epi, int lanes, int variant) {
     switch (epi) {
-        case sk::EPI_SPMV:     return pick_g<sk::EPI_SPMV>(lanes);
-        case sk::EPI_RESIDUAL: return pick_g<sk::EPI_RESIDUAL>(lanes);
-        case sk::EPI_JACOBI:   return pick_g<sk::EPI_JACOBI>(lanes);
-        case sk::EPI_CHEBY0:   return pick_g<sk::EPI_CHEBY0>(lanes);
-        case sk::EPI_CHEBYK:   return pick_g<sk::EPI_CHEBYK>(lanes);
-        default:               return pick_g<sk::EPI_SUB>(lanes);
+        case sk::EPI_SPMV:     return pick_v<sk::EPI_SPMV>(lanes, variant);
+        case sk::EPI_RESIDUAL: return pick_v<sk::EPI_RESIDUAL>(lanes, variant);
+        case sk::EPI_JACOBI:   return pick_v<sk::EPI_JACOBI>(lanes, variant);
+        case sk::EPI_CHEBY0:   return pick_v<sk::EPI_CHEBY0>(lanes, variant);
+        case sk::EPI_CHEBYK:   return pick_v<sk::EPI_CHEBYK>(lanes, variant);
+        default:               return pick_v<sk::EPI_SUB>(lanes, variant);
+    }
+}
+template <int EPI>
+VecKernelFn pick_vec_g(int lanes) {
+    switch (lanes) {
+        case 1:  return sk::k_csr_vector<EPI, 1>;
+        case 2:  return sk::k_csr_vector<EPI, 2>;
+        case 4:  return sk::k_csr_vector<EPI, 4>;
+        case 8:  return sk::k_csr_vector<EPI, 8>;
+        case 16: return sk::k_csr_vector<EPI, 16>;
+        case 32: return sk::k_csr_vector<EPI, 32>;
+        default: return sk::k_csr_vector<EPI, 64>;
+    }
+}
+VecKernelFn pick_vec(int epi, int lanes) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return pick_vec_g<sk::EPI_SPMV>(lanes);
+        case sk::EPI_RESIDUAL: return pick_vec_g<sk::EPI_RESIDUAL>(lanes);
+        case sk::EPI_JACOBI:   return pick_vec_g<sk::EPI_JACOBI>(lanes);
+        case sk::EPI_CHEBY0:   return pick_vec_g<sk::EPI_CHEBY0>(lanes);
+        case sk::EPI_CHEBYK:   return pick_vec_g<sk::EPI_CHEBYK>(lanes);
+        default:               return pick_vec_g<sk::EPI_SUB>(lanes);
     }
 }
 
@@ -188,10 +234,19 @@ struct EpiArgs {
 int launch_part(const CsrPart &P, int epi, const double *x, double *y, const EpiArgs &e) {
     if (P.nblk == 0) return SGPU_OK;
     sk::SpmvArgs a;
-    a.row_ptr = P.row_ptr; a.col = P.col; a.val = P.val; a.blk_row = P.blk_row;
+    a.row_ptr = P.row_ptr; a.col = P.col; a.val = P.val;
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
-    a.c0 = e.c0; a.c1 = e.c1; a.nblk = P.nblk; a.rows = P.rows;
-    hipLaunchKernelGGL(pick(epi, P.lanes), dim3(P.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+    a.c0 = e.c0; a.c1 = e.c1; a.rows = P.rows;
+    if (P.variant == 3) {
+        const int rpb = sk::BLOCK / P.lanes;
+        a.blk_row = nullptr; a.nblk = 0;
+        hipLaunchKernelGGL(pick_vec(epi, P.lanes), dim3((P.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
+    } else {
+        const bool big = P.variant == 2 || P.variant == 6 || P.variant == 7;
+        a.blk_row = big ? P.blk_row_big : P.blk_row;
+        a.nblk = big ? P.nblk_big : P.nblk;
+        hipLaunchKernelGGL(pick(epi, P.lanes, P.variant), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+    }
     HIPCHK(hipGetLastError());
     return SGPU_OK;
 }
@@ -440,6 +495,7 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         }
         std::vector<double> val(d->val_local, d->val_local + d->nnz_l_local);
         CHK(build_part(op->loc, rp, col, val, nullptr));
+        if (d->M <= sk::CG_MAXN) { op->h_rp = rp; op->h_col = col; op->h_val = val; }
     }
     // remote part: CSC over the receive buffer -> CSR over the halo buffer on the rows that own remote entries
     if (d->nnz_l_remote > 0) {
@@ -533,6 +589,41 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
     return SGPU_OK;
 }
 
+int sgpu_op_set_variant(sgpu_op *op, int variant) {
+    if (!op) return fail(SGPU_ERR_ARG, "null op");
+    if (variant < 0 || variant > 7) return fail(SGPU_ERR_ARG, "variant must be 0..7");
+    op->loc.variant = variant;
+    return SGPU_OK;
+}
+
+// Plan-time autotune of the local kernel: time a handful of (variant, lanes) candidates on the
+// operator itself and keep the fastest.  Summation order inside a row depends on the choice, so
+// results may differ at rounding level between choices (never between runs of one choice).
+int sgpu_op_autotune(sgpu_op *op) {
+    CHK(need_ctx());
+    if (!op) return fail(SGPU_ERR_ARG, "null op");
+    if (op->loc.nnz < 200000) return SGPU_OK;          // launch-latency territory: keep the heuristic
+    const int g0 = auto_lanes(op->loc.nrows, op->loc.nblk);
+    std::vector<int> lanes;
+    for (int g : {g0 / 2, g0, g0 * 2}) if (g >= 1 && g <= 64) lanes.push_back(g);
+    DevBuf x, y, r;
+    CHK(x.alloc(op->N_local)); CHK(y.alloc(op->M)); CHK(r.alloc(op->M));
+    CHK(sgpu_vec_fill(x.p, 1.0, op->N_local)); CHK(sgpu_vec_fill(r.p, 1.0, op->M));
+    const int kind = op->inv_diag ? 1 : 0;
+    float best = 1e30f;
+    int bv = 0, bg = g0;
+    for (int round = 0; round < 2; ++round)
+        for (int v : {0, 2, 3})
+            for (int gl : lanes) {
+                op->loc.variant = v; op->loc.lanes = gl;
+                float ms = 0;
+                CHK(sgpu_time_kernel(op, kind, x.p, r.p, y.p, round == 0 ? 2 : 6, &ms));
+                if (round == 1 && ms < best) { best = ms; bv = v; bg = gl; }
+            }
+    op->loc.variant = bv; op->loc.lanes = bg;
+    return SGPU_OK;
+}
+
 int sgpu_spmv(sgpu_op *op, const value_t *v, value_t *w) {
     CHK(need_ctx());
     if (!op || !v || !w) return fail(SGPU_ERR_ARG, "null argument");
@@ -593,13 +684,6 @@ int sgpu_debug_inject_halo(sgpu_op *op, const value_t *recv_host) {
 }
 
 // ---- host-slice forms ----
-namespace {
-struct DevBuf {
-    double *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    int alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(1, n) * sizeof(double)) == hipSuccess ? SGPU_OK : fail(SGPU_ERR_NOMEM, "hipMalloc failed"); }
-};
-}
 
 int sgpu_spmv_host(sgpu_op *op, const value_t *v_host, value_t *w_host) {
     CHK(need_ctx());
@@ -643,6 +727,11 @@ struct sgpu_amg {
     double *alt0 = nullptr;   // ping-pong partner of the caller's level-0 u
     // solve work vectors (level 0)
     double *r = nullptr, *rho = nullptr, *hh = nullptr, *p = nullptr;
+    // captured V-cycles, one per (u, rhs) pointer pair (single rank): replaying a hipGraph removes
+    // the ~70 launch gaps of a V-cycle, which weigh as much as a whole coarse level
+    struct Captured { double *u; const double *rhs; hipGraph_t graph; hipGraphExec_t exec; };
+    double *Ainv = nullptr;   // dense inverse of the coarsest operator (coarse_solver == 1)
+    std::vector<Captured> graphs;
 };
 
 namespace {
@@ -699,6 +788,12 @@ int coarse_cg_dist(sgpu_amg *h, sgpu_op *A, double *u, const double *rhs, int *i
 
 int coarse_solve(sgpu_amg *h, double *u, const double *rhs, int *iters) {
     sgpu_op *A = h->A[h->nlevels - 1];
+    if (h->Ainv) {
+        hipLaunchKernelGGL(sk::k_dense_solve, dim3(1), dim3(sk::CG_BLOCK), 0, g.cs, h->Ainv, rhs, u, (int)A->M);
+        HIPCHK(hipGetLastError());
+        if (iters) *iters = 0;
+        return SGPU_OK;
+    }
     if (g.nranks == 1) return coarse_cg_single(h, A, u, rhs, iters);
     return coarse_cg_dist(h, A, u, rhs, iters);
 }
@@ -741,10 +836,30 @@ int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, 
     return SGPU_OK;
 }
 
-int vcycle0(sgpu_amg *h, double *u, const double *rhs) {
+int vcycle0_eager(sgpu_amg *h, double *u, const double *rhs) {
     double *out = nullptr;
     CHK(vcycle_level(h, 0, u, h->alt0, rhs, &out));
     if (out != u) HIPCHK(hipMemcpyAsync(u, out, (size_t)h->A[0]->M * sizeof(double), hipMemcpyDeviceToDevice, g.cs));
+    return SGPU_OK;
+}
+
+int vcycle0(sgpu_amg *h, double *u, const double *rhs) {
+    if (!h->prm.use_graph || g.nranks > 1) return vcycle0_eager(h, u, rhs);
+    for (auto &c : h->graphs)
+        if (c.u == u && c.rhs == rhs) { HIPCHK(hipGraphLaunch(c.exec, g.cs)); return SGPU_OK; }
+    sgpu_amg::Captured c{u, rhs, nullptr, nullptr};
+    HIPCHK(hipStreamBeginCapture(g.cs, hipStreamCaptureModeThreadLocal));
+    const int st = vcycle0_eager(h, u, rhs);
+    const hipError_t e = hipStreamEndCapture(g.cs, &c.graph);
+    if (st != SGPU_OK) { if (c.graph) hipGraphDestroy(c.graph); return st; }
+    if (e != hipSuccess) return fail(SGPU_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    HIPCHK(hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0));
+    if (h->graphs.size() >= 8) {                  // bounded cache
+        hipGraphExecDestroy(h->graphs.front().exec); hipGraphDestroy(h->graphs.front().graph);
+        h->graphs.erase(h->graphs.begin());
+    }
+    h->graphs.push_back(c);
+    HIPCHK(hipGraphLaunch(c.exec, g.cs));
     return SGPU_OK;
 }
 
@@ -755,9 +870,9 @@ extern "C" {
 int sgpu_amg_default_params(sgpu_amg_params *p) {
     if (!p) return fail(SGPU_ERR_ARG, "null params");
     p->preSmooth = 3; p->postSmooth = 3; p->smoother = 1;          /* saena.hpp:151-155: "chebyshev", 3, 3 */
-    p->jacobi_omega = 0.0; p->coarse_solver = 0;
+    p->jacobi_omega = 0.0; p->coarse_solver = 1;                   /* saena_object.h:165 direct_solver = "SuperLU" */
     p->CG_coarsest_max_iter = 150; p->CG_coarsest_tol = 1e-12;    /* saena_object.h:155-156 */
-    p->solver_max_iter = 100; p->solver_tol = 1e-8; p->use_graph = 0;
+    p->solver_max_iter = 100; p->solver_tol = 1e-8; p->use_graph = 1;
     return SGPU_OK;
 }
 
@@ -789,6 +904,34 @@ int sgpu_amg_create(int nlevels, sgpu_op *const *A, sgpu_op *const *P, sgpu_op *
         if (l < nlevels - 1) HIPCHK(alloc(&h->res[l], n));
         if (l >= 1) { HIPCHK(alloc(&h->rhs[l], n)); HIPCHK(alloc(&h->u[l], n)); HIPCHK(alloc(&h->alt[l], n)); }
     }
+    if (h->prm.coarse_solver == 1 && g.nranks == 1) {
+        // dense inverse by Gauss-Jordan with partial pivoting (host, once)
+        sgpu_op *Ac = A[nlevels - 1];
+        const int n = Ac->M;
+        if (n > sk::CG_MAXN || (n > 0 && Ac->h_rp.empty())) return fail(SGPU_ERR_ARG, "coarsest level too large for the dense direct solve (%d rows)", n);
+        std::vector<double> a((size_t)n * n, 0.0), inv((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i) {
+            inv[(size_t)i * n + i] = 1.0;
+            for (int k = Ac->h_rp[i]; k < Ac->h_rp[i + 1]; ++k) a[(size_t)i * n + Ac->h_col[k]] = Ac->h_val[k];
+        }
+        for (int c = 0; c < n; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < n; ++r) if (std::fabs(a[(size_t)r * n + c]) > std::fabs(a[(size_t)piv * n + c])) piv = r;
+            if (a[(size_t)piv * n + c] == 0.0) return fail(SGPU_ERR_ARG, "coarsest operator is singular");
+            if (piv != c) for (int j = 0; j < n; ++j) { std::swap(a[(size_t)piv * n + j], a[(size_t)c * n + j]); std::swap(inv[(size_t)piv * n + j], inv[(size_t)c * n + j]); }
+            const double d = 1.0 / a[(size_t)c * n + c];
+            for (int j = 0; j < n; ++j) { a[(size_t)c * n + j] *= d; inv[(size_t)c * n + j] *= d; }
+            for (int r = 0; r < n; ++r) {
+                if (r == c) continue;
+                const double f = a[(size_t)r * n + c];
+                if (f == 0.0) continue;
+                for (int j = 0; j < n; ++j) { a[(size_t)r * n + j] -= f * a[(size_t)c * n + j]; inv[(size_t)r * n + j] -= f * inv[(size_t)c * n + j]; }
+            }
+        }
+        CHK(dev_upload(&h->Ainv, inv.data(), inv.size()));
+    }
+    for (int l = 0; l < nlevels - 1; ++l)          // no allocation may happen inside a graph capture
+        if (h->prm.smoother == 1) CHK(ensure_d(A[l]));
     const size_t n0 = (size_t)A[0]->M;
     HIPCHK(alloc(&h->alt0, n0));
     HIPCHK(alloc(&h->r, n0)); HIPCHK(alloc(&h->rho, n0)); HIPCHK(alloc(&h->hh, n0)); HIPCHK(alloc(&h->p, n0));
@@ -803,6 +946,8 @@ int sgpu_amg_destroy(sgpu_amg *h) {
     for (auto p : h->rhs) hipFree(p);
     for (auto p : h->u) hipFree(p);
     for (auto p : h->alt) hipFree(p);
+    for (auto &c : h->graphs) { hipGraphExecDestroy(c.exec); hipGraphDestroy(c.graph); }
+    hipFree(h->Ainv);
     hipFree(h->alt0); hipFree(h->r); hipFree(h->rho); hipFree(h->hh); hipFree(h->p);
     delete h;
     return SGPU_OK;

@@ -77,6 +77,14 @@ def main():
     capi.check(capi.lib().sgpu_device_sync())
     dt = (time.time() - t0) / n
     print(f"raw V-cycle: {dt * 1e3:.3f} ms -> {1 / dt:.1f} V-cycles/s", flush=True)
+    nc = S.level_info(S.num_levels - 1)["rows"]
+    cu, cr = capi.DeviceVector(nc, np.zeros(nc)), capi.DeviceVector(nc, np.ones(nc))
+    import ctypes as C
+    t0 = time.time()
+    for _ in range(n):
+        capi.check(capi.lib().sgpu_coarsest_solve(h, cu.ptr, cr.ptr, None))
+    capi.check(capi.lib().sgpu_device_sync())
+    print(f"coarsest solve: {(time.time() - t0) / n * 1e6:.1f} us", flush=True)
 
 
 if __name__ == "__main__":

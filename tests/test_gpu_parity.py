@@ -108,6 +108,30 @@ def test_spmv_lane_variants(capi, name, lanes):
     assert np.all(np.abs(got - want) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
 
 
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+def test_kernel_variants(capi, name, variant):
+    """hoisted-load / 32 KiB / vector-CSR variants of the local kernel: same results"""
+    entries, M = get_problem(name)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    G.set_variant(variant)
+    x, rhs = inputs.v2(M), inputs.rhs2(M)
+    bound = abs_bound(entries, M, x)
+    dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
+    for lanes in (1, 4, 16, 64):
+        G.set_lanes_per_row(lanes)
+        G.spmv(dx, dy)
+        got, want = dy.download(), A.matvec(x)
+        if lanes == 1 and variant != 3 and name != "band3000_1400":
+            np.testing.assert_array_equal(got, want)          # stream variants keep the sequential row sum
+        else:
+            assert np.all(np.abs(got - want) <= TOL_SPMV * bound + 1e-300)
+        du = capi.DeviceVector(M, x)
+        G.jacobi(2, du, dr)
+        assert rel(du.download(), A.jacobi(2, x, rhs)) <= TOL_SMOOTH
+
+
 @pytest.mark.parametrize("name", ["poisson12", "poisson20", "band300_7", "irregular5000"])
 def test_residual_jacobi_chebyshev(capi, name):
     entries, M = get_problem(name)

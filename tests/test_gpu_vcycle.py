@@ -33,7 +33,7 @@ def hier():
     return As, Ps, Rs
 
 
-def build(capi, hier, smoother, pre=3, post=3, max_iter=60, tol=1e-8):
+def build(capi, hier, smoother, pre=3, post=3, max_iter=60, tol=1e-8, use_graph=True, coarse_solver="direct"):
     As, Ps, Rs = hier
     OA, OP, OR = hierarchy.oracle_hierarchy(As, Ps, Rs)
     eig = hierarchy.eig_estimates(As)
@@ -43,7 +43,8 @@ def build(capi, hier, smoother, pre=3, post=3, max_iter=60, tol=1e-8):
     GA = [util.gpu_operator(a) for a in OA]
     GP = [util.gpu_operator(p) for p in OP]
     GR = [util.gpu_operator(r) for r in OR]
-    G = capi.Amg(GA, GP, GR, eig_max=eig, pre=pre, post=post, smoother=smoother, max_iter=max_iter, tol=tol)
+    G = capi.Amg(GA, GP, GR, eig_max=eig, pre=pre, post=post, smoother=smoother, max_iter=max_iter, tol=tol, use_graph=use_graph,
+                 coarse_solver=coarse_solver)
     return O, G, (OA, OP, OR), (GA, GP, GR)
 
 
@@ -51,8 +52,21 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
+def test_coarsest_direct(capi, hier):
+    """dense direct coarsest solve (the reference's default is SuperLU): equals the oracle's CG answer to its tolerance"""
+    O, G, (OA, _, _), _ = build(capi, hier, "jacobi", coarse_solver="direct")
+    n = OA[-1].Mbig
+    rhs = inputs.rhs2(n)
+    want, _ = O.coarsest_cg(rhs)
+    du, dr = capi.DeviceVector(n, np.ones(n)), capi.DeviceVector(n, rhs)     # the initial guess is ignored
+    G.coarsest_solve(du, dr)
+    assert rel(du.download(), want) <= 1e-10
+    r = OA[-1].residual(du.download(), rhs)
+    assert np.linalg.norm(r) <= 1e-13 * np.linalg.norm(rhs) * 10
+
+
 def test_coarsest_cg(capi, hier):
-    O, G, (OA, _, _), _ = build(capi, hier, "jacobi")
+    O, G, (OA, _, _), _ = build(capi, hier, "jacobi", coarse_solver="CG")
     n = OA[-1].Mbig
     rhs = inputs.rhs2(n)
     want, it_o = O.coarsest_cg(rhs)
@@ -93,6 +107,20 @@ def test_solve_and_pcg_histories(capi, hier, smoother):
         assert np.all(np.abs(hist_g - hist_o) <= 1e-6 * hist_o), (name, hist_g, hist_o)
         assert hist_g[-1] <= 1e-8 * hist_g[0]
         assert rel(du.download(), u_o) <= 1e-9
+
+
+@pytest.mark.parametrize("smoother", ["jacobi", "chebyshev"])
+def test_graph_replay_equals_eager(capi, hier, smoother):
+    """the hipGraph replay of a V-cycle is bit-identical to the eager launches, also when replayed"""
+    O, Gg, (OA, _, _), _ = build(capi, hier, smoother, use_graph=True)
+    _, Ge, _, _ = build(capi, hier, smoother, use_graph=False)
+    n = OA[0].Mbig
+    rhs, u0 = inputs.rhs2(n), inputs.v2(n) * 0.01
+    dug, due, dr = capi.DeviceVector(n, u0), capi.DeviceVector(n, u0), capi.DeviceVector(n, rhs)
+    for _ in range(3):                                  # first call captures, later calls replay
+        Gg.vcycle(dug, dr)
+        Ge.vcycle(due, dr)
+        np.testing.assert_array_equal(dug.download(), due.download())
 
 
 def test_two_level_and_single_level(capi):
