@@ -1,0 +1,54 @@
+// poisson.cpp -- the reference's experiments/Poisson.cpp flow on the MI355X path:
+//   ./poisson <mx> [options.xml]
+// 3D 7-point Poisson on an mx^3 grid: generate, assemble, AMG setup, 1 warm-up + timed solve_pCG.
+// Prints the residual lines the reference prints (src/saena_object_solve.cpp:2502,2681-2682).
+#include "saena.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+int main(int argc, char **argv) {
+    if (argc < 2) { printf("usage: %s <mx> [options.xml]\n", argv[0]); return 1; }
+    const index_t mx = atoi(argv[1]);
+    saena::init(0, 0, 1, nullptr);
+    saena::comm comm;
+    const int rank = comm.rank();
+
+    saena::matrix A(comm);
+    saena::laplacian3D(&A, mx, mx, mx);
+    A.assemble();
+
+    value_t *rhs_std = nullptr;
+    index_t first = 0;
+    const index_t sz = saena::laplacian3D_set_rhs(rhs_std, mx, mx, mx, comm, &first);
+    saena::vector rhs(comm);
+    rhs.set(rhs_std, sz, first);
+    rhs.assemble();
+
+    saena::options opts = argc > 2 ? saena::options(std::string(argv[2]))
+                                   : saena::options(50, 1e-8, "jacobi", 3, 3, "jacobi", 0.2f, true, 20, 3, 1e-14, 1e-8, 1, 2);
+    if (argc > 2) A.set_eig(std::string(argv[2]));
+
+    saena::amg solver;
+    solver.set_verbose(true);
+    auto t0 = std::chrono::steady_clock::now();
+    solver.set_matrix(&A, &opts);
+    solver.set_rhs(rhs);
+    auto t1 = std::chrono::steady_clock::now();
+    if (!rank) printf("setup: %.3f s\n", std::chrono::duration<double>(t1 - t0).count());
+
+    value_t *u = nullptr;
+    solver.solve_pCG(u, &opts, false);                    // warm-up
+    t0 = std::chrono::steady_clock::now();
+    solver.solve_pCG(u, &opts);
+    t1 = std::chrono::steady_clock::now();
+    if (!rank) printf("solve_pCG: %.3f ms, %d iterations\n", 1e3 * std::chrono::duration<double>(t1 - t0).count(), solver.last_iterations());
+
+    saena::free_vector(u);
+    free(rhs_std);
+    solver.destroy();
+    A.destroy();
+    saena::finalize();
+    return 0;
+}

@@ -1,0 +1,228 @@
+// saena.hpp -- the public C++ surface of Saena, kept for the MI355X path.
+//
+// Mirrors the reference's include/saena.hpp:14-265 (classes saena::matrix, saena::vector,
+// saena::options, saena::amg and the generator functions of include/aux_functions2.h:12-43) with
+// the same method names, argument meaning and defaults, and the index_t / nnz_t / value_t typedefs
+// of include/data_struct.h:36-38, so that a driver such as experiments/Poisson.cpp ports by
+// replacing `MPI_Comm` with `saena::comm`.  Only the members on (or feeding) the V-cycle hot path
+// are provided; GMRES, lazy updates, matmat, PETSc bridges etc. are out of scope.
+//
+// Differences from the reference, all at the boundary:
+//   * the communicator is the GPU runtime's (one process = one rank = one MI355X, RCCL), wrapped
+//     in saena::comm; saena::init()/finalize() replace MPI_Init/MPI_Finalize;
+//   * matvec / solve / solve_pCG run on the GPU through the C ABI of include/saena_gpu.h; there is
+//     no CPU fallback (calls fail with a message when no MI355X is visible);
+//   * errors throw std::runtime_error instead of printf + exit(EXIT_FAILURE).
+#pragma once
+#include <string>
+#include <vector>
+
+typedef int    index_t;   // Saena index type    (data_struct.h:36)
+typedef long   nnz_t;     // Saena nonzero type  (data_struct.h:37)
+typedef double value_t;   // Saena value type    (data_struct.h:38)
+
+namespace saena_host { class saena_matrix; class amg_hierarchy; struct Comm; }
+struct sgpu_op;
+struct sgpu_amg;
+
+namespace saena {
+
+// replaces MPI_Init / MPI_Comm_rank / MPI_Comm_size / MPI_Finalize
+// rccl_unique_id: 128 bytes from saena::unique_id() on rank 0 (any side channel), nullptr when nranks == 1
+void init(int device_id = 0, int rank = 0, int nranks = 1, const void *rccl_unique_id = nullptr);
+void unique_id(void *out128);
+void finalize();
+
+class comm {
+public:
+    comm();                       // the world communicator of saena::init()
+    int rank() const;
+    int size() const;
+    saena_host::Comm *impl() const { return c_; }
+private:
+    saena_host::Comm *c_;
+};
+
+class vector;
+
+class matrix {
+public:
+    matrix();
+    explicit matrix(comm c);
+    ~matrix();
+    matrix(const matrix &) = delete;
+    matrix &operator=(const matrix &) = delete;
+
+    void set_comm(comm c);
+    int set(index_t i, index_t j, value_t val);                                  // set individual value
+    int set(index_t *row, index_t *col, value_t *val, nnz_t nnz_local);          // set multiple values
+    int set(index_t i, index_t j, unsigned int size_x, unsigned int size_y, value_t *val);   // set contiguous block
+
+    void set_eig(const std::string &opts_fname);   // reads the optional eig="..." attribute of the options XML
+    void set_eig(double eig);
+    void set_remove_boundary(bool remove_bound);
+    bool add_dup = true;                           // if false replace the duplicate, otherwise add the values together
+    int  add_duplicates(bool add);
+
+    int assemble(bool scale = false, bool use_dense = false);
+    int assemble_band_matrix(bool use_dense = false);
+
+    saena_host::saena_matrix *get_internal_matrix();
+    comm    get_comm();
+    index_t get_num_rows();
+    index_t get_num_local_rows();
+    nnz_t   get_nnz();
+    nnz_t   get_local_nnz();
+    std::vector<index_t> get_orig_split();
+    std::vector<index_t> get_split();
+
+    // w = A v on this rank's slices (GPU)
+    void matvec(std::vector<value_t> &v, std::vector<value_t> &w);
+    void matvec(saena::vector &v, saena::vector &w);
+
+    int  erase();
+    void destroy();
+
+    sgpu_op *device_op();          // created on first use (sgpu_op_create)
+private:
+    comm c_;
+    saena_host::saena_matrix *m_pImpl;
+    sgpu_op *dev_ = nullptr;
+};
+
+class vector {
+public:
+    vector();
+    explicit vector(comm c);
+    void set_comm(comm c);
+    int set_idx_offset(index_t offset);
+    int set(index_t i, value_t val);                                   // set individual value
+    int set(const index_t *idx, const value_t *val, index_t size);     // set multiple values
+    int set(const value_t *val, index_t size, index_t offset);         // contiguous values starting at global index offset
+    int set(const value_t *val, index_t size);                         // contiguous values starting at idx_offset
+    int set_dup_flag(bool add);
+    int assemble();
+    void get_vec(value_t *&vec);        // this rank's values in ascending index order (owned by the vector)
+    index_t get_size() const { return (index_t)val_.size(); }
+    index_t first_index() const { return idx_.empty() ? 0 : idx_.front(); }
+    const std::vector<index_t> &indices() const { return idx_; }
+    comm get_comm() { return c_; }
+private:
+    comm c_;
+    index_t ofst_ = 0;
+    bool add_dup_ = false;
+    std::vector<index_t> idx_;
+    std::vector<value_t> val_;
+    bool assembled_ = false;
+};
+
+class options {
+private:
+    int    solver_max_iter;
+    double relative_tol;
+    std::string smoother;
+    int    preSmooth;
+    int    postSmooth;
+    std::string PSmoother;
+    float  connStrength;
+    bool   dynamic_levels;
+    int    max_level;
+    int    float_level;
+    double filter_thre;
+    double filter_max;
+    int    filter_start;
+    int    filter_rate;
+    bool   switch_to_dense;
+    float  dense_thre;
+    int    dense_sz_thre;
+    std::string petsc_solver;
+public:
+    explicit options(int max_iter = 100, double relative_tol = 1e-8, std::string smoother = "chebyshev",
+                     int preSmooth = 3, int postSmooth = 3, std::string PSmoother = "jacobi", float connStrength = 0.3,
+                     bool dynamic_lev = true, int max_lev = 10, int float_lev = 3,
+                     double fil_thr = 1e-14, double fil_max = 1e-8, int fil_st = 1, int fil_rate = 2,
+                     bool switch_to_den = false, float dense_thr = 0.1, int dense_sz_thr = 5000);
+    explicit options(const std::string &name);       // parameters from an xml file
+    void set(int max_iter = 100, double relative_tol = 1e-8, std::string smoother = "chebyshev",
+             int preSmooth = 3, int postSmooth = 3, std::string PSmoother = "jacobi", float connStrength = 0.3,
+             bool dynamic_lev = true, int max_lev = 10, int float_lev = 3,
+             double fil_thr = 1e-14, double fil_max = 1e-8, int fil_st = 1, int fil_rate = 2,
+             bool switch_to_den = false, float dense_thr = 0.1, int dense_sz_thr = 5000);
+    void set_from_file(const std::string &name);
+    void set_solve_params(int max_iter = 100, double relative_tolerance = 1e-8, std::string smoother = "chebyshev",
+                          int preSmooth = 3, int postSmooth = 3);
+    void set_max_iter(int v) { solver_max_iter = v; }
+    void set_relative_tolerance(double v) { relative_tol = v; }
+    void set_smoother(std::string v) { smoother = std::move(v); }
+    void set_preSmooth(int v) { preSmooth = v; }
+    void set_postSmooth(int v) { postSmooth = v; }
+    int         get_max_iter() const { return solver_max_iter; }
+    double      get_tol() const { return relative_tol; }
+    std::string get_smoother() const { return smoother; }
+    int         get_preSmooth() const { return preSmooth; }
+    int         get_postSmooth() const { return postSmooth; }
+    std::string get_PSmoother() const { return PSmoother; }
+    float       get_connStr() const { return connStrength; }
+    bool        get_dynamic_levels() const { return dynamic_levels; }
+    int         get_max_lev() const { return max_level; }
+    int         get_float_lev() const { return float_level; }
+    double      get_filter_thre() const { return filter_thre; }
+    double      get_filter_max() const { return filter_max; }
+    int         get_filter_start() const { return filter_start; }
+    int         get_filter_rate() const { return filter_rate; }
+    bool        get_switch_dense() const { return switch_to_dense; }
+    float       get_dense_thre() const { return dense_thre; }
+    int         get_dense_sz_thre() const { return dense_sz_thre; }
+    std::string get_petsc_solver() const { return petsc_solver; }
+};
+
+class amg {
+public:
+    amg();
+    ~amg();
+    amg(const amg &) = delete;
+    amg &operator=(const amg &) = delete;
+
+    void set_dynamic_levels(const bool &dl = true);
+    int set_matrix(saena::matrix *A, saena::options *opts);   // smoothed-aggregation setup (host) + upload
+    int set_rhs(saena::vector &rhs);                          // note: this function copies the rhs
+    int set_rhs(const value_t *rhs_local, index_t size);      // already partitioned like A (interior numbering)
+
+    // before calling solve, u may be nullptr; after, it holds this rank's slice of the solution
+    // (allocated here when null; free it with saena::free_vector)
+    int solve(value_t *&u, saena::options *opts);
+    int solve_pCG(value_t *&u, saena::options *opts, bool print_info = true);
+
+    int  set_verbose(bool verb);
+    bool verbose = false;
+    int  set_multigrid_max_level(int max);
+    int  get_num_levels() const;
+    // residual norms of the last solve: hist[0] = initial, hist[k] after iteration k
+    const std::vector<value_t> &residual_history() const { return hist_; }
+    int  last_iterations() const { return iters_; }
+    void destroy();
+    sgpu_amg *device_handle() { return damg_; }
+private:
+    saena::matrix *A_ = nullptr;
+    saena_host::amg_hierarchy *H_ = nullptr;
+    std::vector<sgpu_op *> dA_, dP_, dR_;
+    sgpu_amg *damg_ = nullptr;
+    std::vector<value_t> rhs_;
+    std::vector<value_t> hist_;
+    int iters_ = 0;
+    bool dynamic_levels_ = true;
+    int max_level_override_ = -1;
+    void drop_device();
+    int run(value_t *&u, saena::options *opts, bool pcg, bool print_info);
+};
+
+void free_vector(value_t *u);
+
+// Matrix generator functions (reference include/aux_functions2.h:12-43)
+int laplacian3D(saena::matrix *A, index_t mx, index_t my, index_t mz);
+// this rank's z-slabs of the full mx*my*mz grid (boundary included), as the reference returns them;
+// pair with saena::vector::set(val, size, offset) using the returned first global index
+index_t laplacian3D_set_rhs(value_t *&rhs, index_t mx, index_t my, index_t mz, comm c, index_t *first_index = nullptr);
+int band_matrix(saena::matrix &A, index_t M, unsigned int bandwidth);
+
+} // namespace saena

@@ -1,0 +1,306 @@
+// saena.cpp -- implementation of the public C++ surface (include/saena.hpp) over the host mirror
+// and the C ABI of the GPU library.  Built into libsaena_amd.so only.
+#ifdef SAENA_WITH_GPU
+#include "../../../include/saena.hpp"
+#include "../../../include/saena_gpu.h"
+#include "amg_setup.h"
+#include "saena_matrix.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+extern "C" saena_host::Comm *sgpu_new_host_comm();
+
+namespace {
+void gchk(int s, const char *what) {
+    if (s != SGPU_OK) throw std::runtime_error(std::string(what) + ": " + sgpu_last_error());
+}
+saena_host::Comm *world() {
+    static saena_host::Comm *w = nullptr;
+    if (!w) {
+        w = sgpu_new_host_comm();
+        if (!w) throw std::runtime_error("saena::init() has not been called (no MI355X context)");
+    }
+    return w;
+}
+void fill_desc(const saena_host::DistLayout &L, const std::vector<value_t> *inv_diag, sgpu_op_desc *d) {
+    d->M = L.M; d->N_local = L.N_local; d->col_offset = L.col_offset;
+    d->nnz_l_local = L.nnz_l_local;
+    d->nnzPerRow_local = L.nnzPerRow_local.data(); d->col_local = L.col_local.data(); d->val_local = L.val_local.data();
+    d->nnz_l_remote = L.nnz_l_remote; d->col_remote_size = L.col_remote_size;
+    d->nnzPerCol_remote = L.nnzPerCol_remote.data(); d->row_remote = L.row_remote.data(); d->val_remote = L.val_remote.data();
+    d->numRecvProc = L.numRecvProc; d->numSendProc = L.numSendProc;
+    d->recvProcRank = L.recvProcRank.data(); d->recvProcCount = L.recvProcCount.data();
+    d->sendProcRank = L.sendProcRank.data(); d->sendProcCount = L.sendProcCount.data();
+    d->vIndexSize = L.vIndexSize; d->vIndex = L.vIndex.data();
+    d->inv_diag = inv_diag && !inv_diag->empty() ? inv_diag->data() : nullptr;
+    d->halo_fp32 = 0;
+}
+} // namespace
+
+namespace saena {
+
+void init(int device_id, int rank, int nranks, const void *uid) { gchk(sgpu_init(device_id, rank, nranks, uid), "saena::init"); }
+void unique_id(void *out128) { gchk(sgpu_get_unique_id(out128), "saena::unique_id"); }
+void finalize() { sgpu_finalize(); }
+
+comm::comm() : c_(world()) {}
+int comm::rank() const { return c_->rank; }
+int comm::size() const { return c_->nranks; }
+
+// ---------------------------------------------------------------- matrix
+matrix::matrix() : c_(), m_pImpl(new saena_host::saena_matrix(c_.impl())) {}
+matrix::matrix(comm c) : c_(c), m_pImpl(new saena_host::saena_matrix(c.impl())) {}
+matrix::~matrix() { destroy(); }
+void matrix::set_comm(comm c) { c_ = c; m_pImpl->comm = c.impl(); }
+int matrix::set(index_t i, index_t j, value_t val) { return m_pImpl->set(i, j, val); }
+int matrix::set(index_t *row, index_t *col, value_t *val, nnz_t n) { return m_pImpl->set(row, col, val, n); }
+int matrix::set(index_t i, index_t j, unsigned int size_x, unsigned int size_y, value_t *val) {
+    // contiguous block, row-major values (saena_matrix.cpp set(i,j,size_x,size_y,val))
+    for (unsigned int a = 0; a < size_x; ++a)
+        for (unsigned int b = 0; b < size_y; ++b) m_pImpl->set(i + (index_t)a, j + (index_t)b, val[a * size_y + b]);
+    return 0;
+}
+void matrix::set_eig(double e) { m_pImpl->set_eig(e); }
+void matrix::set_eig(const std::string &fname) {          // saena.cpp:124-135: optional eig="..." attribute
+    std::ifstream f(fname);
+    if (!f) throw std::runtime_error("Could not find the xml file!");
+    std::stringstream ss; ss << f.rdbuf();
+    const std::string s = ss.str();
+    const size_t p = s.find("eig=\"");
+    if (p == std::string::npos) return;
+    const size_t q = s.find('"', p + 5);
+    const double e = std::stod(s.substr(p + 5, q - p - 5));
+    if (e != 0.0) m_pImpl->set_eig(e);
+}
+void matrix::set_remove_boundary(bool b) { m_pImpl->remove_boundary = b; }
+int matrix::add_duplicates(bool add) { add_dup = add; m_pImpl->add_duplicates = add; return 0; }
+int matrix::assemble(bool scale, bool use_dense) {
+    if (scale || use_dense) throw std::runtime_error("saena::matrix::assemble: scale/use_dense are not on the GPU path (defaults are false in the reference's drivers)");
+    m_pImpl->add_duplicates = add_dup;
+    return m_pImpl->assemble();
+}
+int matrix::assemble_band_matrix(bool use_dense) { return assemble(false, use_dense); }
+saena_host::saena_matrix *matrix::get_internal_matrix() { return m_pImpl; }
+comm matrix::get_comm() { return c_; }
+index_t matrix::get_num_rows() { return m_pImpl->remove_boundary ? m_pImpl->Mbig_with_bound : m_pImpl->Mbig; }   // saena.cpp:188: size before removing boundary
+index_t matrix::get_num_local_rows() { return m_pImpl->M; }
+nnz_t matrix::get_nnz() { return m_pImpl->nnz_g; }
+nnz_t matrix::get_local_nnz() { return m_pImpl->nnz_l; }
+std::vector<index_t> matrix::get_orig_split() { return m_pImpl->split; }
+std::vector<index_t> matrix::get_split() { return m_pImpl->split; }
+
+sgpu_op *matrix::device_op() {
+    if (!dev_) {
+        if (!m_pImpl->assembled) throw std::runtime_error("saena::matrix: assemble() first");
+        sgpu_op_desc d;
+        fill_desc(m_pImpl->L, &m_pImpl->inv_diag, &d);
+        gchk(sgpu_op_create(&d, &dev_), "sgpu_op_create");
+    }
+    return dev_;
+}
+void matrix::matvec(std::vector<value_t> &v, std::vector<value_t> &w) {
+    if ((index_t)v.size() != m_pImpl->M) throw std::runtime_error("saena::matrix::matvec: v must hold this rank's rows");
+    w.resize(v.size());
+    gchk(sgpu_spmv_host(device_op(), v.data(), w.data()), "sgpu_spmv_host");
+}
+void matrix::matvec(saena::vector &v, saena::vector &w) {
+    value_t *p = nullptr;
+    v.get_vec(p);
+    std::vector<value_t> vin(p, p + v.get_size()), wout;
+    matvec(vin, wout);
+    w.set(wout.data(), (index_t)wout.size(), m_pImpl->split[c_.rank()]);
+    w.assemble();
+}
+int matrix::erase() {
+    if (dev_) { sgpu_op_destroy(dev_); dev_ = nullptr; }
+    saena_host::Comm *c = m_pImpl->comm;
+    delete m_pImpl;
+    m_pImpl = new saena_host::saena_matrix(c);
+    return 0;
+}
+void matrix::destroy() {
+    if (dev_) { sgpu_op_destroy(dev_); dev_ = nullptr; }
+    delete m_pImpl;
+    m_pImpl = nullptr;
+}
+
+// ---------------------------------------------------------------- vector
+vector::vector() : c_() {}
+vector::vector(comm c) : c_(c) {}
+void vector::set_comm(comm c) { c_ = c; }
+int vector::set_idx_offset(index_t o) { ofst_ = o; return 0; }
+int vector::set(index_t i, value_t v) { idx_.push_back(i + ofst_); val_.push_back(v); assembled_ = false; return 0; }
+int vector::set(const index_t *idx, const value_t *val, index_t n) { for (index_t k = 0; k < n; ++k) set(idx[k], val[k]); return 0; }
+int vector::set(const value_t *val, index_t n, index_t offset) {
+    for (index_t k = 0; k < n; ++k) { idx_.push_back(offset + k); val_.push_back(val[k]); }
+    assembled_ = false;
+    return 0;
+}
+int vector::set(const value_t *val, index_t n) { return set(val, n, ofst_); }
+int vector::set_dup_flag(bool add) { add_dup_ = add; return 0; }
+int vector::assemble() {            // saena_vector::assemble: sort by index, combine duplicates
+    std::vector<size_t> order(idx_.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [this](size_t a, size_t b) { return idx_[a] < idx_[b]; });
+    std::vector<index_t> ni; std::vector<value_t> nv;
+    for (size_t k = 0; k < order.size(); ++k) {
+        const index_t i = idx_[order[k]];
+        value_t v = val_[order[k]];
+        while (k + 1 < order.size() && idx_[order[k + 1]] == i) { ++k; v = add_dup_ ? v + val_[order[k]] : val_[order[k]]; }
+        ni.push_back(i); nv.push_back(v);
+    }
+    idx_.swap(ni); val_.swap(nv);
+    assembled_ = true;
+    return 0;
+}
+void vector::get_vec(value_t *&vec) { if (!assembled_) assemble(); vec = val_.data(); }
+
+// ---------------------------------------------------------------- options
+options::options(int max_iter, double tol, std::string sm, int pre, int post, std::string PSm, float conn, bool dyn, int max_lev,
+                 int float_lev, double fil_thr, double fil_max, int fil_st, int fil_rate, bool sw_dense, float dense_thr, int dense_sz) {
+    set(max_iter, tol, std::move(sm), pre, post, std::move(PSm), conn, dyn, max_lev, float_lev, fil_thr, fil_max, fil_st, fil_rate, sw_dense, dense_thr, dense_sz);
+}
+options::options(const std::string &name) { set(); set_from_file(name); }
+void options::set(int max_iter, double tol, std::string sm, int pre, int post, std::string PSm, float conn, bool dyn, int max_lev,
+                  int float_lev, double fil_thr, double fil_max, int fil_st, int fil_rate, bool sw_dense, float dense_thr, int dense_sz) {
+    solver_max_iter = max_iter; relative_tol = tol; smoother = std::move(sm); preSmooth = pre; postSmooth = post; PSmoother = std::move(PSm);
+    connStrength = conn; dynamic_levels = dyn; max_level = max_lev; float_level = float_lev; filter_thre = fil_thr; filter_max = fil_max;
+    filter_start = fil_st; filter_rate = fil_rate; switch_to_dense = sw_dense; dense_thre = dense_thr; dense_sz_thre = dense_sz;
+}
+void options::set_from_file(const std::string &name) {
+    saena_host::amg_options o;
+    o.set_from_file(name);
+    set(o.solver_max_iter, o.relative_tol, o.smoother, o.preSmooth, o.postSmooth, o.PSmoother, o.connStrength, o.dynamic_levels, o.max_level,
+        o.float_level, o.filter_thre, o.filter_max, o.filter_start, o.filter_rate, o.switch_to_dense, o.dense_thre, o.dense_sz_thre);
+}
+void options::set_solve_params(int max_iter, double tol, std::string sm, int pre, int post) {
+    solver_max_iter = max_iter; relative_tol = tol; smoother = std::move(sm); preSmooth = pre; postSmooth = post;
+}
+
+// ---------------------------------------------------------------- amg
+amg::amg() {}
+amg::~amg() { destroy(); }
+void amg::set_dynamic_levels(const bool &dl) { dynamic_levels_ = dl; }
+int amg::set_verbose(bool v) { verbose = v; return 0; }
+int amg::set_multigrid_max_level(int m) { max_level_override_ = m; return 0; }
+int amg::get_num_levels() const { return H_ ? H_->max_level + 1 : 0; }
+void amg::drop_device() {
+    if (damg_) { sgpu_amg_destroy(damg_); damg_ = nullptr; }
+    for (auto *v : {&dA_, &dP_, &dR_}) {
+        for (size_t i = 0; i < v->size(); ++i)
+            if (!(v == &dA_ && i == 0)) sgpu_op_destroy((*v)[i]);      // level-0 A belongs to the saena::matrix
+        v->clear();
+    }
+}
+void amg::destroy() {
+    drop_device();
+    delete H_; H_ = nullptr;
+}
+
+int amg::set_matrix(saena::matrix *A, saena::options *opts) {
+    destroy();
+    A_ = A;
+    saena_host::amg_options o;
+    o.solver_max_iter = opts->get_max_iter(); o.relative_tol = opts->get_tol(); o.smoother = opts->get_smoother();
+    o.preSmooth = opts->get_preSmooth(); o.postSmooth = opts->get_postSmooth(); o.PSmoother = opts->get_PSmoother();
+    o.connStrength = opts->get_connStr(); o.dynamic_levels = opts->get_dynamic_levels() && dynamic_levels_;
+    o.max_level = max_level_override_ >= 0 ? max_level_override_ : opts->get_max_lev(); o.float_level = opts->get_float_lev();
+    o.filter_thre = opts->get_filter_thre(); o.filter_max = opts->get_filter_max(); o.filter_start = opts->get_filter_start();
+    o.filter_rate = opts->get_filter_rate();
+    H_ = new saena_host::amg_hierarchy();
+    H_->setup(A->get_internal_matrix(), o);
+    const int n = H_->max_level + 1;
+    std::vector<double> eig;
+    for (int l = 0; l < n; ++l) {
+        const saena_host::amg_level &g = H_->levels[l];
+        sgpu_op_desc d; sgpu_op *op = nullptr;
+        if (l == 0) op = A->device_op();
+        else { fill_desc(g.A->L, &g.A->inv_diag, &d); gchk(sgpu_op_create(&d, &op), "sgpu_op_create(A)"); }
+        dA_.push_back(op);
+        eig.push_back(g.A->eig_max_of_invdiagXA);
+        if (l < n - 1) {
+            fill_desc(g.P.L, nullptr, &d); gchk(sgpu_op_create(&d, &op), "sgpu_op_create(P)"); dP_.push_back(op);
+            fill_desc(g.R.L, nullptr, &d); gchk(sgpu_op_create(&d, &op), "sgpu_op_create(R)"); dR_.push_back(op);
+        }
+    }
+    if (!std::getenv("SAENA_NO_AUTOTUNE"))
+        for (auto *v : {&dA_, &dP_, &dR_})
+            for (sgpu_op *op : *v) gchk(sgpu_op_autotune(op), "sgpu_op_autotune");
+    sgpu_amg_params p;
+    sgpu_amg_default_params(&p);
+    p.preSmooth = o.preSmooth; p.postSmooth = o.postSmooth; p.smoother = o.smoother == "jacobi" ? 0 : 1;
+    p.solver_max_iter = o.solver_max_iter; p.solver_tol = o.relative_tol;
+    gchk(sgpu_amg_create(n, dA_.data(), dP_.data(), dR_.data(), eig.data(), &p, &damg_), "sgpu_amg_create");
+    if (verbose && A->get_comm().rank() == 0) {
+        printf("_____________________________\n\nnumber of levels = << %d >> (the finest level is 0)\n", n - 1);
+        for (int l = 0; l < n; ++l) printf("level %d: rows %d, nnz %ld\n", l, H_->levels[l].A->Mbig, (long)H_->levels[l].A->nnz_g);
+    }
+    return 0;
+}
+
+int amg::set_rhs(saena::vector &rhs) {
+    if (!A_) throw std::runtime_error("saena::amg::set_rhs: set_matrix first");
+    value_t *p = nullptr;
+    rhs.get_vec(p);
+    std::vector<value_t> vals(p, p + rhs.get_size());
+    rhs_ = A_->get_internal_matrix()->scatter_rhs(rhs.indices(), vals);
+    return 0;
+}
+int amg::set_rhs(const value_t *rhs_local, index_t size) {
+    if (!A_ || size != A_->get_num_local_rows()) throw std::runtime_error("saena::amg::set_rhs: size does not match the local rows");
+    rhs_.assign(rhs_local, rhs_local + size);
+    return 0;
+}
+
+int amg::run(value_t *&u, saena::options *opts, bool pcg, bool print_info) {
+    if (!damg_) throw std::runtime_error("saena::amg: set_matrix first");
+    const size_t n = (size_t)A_->get_num_local_rows();
+    if (rhs_.size() != n) throw std::runtime_error("saena::amg: set_rhs first");
+    (void)opts;    // solve parameters were fixed by set_matrix (the reference re-reads max_iter/tol/smoother here)
+    value_t *du = nullptr, *dr = nullptr;
+    gchk(sgpu_vec_alloc(&du, n), "alloc"); gchk(sgpu_vec_alloc(&dr, n), "alloc");
+    gchk(sgpu_vec_upload(dr, rhs_.data(), n), "upload");
+    hist_.assign(1024, 0.0);
+    int st = pcg ? sgpu_solve_pCG(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size())
+                 : sgpu_solve(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size());
+    if (st != SGPU_OK && st != SGPU_ERR_NOCONV) { sgpu_vec_free(du); sgpu_vec_free(dr); gchk(st, "solve"); }
+    hist_.resize((size_t)std::min<int>(iters_ + 1, 1024));
+    if (!u) u = static_cast<value_t *>(std::malloc(std::max<size_t>(1, n) * sizeof(value_t)));   // saena_aligned_alloc in the reference
+    gchk(sgpu_vec_download(u, du, n), "download");
+    sgpu_vec_free(du); sgpu_vec_free(dr);
+    if (print_info && A_->get_comm().rank() == 0) {           // saena_object_solve.cpp:2502,2681-2682
+        printf("\ninitial residual        = %e \n", hist_.front());
+        printf("stopped at iteration    = %d \nfinal absolute residual = %e\nrelative residual       = %e \n",
+               iters_, hist_.back(), hist_.back() / hist_.front());
+    }
+    return st == SGPU_OK ? 0 : 1;
+}
+int amg::solve(value_t *&u, saena::options *opts) { return run(u, opts, false, true); }
+int amg::solve_pCG(value_t *&u, saena::options *opts, bool print_info) { return run(u, opts, true, print_info); }
+
+void free_vector(value_t *u) { std::free(u); }
+
+// ---------------------------------------------------------------- generators
+int laplacian3D(saena::matrix *A, index_t mx, index_t my, index_t mz) { return saena_host::laplacian3D(A->get_internal_matrix(), mx, my, mz); }
+index_t laplacian3D_set_rhs(value_t *&rhs, index_t mx, index_t my, index_t mz, comm c, index_t *first_index) {
+    index_t lo = 0;
+    std::vector<value_t> v = saena_host::laplacian3D_set_rhs(*c.impl(), mx, my, mz, &lo);
+    rhs = static_cast<value_t *>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(value_t)));
+    std::copy(v.begin(), v.end(), rhs);
+    if (first_index) *first_index = lo;
+    return (index_t)v.size();
+}
+int band_matrix(saena::matrix &A, index_t M, unsigned int bandwidth) {
+    saena_host::band_matrix(A.get_internal_matrix(), M, bandwidth);
+    return A.assemble_band_matrix();
+}
+
+} // namespace saena
+
+#endif // SAENA_WITH_GPU

@@ -123,27 +123,12 @@ int saena_band_matrix(saena_matrix_h *A, index_t M, unsigned int bw) { return gu
 int saena_laplacian3D_set_rhs(saena_matrix_h *Ah, index_t mx, index_t my, index_t mz, value_t *rhs_local) {
     return guard([&] {
         saena_matrix &A = Ah->A;
-        if (!A.assembled) throw std::runtime_error("matrix is not assembled");
-        Comm &c = *A.comm;
         index_t lo = 0;
-        std::vector<value_t> full = laplacian3D_set_rhs(c, mx, my, mz, &lo);
-        std::vector<value_t> in = A.remove_boundary_rhs(full, lo);     // set_repartition_rhs, saena_object_repart_shrink.cpp:179-206
-        const auto &B = A.bound_row_global;
-        const index_t new_lo = lo - (index_t)(std::lower_bound(B.begin(), B.end(), lo) - B.begin());
-        // repart_vector to A.split (saena_object_repart_shrink.cpp:218)
-        struct rec { index_t id; value_t v; };
-        std::vector<rec> recs(in.size());
-        for (size_t i = 0; i < in.size(); ++i) recs[i] = {new_lo + (index_t)i, in[i]};
-        std::vector<int> cnt((size_t)c.nranks, 0);
-        for (const auto &r : recs) {
-            int p = (int)lower_bound2(A.split.data(), A.split.data() + c.nranks, r.id);
-            while (p < c.nranks - 1 && A.split[p + 1] <= r.id) ++p;
-            cnt[p]++;
-        }
-        std::vector<rec> got = c.nranks == 1 ? recs : c.alltoallv_records(recs, cnt);   // ids ascend, so recs are grouped by owner
-        if ((index_t)got.size() != A.M) throw std::runtime_error("rhs does not match the matrix partition");
-        const index_t ofs = A.split[c.rank];
-        for (const auto &r : got) rhs_local[r.id - ofs] = r.v;
+        std::vector<value_t> full = laplacian3D_set_rhs(*A.comm, mx, my, mz, &lo);
+        std::vector<index_t> idx(full.size());
+        for (size_t i = 0; i < full.size(); ++i) idx[i] = lo + (index_t)i;
+        std::vector<value_t> mine = A.scatter_rhs(idx, full);          // set_repartition_rhs, saena_object_repart_shrink.cpp:154-218
+        std::copy(mine.begin(), mine.end(), rhs_local);
     });
 }
 

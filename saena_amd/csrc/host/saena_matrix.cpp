@@ -234,6 +234,32 @@ std::vector<value_t> saena_matrix::remove_boundary_rhs(const std::vector<value_t
     return out;
 }
 
+std::vector<value_t> saena_matrix::scatter_rhs(const std::vector<index_t> &idx, const std::vector<value_t> &val) const {
+    if (!assembled) throw std::runtime_error("scatter_rhs: the matrix is not assembled");
+    if (idx.size() != val.size()) throw std::runtime_error("scatter_rhs: index/value size mismatch");
+    Comm &c = *comm;
+    struct rec { index_t id; value_t v; };
+    const auto &B = bound_row_global;
+    std::vector<rec> recs;
+    recs.reserve(idx.size());
+    for (size_t i = 0; i < idx.size(); ++i) {
+        const index_t g = idx[i];
+        auto it = std::lower_bound(B.begin(), B.end(), g);
+        if (it != B.end() && *it == g) continue;                       // boundary row: dropped (saena_object.cpp:716-724)
+        const index_t nid = g - (index_t)(it - B.begin());
+        if (nid < 0 || nid >= Mbig) throw std::runtime_error("scatter_rhs: index outside the matrix");
+        recs.push_back({nid, val[i]});
+    }
+    std::vector<rec> got = route(c, recs, split, [](const rec &r) { return r.id; });
+    std::vector<value_t> out((size_t)M, 0.0);
+    std::vector<char> seen((size_t)M, 0);
+    const index_t ofs = split[c.rank];
+    for (const auto &r : got) { out[r.id - ofs] = r.v; seen[r.id - ofs] = 1; }
+    for (index_t i = 0; i < M; ++i)
+        if (!seen[i]) throw std::runtime_error("scatter_rhs: the right-hand side does not cover row " + std::to_string(i + ofs));
+    return out;
+}
+
 // ---------------------------------------------------------------------------
 // set_off_on_diagonal (saena_matrix_setup.cpp:793-1098)
 void DistLayout::build(Comm &c, const std::vector<cooEntry> &entry, const std::vector<index_t> &split_row,

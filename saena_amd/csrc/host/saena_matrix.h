@@ -101,6 +101,10 @@ public:
     // drop the rows of a full-length (with boundary) local vector slice that were removed
     // (remove_boundary_rhs, src/saena_object.cpp:699-730); rhs_with_bound covers [lo, hi) of the original numbering
     std::vector<value_t> remove_boundary_rhs(const std::vector<value_t> &rhs_with_bound, index_t lo) const;
+    // set_repartition_rhs (src/saena_object_repart_shrink.cpp:154-218): entries (global index in the ORIGINAL
+    // numbering, value) held by any rank -> this rank's slice of the assembled system (boundary rows dropped,
+    // renumbered, moved to the owner by `split`).  Collective.
+    std::vector<value_t> scatter_rhs(const std::vector<index_t> &idx_with_bound, const std::vector<value_t> &val) const;
 
 private:
     std::vector<cooEntry> data_in;     // what set() collected (data_coo in the reference)

@@ -163,3 +163,28 @@ def test_full_pipeline_poisson32_matches_reference_pins(capi):
     u2, it2, hist2, conv2 = S.solve(rhs)
     u2_o, it2_o, hist2_o = amg.solve(rhs)
     assert conv2 and it2 == it2_o and np.all(np.abs(hist2 - hist2_o) <= TOL_HIST * hist2_o[0])
+
+
+def test_cpp_surface_poisson_driver(capi, tmp_path):
+    """examples/poisson.cpp drives include/saena.hpp (saena::matrix / vector / options / amg) exactly like the
+    reference's experiments/Poisson.cpp; its printed residuals must be the reference's."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "poisson")
+    assert os.path.exists(exe), "build first (__graft_entry__.build())"
+    xml = tmp_path / "options001.xml"
+    xml.write_text('<?xml version="1.0" encoding="utf-8" ?>\n<SAENA>\n    <OPTIONS\n\tsolver_max_iter="50"\n\tsolver_tol="1e-8"\n'
+                   '\tsmoother="jacobi"\n\tpreSmooth="3"\n\tpostSmooth="3"\n\tPSmoother="jacobi"\n\tconn_str="0.2"\n\tdynamic_levels="1"\n'
+                   '\tmax_level="20"\n\tfloat_level="3"\n\tfilter_thre="1e-14"\n\tfilter_max="1e-8"\n\tfilter_start="1"\n\tfilter_rate="2"\n'
+                   '\tswitch_to_dense="0"\n\tdense_thre="0.1"\n\tdense_sz_thre="5000"\n\tpetsc=""/>\n</SAENA>\n')
+    out = subprocess.run([exe, "32", str(xml)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    assert "number of levels = << 4 >>" in txt
+    assert "level 1: rows 13500, nnz 833962" in txt and "level 4: rows 69, nnz 4761" in txt
+    assert re.search(r"initial residual\s+= 7\.227341e\+03", txt), txt
+    assert re.search(r"stopped at iteration\s+= 7", txt), txt
+    assert re.search(r"final absolute residual = 2\.24625\de-05", txt), txt
+    assert re.search(r"relative residual\s+= 3\.10799\de-09", txt), txt
