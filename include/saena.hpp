@@ -53,6 +53,8 @@ public:
     matrix(const matrix &) = delete;
     matrix &operator=(const matrix &) = delete;
 
+    int read_file(const char *name);
+    int read_file(const char *name, const std::string &input_type);
     void set_comm(comm c);
     int set(index_t i, index_t j, value_t val);                                  // set individual value
     int set(index_t *row, index_t *col, value_t *val, nnz_t nnz_local);          // set multiple values

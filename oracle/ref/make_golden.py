@@ -35,6 +35,14 @@ CASES = [
     (("band", "300", "7"), (1, 2, 4)),
     (("band", "64", "63"), (1, 2)),
 ]
+# SuiteSparse matrices shipped in the reference's data/ (data/florida_matrices.txt names bcsstk28 and plat362)
+REFDATA = "/root/reference/data"
+FILE_CASES = [
+    (("file", f"{REFDATA}/old/plat362.mtx", "plat362"), (1, 2)),
+    (("file", f"{REFDATA}/FloridaCollection/SiH4.mtx", "SiH4"), (1, 4)),          # irregular rows (1..~250 nnz)
+    (("file", f"{REFDATA}/FloridaCollection/fxm3_6.mtx", "fxm3_6"), (1, 3)),      # pattern symmetric
+    # (bcsstk28 aborts inside the reference itself: "Saena not working on this one", data/florida_matrices.txt)
+]
 NORM_CASES = [(("norms", "32"), (1, 2, 4)), (("norms", "128"), (1, 8))]
 
 
@@ -66,7 +74,7 @@ def main():
     os.makedirs(GOLDEN, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="refdump_")
     try:
-        for kind_args, nps in CASES:
+        for kind_args, nps in CASES + FILE_CASES:
             for p in nps:
                 run(kind_args, p, tmp)
         for key, arrs in pack(tmp).items():

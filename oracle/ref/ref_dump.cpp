@@ -11,6 +11,7 @@
 // usage: mpirun -np P ref_dump <outdir> poisson <m>  [full]
 //        mpirun -np P ref_dump <outdir> band <M> <bw>
 //        mpirun -np P ref_dump <outdir> norms <m>          (norm pins only, large m)
+//        mpirun -np P ref_dump <outdir> file <matrix.mtx|.bin> <tag>   (one of the reference's data files)
 //
 // Reference interfaces exercised (file:line in the reference checkout):
 //   saena_matrix::set/assemble            src/saena_matrix.cpp:459, src/saena_matrix_setup.cpp:4
@@ -135,7 +136,11 @@ int main(int argc, char **argv) {
         const int M = atoi(argv[3]), bw = atoi(argv[4]);
         fill_band(A, M, bw);
         tag = "band" + std::to_string(M) + "_" + std::to_string(bw);
+    } else if (kind == "file") {                 // saena_matrix::read_file (src/saena_matrix.cpp:17-385) on one of the reference's data files
+        A.read_file(argv[3]);
+        tag = argv[4];
     } else { MPI_Finalize(); return 1; }
+    const bool light = (kind == "file");         // vectors only: the layout arrays of these matrices are too big to commit
     A.assemble(false);
     const std::string pfx = tag + ".np" + std::to_string(g_np) + ".";
 
@@ -170,7 +175,7 @@ int main(int argc, char **argv) {
         write_raw(pfx + "split", "i32", std::vector<int>(A.split.begin(), A.split.end()));
         std::vector<long> meta = {(long)A.Mbig, (long)A.nnz_g, (long)g_np};
         write_raw(pfx + "meta", "i64", meta);
-        dump_layout(A, pfx);
+        if (!light) dump_layout(A, pfx);
 
         A.matvec(v2.data(), w.data());
         write_raw(pfx + "Av2", "f64", gather_d(w.data(), M));
@@ -195,6 +200,11 @@ int main(int argc, char **argv) {
         A.matvec_sparse_float(v2.data(), w.data());
         write_raw(pfx + "Av2_float", "f64", gather_d(w.data(), M));
 
+        if (light) {
+            if (!g_rank) printf("%s np=%d Mbig=%d nnz_g=%ld  |Av|^2=%.16g\n", tag.c_str(), g_np, (int)A.Mbig, (long)A.nnz_g, pins[0]);
+            MPI_Finalize();
+            return 0;
+        }
         // ---- grid transfer: synthetic closed-form P (fine rows x coarse cols) ----
         // P(i,j) = 1/(1+|i-2j|) + 0.001*i for j in {i/2-1, i/2, i/2+1} (global ids), clipped.
         const int Mbig = A.Mbig, Nc = (Mbig + 1) / 2;

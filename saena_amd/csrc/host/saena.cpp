@@ -57,6 +57,8 @@ int comm::size() const { return c_->nranks; }
 matrix::matrix() : c_(), m_pImpl(new saena_host::saena_matrix(c_.impl())) {}
 matrix::matrix(comm c) : c_(c), m_pImpl(new saena_host::saena_matrix(c.impl())) {}
 matrix::~matrix() { destroy(); }
+int matrix::read_file(const char *name) { return m_pImpl->read_file(name, ""); }
+int matrix::read_file(const char *name, const std::string &t) { return m_pImpl->read_file(name, t); }
 void matrix::set_comm(comm c) { c_ = c; m_pImpl->comm = c.impl(); }
 int matrix::set(index_t i, index_t j, value_t val) { return m_pImpl->set(i, j, val); }
 int matrix::set(index_t *row, index_t *col, value_t *val, nnz_t n) { return m_pImpl->set(row, col, val, n); }

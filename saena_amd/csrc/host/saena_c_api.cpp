@@ -88,6 +88,8 @@ int saena_matrix_set(saena_matrix_h *A, index_t i, index_t j, value_t v) { retur
 int saena_matrix_set_many(saena_matrix_h *A, const index_t *r, const index_t *c, const value_t *v, nnz_t n) {
     return guard([&] { A->A.set(r, c, v, n); });
 }
+int saena_matrix_read_file(saena_matrix_h *A, const char *name, const char *type) { return guard([&] { A->A.read_file(name, type ? type : ""); }); }
+int saena_matrix_write_bin(saena_matrix_h *A, const char *name) { return guard([&] { A->A.write_bin(name); }); }
 int saena_matrix_set_remove_boundary(saena_matrix_h *A, int b) { A->A.remove_boundary = b != 0; return 0; }
 int saena_matrix_add_duplicates(saena_matrix_h *A, int add) { A->A.add_duplicates = add != 0; return 0; }
 int saena_matrix_set_eig(saena_matrix_h *A, double e) { A->A.set_eig(e); return 0; }
@@ -247,14 +249,16 @@ int saena_amg_to_device(saena_amg_h *S) {
     for (int l = 0; l < n; ++l) {
         sgpu_op_desc d; sgpu_op *o = nullptr;
         const amg_level &g = S->H.levels[l];
-        const int fp32 = 0;      // halo precision per level: float_level semantics are a later row
-        fill_desc(g.A->L, &g.A->inv_diag, &d); d.halo_fp32 = fp32;
+        // float_level (saena_object.cpp:241-244,277-285): A of level >= float_level, P/R of level >= float_level
+        // exchange their halos in fp32 (compute stays fp64).  Only matters with more than one rank.
+        const int fl = S->H.opts.float_level;
+        fill_desc(g.A->L, &g.A->inv_diag, &d); d.halo_fp32 = l >= fl ? 1 : 0;
         if (gchk(sgpu_op_create(&d, &o))) return -2;
         S->dA.push_back(o);
         eig.push_back(g.A->eig_max_of_invdiagXA);
         if (l < n - 1) {
-            fill_desc(g.P.L, nullptr, &d); if (gchk(sgpu_op_create(&d, &o))) return -2; S->dP.push_back(o);
-            fill_desc(g.R.L, nullptr, &d); if (gchk(sgpu_op_create(&d, &o))) return -2; S->dR.push_back(o);
+            fill_desc(g.P.L, nullptr, &d); d.halo_fp32 = l >= fl ? 1 : 0; if (gchk(sgpu_op_create(&d, &o))) return -2; S->dP.push_back(o);
+            fill_desc(g.R.L, nullptr, &d); d.halo_fp32 = l >= fl ? 1 : 0; if (gchk(sgpu_op_create(&d, &o))) return -2; S->dR.push_back(o);
         }
     }
     if (!std::getenv("SAENA_NO_AUTOTUNE"))

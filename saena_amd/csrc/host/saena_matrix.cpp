@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <fstream>
 #include <numeric>
+#include <sstream>
 
 namespace saena_host {
 
@@ -62,6 +64,83 @@ int saena_matrix::set(index_t row, index_t col, value_t val) {
 int saena_matrix::set(const index_t *row, const index_t *col, const value_t *val, nnz_t n) {
     data_in.reserve(data_in.size() + (size_t)n);
     for (nnz_t i = 0; i < n; ++i) data_in.emplace_back(row[i], col[i], val[i]);
+    return 0;
+}
+
+int saena_matrix::read_file(const std::string &filename, const std::string &input_type) {
+    Comm &c = *comm;
+    const size_t ext = filename.find_last_of('.');
+    if (ext == std::string::npos || ext == filename.size() - 1) throw std::runtime_error("The matrix file name does not have an extension!");
+    const std::string fe = filename.substr(ext + 1);
+    std::vector<cooEntry> all;
+    if (fe == "mtx") {
+        std::ifstream in(filename);
+        if (!in) throw std::runtime_error("Could not open the matrix file <" + filename + ">");
+        std::string mat_type(input_type), line;
+        std::getline(in, line);
+        bool pattern_field = false;
+        if (line.rfind("%%MatrixMarket", 0) == 0) {                        // :48-62 metadata line
+            std::istringstream hs(line);
+            std::string t0, t1, t2, field, symm;
+            hs >> t0 >> t1 >> t2 >> field >> symm;
+            pattern_field = field == "pattern";
+            if (mat_type.empty()) {
+                if (field != "pattern") { if (symm == "symmetric") mat_type = "triangle"; }
+                else mat_type = "pattern";
+            }
+        } else {
+            in.seekg(0);
+        }
+        while (in.peek() == '%') in.ignore(1 << 20, '\n');
+        long M_in = 0, N_in = 0, nnz = 0;
+        in >> M_in >> N_in >> nnz;
+        (void)pattern_field;
+        index_t a = 0, b = 0;
+        value_t v = 0.0;
+        if (mat_type.empty()) {
+            while (in >> a >> b >> v) all.emplace_back(a - 1, b - 1, v);
+        } else if (mat_type == "triangle") {
+            while (in >> a >> b >> v) { all.emplace_back(a - 1, b - 1, v); if (a != b) all.emplace_back(b - 1, a - 1, v); }
+        } else if (mat_type == "pattern" || mat_type == "tripattern") {     // value 1 for a pattern matrix, mirrored
+            while (in >> a >> b) { all.emplace_back(a - 1, b - 1, 1.0); if (a != b) all.emplace_back(b - 1, a - 1, 1.0); }
+        } else {
+            throw std::runtime_error("the input type is not valid!");
+        }
+        std::sort(all.begin(), all.end(), col_major);                       // :136 what the .bin holds
+    } else if (fe == "bin") {
+        std::ifstream in(filename, std::ios::binary | std::ios::ate);
+        if (!in) throw std::runtime_error("Could not open the matrix file <" + filename + ">");
+        const std::streamsize bytes = in.tellg();
+        const size_t n = (size_t)bytes / 16;
+        if (n == 0) throw std::runtime_error("number of nonzeros is 0 inside function read_file");
+        in.seekg(0);
+        all.resize(n);
+        static_assert(sizeof(cooEntry) == 16, "cooEntry must be the 16-byte triple");
+        in.read(reinterpret_cast<char *>(all.data()), (std::streamsize)(n * 16));
+    } else {
+        throw std::runtime_error("The extension of file should be either mtx (matrix market) or bin (binary)!");
+    }
+    // this rank's chunk (:343-361)
+    const nnz_t nnz_all = (nnz_t)all.size();
+    const nnz_t chunk = nnz_all / c.nranks;
+    const nnz_t lo = c.rank * chunk, hi = c.rank == c.nranks - 1 ? nnz_all : lo + chunk;
+    data_in.insert(data_in.end(), all.begin() + lo, all.begin() + hi);
+    return 0;
+}
+
+int saena_matrix::write_bin(const std::string &filename) const {
+    std::ofstream out(filename, std::ios::binary);
+    if (!out) throw std::runtime_error("could not open <" + filename + "> for writing");
+    if (!entry.empty()) {
+        out.write(reinterpret_cast<const char *>(entry.data()), (std::streamsize)(entry.size() * sizeof(cooEntry)));
+    } else {                                   // one-rank CSR-only operators
+        nnz_t k = 0;
+        std::vector<cooEntry> e;
+        for (index_t i = 0; i < L.M; ++i)
+            for (index_t j = 0; j < L.nnzPerRow_local[i]; ++j, ++k) e.emplace_back(i + split[comm->rank], L.col_local[k], L.val_local[k]);
+        std::sort(e.begin(), e.end(), col_major);
+        out.write(reinterpret_cast<const char *>(e.data()), (std::streamsize)(e.size() * sizeof(cooEntry)));
+    }
     return 0;
 }
 

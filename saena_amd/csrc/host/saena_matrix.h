@@ -83,6 +83,13 @@ public:
 
     int set(index_t row, index_t col, value_t val);                           // saena_matrix.cpp:459
     int set(const index_t *row, const index_t *col, const value_t *val, nnz_t n);
+    // read_file (saena_matrix.cpp:17-385): MatrixMarket coordinate (.mtx; general / symmetric -> mirrored /
+    // pattern -> value 1, mirrored; input_type "", "triangle", "pattern", "tripattern") or the 16-byte triple
+    // binary (.bin: int32 row, int32 col, float64 val, 0-based).  Every rank keeps its nnz_g/nprocs chunk of the
+    // column-major sorted entries, like the reference's MPI_File_read_at (:353-361); assemble() follows.
+    int read_file(const std::string &filename, const std::string &input_type = "");
+    // write this rank's assembled entries as 16-byte triples (the reference's .bin format, :198-203)
+    int write_bin(const std::string &filename) const;
     // assemble (saena_matrix_setup.cpp:4): setup_initial_data + repartition_nnz_initial + matrix_setup
     int assemble();
     // skip the repartition and use the given row split (entries must already be global/deduplicated)

@@ -301,6 +301,18 @@ __global__ __launch_bounds__(BLOCK) void k_pack(const double *__restrict__ v, co
     }
 }
 
+// fp32 halo on the wire (matvec_sparse_float, saena_matrix_matvec.cpp:464,531,538): pack straight to float,
+// widen the received floats back to double before the remote part reads them
+__global__ __launch_bounds__(BLOCK) void k_pack_f32(const double *__restrict__ v, const int *__restrict__ vIndex,
+                                                    float *__restrict__ send, int n) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) send[i] = (float)v[vIndex[i]];
+}
+__global__ __launch_bounds__(BLOCK) void k_widen_f32(const float *__restrict__ in, double *__restrict__ out, int n) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
 // ---------------------------------------------------------------------------
 // K10: streaming vector kernels (16 B per lane, grid-stride)
 __global__ __launch_bounds__(BLOCK) void k_fill(double *__restrict__ y, double a, size_t n) {

@@ -156,6 +156,7 @@ struct sgpu_op {
     int     vIndexSize = 0, recvSize = 0;
     int    *vIndex = nullptr;
     double *send_buf = nullptr, *recv_buf = nullptr;
+    float  *send_f = nullptr, *recv_f = nullptr;      // fp32 wire buffers (halo_fp32 && nranks > 1)
     std::vector<int> sendRank, sendCount, sendDispl, recvRank, recvCount, recvDispl;
     int     halo_fp32 = 0;
     bool    injected = false;     // test hook: halo supplied by sgpu_debug_inject_halo
@@ -254,18 +255,24 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
 // Start the halo exchange of x on the halo stream (pack on cs, send/recv on hs).
 int halo_begin(sgpu_op *op, const double *x) {
     if (g.nranks == 1 || (op->vIndexSize == 0 && op->recvSize == 0)) return SGPU_OK;
+    const bool f32 = op->halo_fp32 && op->send_f && op->recv_f;
     if (op->vIndexSize) {
-        hipLaunchKernelGGL(sk::k_pack, dim3((op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
-                           x, op->vIndex, op->send_buf, op->vIndexSize, op->halo_fp32);
+        const dim3 grid((op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK);
+        if (f32) hipLaunchKernelGGL(sk::k_pack_f32, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_f, op->vIndexSize);
+        else hipLaunchKernelGGL(sk::k_pack, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_buf, op->vIndexSize, op->halo_fp32);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(op->ev_packed, g.cs));
     HIPCHK(hipStreamWaitEvent(g.hs, op->ev_packed, 0));
     NCCLCHK(ncclGroupStart());
-    for (size_t i = 0; i < op->sendRank.size(); ++i)
-        NCCLCHK(ncclSend(op->send_buf + op->sendDispl[i], (size_t)op->sendCount[i], ncclDouble, op->sendRank[i], g.comm, g.hs));
-    for (size_t i = 0; i < op->recvRank.size(); ++i)
-        NCCLCHK(ncclRecv(op->recv_buf + op->recvDispl[i], (size_t)op->recvCount[i], ncclDouble, op->recvRank[i], g.comm, g.hs));
+    for (size_t i = 0; i < op->sendRank.size(); ++i) {
+        if (f32) NCCLCHK(ncclSend(op->send_f + op->sendDispl[i], (size_t)op->sendCount[i], ncclFloat, op->sendRank[i], g.comm, g.hs));
+        else NCCLCHK(ncclSend(op->send_buf + op->sendDispl[i], (size_t)op->sendCount[i], ncclDouble, op->sendRank[i], g.comm, g.hs));
+    }
+    for (size_t i = 0; i < op->recvRank.size(); ++i) {
+        if (f32) NCCLCHK(ncclRecv(op->recv_f + op->recvDispl[i], (size_t)op->recvCount[i], ncclFloat, op->recvRank[i], g.comm, g.hs));
+        else NCCLCHK(ncclRecv(op->recv_buf + op->recvDispl[i], (size_t)op->recvCount[i], ncclDouble, op->recvRank[i], g.comm, g.hs));
+    }
     NCCLCHK(ncclGroupEnd());
     HIPCHK(hipEventRecord(op->ev_halo, g.hs));
     return SGPU_OK;
@@ -276,7 +283,14 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     CHK(halo_begin(op, x));
     CHK(launch_part(op->loc, epi, x, y, e));
     if (op->has_remote && (g.nranks > 1 || op->injected)) {
-        if (g.nranks > 1) HIPCHK(hipStreamWaitEvent(g.cs, op->ev_halo, 0));
+        if (g.nranks > 1) {
+            HIPCHK(hipStreamWaitEvent(g.cs, op->ev_halo, 0));
+            if (op->halo_fp32 && op->recv_f && op->recvSize) {      // half the bytes crossed xGMI; widen for the remote part
+                hipLaunchKernelGGL(sk::k_widen_f32, dim3((op->recvSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
+                                   op->recv_f, op->recv_buf, op->recvSize);
+                HIPCHK(hipGetLastError());
+            }
+        }
         CHK(launch_part(op->rem, epi, op->recv_buf, y, e));
     }
     return SGPU_OK;
@@ -552,6 +566,10 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->recv_buf), (size_t)op->recvSize * sizeof(double)));
         HIPCHK(hipMemsetAsync(op->recv_buf, 0, (size_t)op->recvSize * sizeof(double), g.cs));
     }
+    if (op->halo_fp32 && g.nranks > 1) {
+        if (op->vIndexSize) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->send_f), (size_t)op->vIndexSize * sizeof(float)));
+        if (op->recvSize) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->recv_f), (size_t)op->recvSize * sizeof(float)));
+    }
     HIPCHK(hipEventCreateWithFlags(&op->ev_packed, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&op->ev_halo, hipEventDisableTiming));
     HIPCHK(hipStreamSynchronize(g.cs));
@@ -563,7 +581,7 @@ int sgpu_op_destroy(sgpu_op *op) {
     if (!op) return SGPU_OK;
     if (g.live) hipDeviceSynchronize();
     op->loc.free_all(); op->rem.free_all();
-    hipFree(op->inv_diag); hipFree(op->tmp); hipFree(op->dvec); hipFree(op->vIndex); hipFree(op->send_buf); hipFree(op->recv_buf);
+    hipFree(op->inv_diag); hipFree(op->tmp); hipFree(op->dvec); hipFree(op->vIndex); hipFree(op->send_buf); hipFree(op->recv_buf); hipFree(op->send_f); hipFree(op->recv_f);
     if (op->ev_packed) hipEventDestroy(op->ev_packed);
     if (op->ev_halo) hipEventDestroy(op->ev_halo);
     delete op;

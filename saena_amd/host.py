@@ -32,6 +32,8 @@ HOST_SYMBOLS = {
     "saena_matrix_free": (None, [_VP]),
     "saena_matrix_set": (C.c_int, [_VP, C.c_int, C.c_int, C.c_double]),
     "saena_matrix_set_many": (C.c_int, [_VP, _PI, _PI, _PD, C.c_long]),
+    "saena_matrix_read_file": (C.c_int, [_VP, C.c_char_p, C.c_char_p]),
+    "saena_matrix_write_bin": (C.c_int, [_VP, C.c_char_p]),
     "saena_matrix_set_remove_boundary": (C.c_int, [_VP, C.c_int]),
     "saena_matrix_add_duplicates": (C.c_int, [_VP, C.c_int]),
     "saena_matrix_set_eig": (C.c_int, [_VP, C.c_double]),
@@ -224,6 +226,13 @@ class Matrix:
     def set_many(self, rows, cols, vals):
         r, c, v = _ai(rows), _ai(cols), _ad(vals)
         _check(self.L, self.L.saena_matrix_set_many(self.h, r.ctypes.data_as(_PI), c.ctypes.data_as(_PI), v.ctypes.data_as(_PD), len(r)))
+
+    def read_file(self, name, input_type=""):
+        _check(self.L, self.L.saena_matrix_read_file(self.h, os.fsencode(name), input_type.encode()))
+        return self
+
+    def write_bin(self, name):
+        _check(self.L, self.L.saena_matrix_write_bin(self.h, os.fsencode(name)))
 
     def set_remove_boundary(self, flag):
         self.L.saena_matrix_set_remove_boundary(self.h, 1 if flag else 0)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from tests import inputs, util
+from tests import inputs, matrices, util
 
 pytestmark = pytest.mark.gpu
 
@@ -163,7 +163,9 @@ def test_against_compiled_reference_golden(capi, fn):
     """Same checks as tests/test_oracle_pins.py, with the GPU in the oracle's place."""
     tag = os.path.basename(fn)[4:].split(".")[0]
     ref = dict(np.load(fn))
-    if tag.startswith("poisson"):
+    if tag in matrices.FILES:
+        entries, M = matrices.entries(tag)
+    elif tag.startswith("poisson"):
         entries, M = orc.laplacian3d(int(tag[7:]))
     else:
         m_, bw = tag[4:].split("_")
@@ -192,6 +194,8 @@ def test_against_compiled_reference_golden(capi, fn):
     du.upload(v2)
     G.chebyshev(4, 1.9371, du, dr)
     assert rel(du.download(), ref["cheby4_v2_rhs2"]) <= TOL_SMOOTH
+    if "P_ec" not in ref:
+        return
     # grid transfers R v, P e and the fused u -= P e
     pr, pc, pv, Nc = inputs.synthetic_P(M)
     P = orc.OracleOp(orc.coo_from_arrays(pr, pc, pv), M, Nc, orc.split_even(M, 1), orc.split_even(Nc, 1), square=False)
@@ -206,6 +210,31 @@ def test_against_compiled_reference_golden(capi, fn):
     du.upload(v2)
     GP.prolong_correct(dec, du)
     assert rel(du.download(), v2 - ref["P_ec"]) <= 1e-14
+
+
+def test_suitesparse_through_product_reader(capi, tmp_path):
+    """config 5: SuiteSparse matrices with irregular rows (reference data/): product reader -> assemble ->
+    GPU SpMV / Jacobi, against the compiled-reference fixtures and the oracle; autotuned kernel choice."""
+    from saena_amd import host
+    for name in ("plat362", "SiH4", "fxm3_6"):
+        ref = dict(np.load(os.path.join(GOLDEN, f"ref_{name}.np1.npz")))
+        A = host.Matrix(host.Comm("gpu", "rccl")).read_file(matrices.path(name, tmp_path)).assemble()
+        entries, M = matrices.entries(name)
+        assert (A.num_rows, A.nnz) == (M, len(entries)) == (ref["meta"][0], ref["meta"][1])
+        op = host.device_operator(A)
+        op.autotune()
+        v, v2, rhs2 = inputs.v_sin(M), inputs.v2(M), inputs.rhs2(M)
+        dx, dy, dr = capi.DeviceVector(M, v), capi.DeviceVector(M), capi.DeviceVector(M, rhs2)
+        op.spmv(dx, dy)
+        assert np.all(np.abs(dy.download() - ref["Av"]) <= TOL_SPMV * abs_bound(entries, M, v))
+        du = capi.DeviceVector(M, v2)
+        op.jacobi(2, du, dr)
+        assert rel(du.download(), ref["jacobi2_v2_rhs2"]) <= TOL_SMOOTH
+        O = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+        op.set_variant(0); op.set_lanes_per_row(1)
+        dx.upload(v2)
+        op.spmv(dx, dy)
+        np.testing.assert_array_equal(dy.download(), O.matvec(v2))
 
 
 @pytest.mark.parametrize("name,nprocs", [("poisson12", 2), ("poisson12", 4), ("poisson20", 3), ("band300_7", 4),

@@ -12,7 +12,7 @@ import pytest
 
 from oracle import oracle as orc
 from saena_amd import host
-from tests import inputs
+from tests import inputs, matrices
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -65,6 +65,22 @@ def test_band_and_duplicates_single_rank():
     np.testing.assert_array_equal(L["val_local"], [3.0, 5.0])
 
 
+@pytest.mark.parametrize("name", ["plat362", "SiH4", "fxm3_6"])
+def test_read_file_mtx_and_bin(name, tmp_path):
+    """read_file (.mtx: real symmetric / pattern symmetric; .bin: 16-byte triples) against an independent parse"""
+    comm = host.Comm("host", "self")
+    A = host.Matrix(comm).read_file(matrices.path(name, tmp_path)).assemble()
+    entries, M = matrices.entries(name)
+    O = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    want = oracle_layout(O, 0)
+    assert_layout_equal(A.layout(), want, name)
+    binf = str(tmp_path / (name + ".bin"))
+    A.write_bin(binf)
+    assert os.path.getsize(binf) == 16 * len(entries)
+    B = host.Matrix(comm).read_file(binf).assemble()
+    assert_layout_equal(B.layout(), want, name + ".bin")
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -79,7 +95,13 @@ def _worker(rank, world, port, case, ret):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         comm = host.Comm("host", "dist", dist)
-        if case[0] == "poisson":
+        if case[0] == "file":
+            import tempfile
+            tmp = tempfile.mkdtemp()
+            A = host.Matrix(comm).read_file(matrices.path(case[1], tmp)).assemble()     # every rank reads its chunk
+            entries, Mbig = matrices.entries(case[1])
+            rhs_want = None
+        elif case[0] == "poisson":
             m = case[1]
             A = host.Matrix(comm).laplacian3D(m).assemble()
             entries, Mbig = orc.laplacian3d(m)
@@ -116,7 +138,8 @@ def _worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, ("poisson", 8)), (3, ("poisson", 12)), (2, ("band", 150, 7)), (4, ("band", 16, 15))])
+@pytest.mark.parametrize("world,case", [(2, ("poisson", 8)), (3, ("poisson", 12)), (2, ("band", 150, 7)), (4, ("band", 16, 15)),
+                                        (3, ("file", "plat362"))])
 def test_distributed_assemble_gloo(world, case):
     import torch.multiprocessing as mp
     port = _free_port()

@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from tests import inputs
+from tests import inputs, matrices
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(glob.glob(os.path.join(GOLDEN, "ref_*.npz")))
@@ -29,6 +29,8 @@ TOL_SMOOTH = 1e-12
 
 
 def _entries(tag):
+    if tag in matrices.FILES:
+        return matrices.entries(tag)
     if tag.startswith("poisson"):
         m = int(tag[len("poisson"):])
         return orc.laplacian3d(m)
@@ -61,10 +63,11 @@ def test_oracle_matches_reference(fn):
 
     A = orc.OracleOp(entries, Mbig, Mbig, split)
 
-    # --- storage layout, rank by rank, bit exact ---
-    sizes = ref["sizes"].reshape(nprocs, 8)
+    # --- storage layout, rank by rank, bit exact (file-matrix fixtures carry vectors only) ---
+    light = "sizes" not in ref
+    sizes = ref["sizes"].reshape(nprocs, 8) if not light else None
     off = {k: 0 for k in ("loc", "rem", "colrem", "vidx", "rp", "sp", "row")}
-    for r in range(nprocs):
+    for r in range(0 if light else nprocs):
         M, nl, nr, ncr, vsz, rsz, nrp, nsp = sizes[r]
         R = A.rank(r)
         assert (R.M, R.nnz_l_local, R.nnz_l_remote, R.col_remote_size) == (M, nl, nr, ncr)
@@ -121,6 +124,8 @@ def test_oracle_matches_reference(fn):
     pins = ref["pins"]
     assert abs(np.dot(A.matvec(v), A.matvec(v)) - pins[0]) <= 1e-12 * pins[0]
 
+    if light:
+        return
     # --- grid transfer operators on the reference's two partitions ---
     pr, pc, pv, Nc = inputs.synthetic_P(Mbig)
     splitNew = ref["splitNew"]
