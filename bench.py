@@ -109,10 +109,10 @@ def vcycle_leg(capi, host, A, m):
 def pmc_traffic(m, world):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
     (PMC counters cannot be read from inside the process); None for other configurations."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_spmv_128.json")
+    path = os.path.join(ROOT, "profiles", "r01_pmc_spmv_128_cc16.json")
     if m == 128 and world == 1 and os.path.exists(path):
         with open(path) as f:
-            return json.load(f)["traffic_bytes_per_launch"], "profiles/r01_pmc_spmv_128.json"
+            return json.load(f)["traffic_bytes_per_launch"], "profiles/r01_pmc_spmv_128_cc16.json"
     return None, None
 
 
@@ -155,7 +155,9 @@ def main():
         split = np.array([r * n * n * n for r in range(world + 1)], np.int32)
         A.assemble(split)                                # even z-slabs: 126 planes per rank
     op = host.device_operator(A)
+    op.autotune()                                        # plan-time choice among the kernel variants
     info = op.info()
+    variant, kernel_name = op.variant()
     M = info["M"]
     g0 = int(A.split[rank])
     x = capi.DeviceVector(M, np.sin(0.001 * (g0 + np.arange(M))))
@@ -211,7 +213,7 @@ def main():
                 "pct_of_hbm_peak": round(B_total / sec_per_step / 1e9 / (HBM_PEAK_GBS * world) * 100, 2),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_csr_stream<EPI_SPMV,1>",
+                "bound": "hbm", "kernel": f"{kernel_name}, {info['lanes_per_row']} lane(s)/row",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "us_per_launch": round(ms_kernel * 1e3, 3), "algorithmic_bytes": B_local,

@@ -67,6 +67,7 @@ SYMBOLS = {
     "sgpu_op_set_lanes_per_row": (C.c_int, [_VP, C.c_int]),
     "sgpu_op_set_variant": (C.c_int, [_VP, C.c_int]),
     "sgpu_op_autotune": (C.c_int, [_VP]),
+    "sgpu_op_get_variant": (C.c_int, [_VP, _PI, C.POINTER(C.c_char_p)]),
     "sgpu_spmv": (C.c_int, [_VP, _VP, _VP]),
     "sgpu_residual": (C.c_int, [_VP, _VP, _VP, _VP]),
     "sgpu_jacobi": (C.c_int, [_VP, C.c_int, C.c_double, _VP, _VP]),
@@ -235,6 +236,11 @@ class Operator:
 
     def set_lanes_per_row(self, lanes):
         check(lib().sgpu_op_set_lanes_per_row(self.h, int(lanes)))
+
+    def variant(self):
+        v, name = C.c_int(), C.c_char_p()
+        check(lib().sgpu_op_get_variant(self.h, C.byref(v), C.byref(name)))
+        return v.value, name.value.decode()
 
     def autotune(self):
         check(lib().sgpu_op_autotune(self.h))

@@ -58,6 +58,15 @@ struct SpmvArgs {
     double        c1;        // d1
     int           nblk;
     const int    *rows;      // remote part: compact list of rows that own remote entries (else nullptr)
+    // column-tile form (k_csr_tile): per block the sorted distinct columns it touches, and per nnz the
+    // 16-bit position of its column in that list
+    const int            *uc_ptr;   // [nblk+1]
+    const int            *ucol;     // [uc_ptr[nblk]]
+    const unsigned short *lcol;     // [nnz] (padded)
+    // 16-bit compressed columns (k_csr_cc16): per block 16 segment bases (multiples of 4096), per nnz
+    // (segment slot << 12) | (column & 4095)
+    const int            *segtab;   // [nblk*16]
+    const unsigned short *ccol;     // [nnz] (padded)
 };
 
 // Remote-part epilogues: the local kernel already applied the epilogue to
@@ -246,6 +255,126 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
     __syncthreads();
 
     // ---- phase 2: G lanes per row
+    constexpr int ROWS_PER_PASS = BLOCK / G;
+    const int g = tid / G, l = tid % G;
+    for (int r = r0 + g; r < r1; r += ROWS_PER_PASS) {
+        const int s = a.row_ptr[r] - a0, e = a.row_ptr[r + 1] - a0;
+        double sum = 0.0;
+        for (int k = s + l; k < e; k += G) sum += lds[k];
+        sum = group_sum<G>(sum);
+        if (l == 0) {
+            if (a.rows) epilogue_remote<EPI>(a, a.rows[r], sum); else epilogue<EPI>(a, r, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1c: column-tile SpMV.  PMC counters show that the 8-byte x[col] gather issues about one lane per
+// clock per CU in the vector L1 (TCP), which caps operators with scattered columns (67 nnz/row coarse
+// levels) near 4.8 TB/s, below the HBM read ceiling.  Here each block first stages the DISTINCT columns
+// it touches (sorted, so the global gather coalesces into runs and each x element is fetched once per
+// block instead of once per nonzero) into an LDS tile, then gathers from LDS (32 lanes/clk) through
+// 16-bit tile-local column ids.  val/lcol stream with 16-B/8-B loads exactly like k_csr_stream, issued
+// before the barrier so they overlap the tile fill.  Bytes per nnz: 8 (val) + 2 (lcol) + 4 nu/nnz (ucol).
+template <int EPI, int G, int CAPV>
+__global__ __launch_bounds__(BLOCK) void k_csr_tile(const SpmvArgs a) {
+    constexpr int LDSN = CAPV + 8;
+    __shared__ __attribute__((aligned(16))) double lds[LDSN];
+    __shared__ __attribute__((aligned(16))) double xt[CAPV];
+    const int tid = threadIdx.x;
+    const int b   = xcd_remap(blockIdx.x, a.nblk);
+    const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
+    const int p0 = a.row_ptr[r0], p1 = a.row_ptr[r1];
+    const int u0 = a.uc_ptr[b], nu = a.uc_ptr[b + 1] - u0;
+
+    // the planner never gives a long row (> CAPV products) to this kernel
+    const int a0 = p0 & ~3;
+    const int nq = (p1 - a0 + 3) >> 2;
+    constexpr int ITER = (LDSN / 4 + BLOCK - 1) / BLOCK;
+    double2 v01[ITER], v23[ITER];
+    uint2   lc[ITER];
+    const int qlast = nq > 0 ? nq - 1 : 0;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {               // val / lcol stream: issued first, consumed after the barrier
+        int q = tid + it * BLOCK;
+        q = q < qlast ? q : qlast;
+        const int idx = a0 + 4 * q;
+        v01[it] = *reinterpret_cast<const double2 *>(a.val + idx);
+        v23[it] = *reinterpret_cast<const double2 *>(a.val + idx + 2);
+        lc[it]  = *reinterpret_cast<const uint2 *>(a.lcol + idx);
+    }
+    for (int t = tid; t < nu; t += BLOCK) xt[t] = a.x[a.ucol[u0 + t]];     // tile fill: sorted columns
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int q = tid + it * BLOCK;
+        if (q < nq) {
+            double2 w01, w23;
+            w01.x = v01[it].x * xt[lc[it].x & 0xffffu];
+            w01.y = v01[it].y * xt[lc[it].x >> 16];
+            w23.x = v23[it].x * xt[lc[it].y & 0xffffu];
+            w23.y = v23[it].y * xt[lc[it].y >> 16];
+            *reinterpret_cast<double2 *>(&lds[4 * q])     = w01;
+            *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = w23;
+        }
+    }
+    __syncthreads();
+
+    constexpr int ROWS_PER_PASS = BLOCK / G;
+    const int g = tid / G, l = tid % G;
+    for (int r = r0 + g; r < r1; r += ROWS_PER_PASS) {
+        const int s = a.row_ptr[r] - a0, e = a.row_ptr[r + 1] - a0;
+        double sum = 0.0;
+        for (int k = s + l; k < e; k += G) sum += lds[k];
+        sum = group_sum<G>(sum);
+        if (l == 0) {
+            if (a.rows) epilogue_remote<EPI>(a, a.rows[r], sum); else epilogue<EPI>(a, r, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1d: k_csr_stream with 16-bit compressed column ids.  The kernel is HBM-bound, so bytes are time:
+// a row block of a mesh-like operator touches only a few 4096-column segments (a 7-point stencil: the
+// three z-planes; a smoothed-aggregation coarse level: five), so each column is stored as a 4-bit slot
+// into the block's table of <= 16 segment bases plus a 12-bit offset: 10 B/nnz instead of 12.  Operators
+// whose blocks touch more than 16 segments keep the 32-bit kernel (decided per operator at plan time).
+// Arithmetic and summation order are those of k_csr_stream (bit-identical results).
+template <int EPI, int G, int CAPV>
+__global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
+    constexpr int LDSN = CAPV + 8;
+    __shared__ __attribute__((aligned(16))) double lds[LDSN];
+    __shared__ int seg[16];
+    const int tid = threadIdx.x;
+    const int b   = xcd_remap(blockIdx.x, a.nblk);
+    const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
+    const int p0 = a.row_ptr[r0], p1 = a.row_ptr[r1];
+    if (tid < 16) seg[tid] = a.segtab[b * 16 + tid];
+    __syncthreads();
+
+    const int a0 = p0 & ~3;
+    const int nq = (p1 - a0 + 3) >> 2;
+    constexpr int ITER = (LDSN / 4 + BLOCK - 1) / BLOCK;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int q = tid + it * BLOCK;
+        if (q < nq) {
+            const int idx = a0 + 4 * q;
+            const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
+            const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
+            const uint2   c   = *reinterpret_cast<const uint2 *>(a.ccol + idx);
+            const unsigned c0 = c.x & 0xffffu, c1 = c.x >> 16, c2 = c.y & 0xffffu, c3 = c.y >> 16;
+            double2 o01, o23;
+            o01.x = v01.x * a.x[seg[c0 >> 12] + (int)(c0 & 4095u)];
+            o01.y = v01.y * a.x[seg[c1 >> 12] + (int)(c1 & 4095u)];
+            o23.x = v23.x * a.x[seg[c2 >> 12] + (int)(c2 & 4095u)];
+            o23.y = v23.y * a.x[seg[c3 >> 12] + (int)(c3 & 4095u)];
+            *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
+            *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
+        }
+    }
+    __syncthreads();
+
     constexpr int ROWS_PER_PASS = BLOCK / G;
     const int g = tid / G, l = tid % G;
     for (int r = r0 + g; r < r1; r += ROWS_PER_PASS) {

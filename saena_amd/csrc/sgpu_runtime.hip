@@ -93,9 +93,20 @@ struct CsrPart {
     int     nblk = 0, nblk_big = 0;
     int     lanes = 1;            // G
     int     variant = 0;          // 0 stream CAP/quad, 1 quad+hoist, 2 CAP_BIG quad+hoist, 3 vector CSR,
-                                  // 4 CAP/pair, 5 CAP/single, 6 CAP_BIG/pair, 7 CAP_BIG/single
+                                  // 4 CAP/pair, 5 CAP/single, 6 CAP_BIG/pair, 7 CAP_BIG/single, 8 column tile CAP, 9 column tile CAP_BIG
+    // column-tile form (built on demand by build_tiles): [0] for the CAP plan, [1] for the CAP_BIG plan
+    int            *uc_ptr[2] = {nullptr, nullptr}, *ucol[2] = {nullptr, nullptr};
+    unsigned short *lcol[2] = {nullptr, nullptr};
+    bool            tile_ok[2] = {false, false};
+    // 16-bit compressed columns (variants 10/11): per plan a segment table and packed column ids
+    int            *segtab[2] = {nullptr, nullptr};
+    unsigned short *ccol[2] = {nullptr, nullptr};
+    bool            cc_ok[2] = {false, false};
+    std::vector<int> h_rp, h_col, h_blk, h_blk_big;   // host copies kept for build_tiles / the coarsest factorisation
     void free_all() {
         hipFree(row_ptr); hipFree(col); hipFree(blk_row); hipFree(blk_row_big); hipFree(rows); hipFree(val);
+        for (int k = 0; k < 2; ++k) { hipFree(uc_ptr[k]); hipFree(ucol[k]); hipFree(lcol[k]); uc_ptr[k] = ucol[k] = nullptr; lcol[k] = nullptr; }
+        for (int k = 0; k < 2; ++k) { hipFree(segtab[k]); hipFree(ccol[k]); segtab[k] = nullptr; ccol[k] = nullptr; }
         row_ptr = col = blk_row = blk_row_big = rows = nullptr; val = nullptr;
     }
 };
@@ -135,11 +146,70 @@ int build_part(CsrPart &P, const std::vector<int> &rp, const std::vector<int> &c
     P.nblk_big = (int)blk_big.size() - 1;
     P.lanes = auto_lanes(P.nrows, P.nblk);
     CHK(dev_upload(&P.blk_row_big, blk_big.data(), blk_big.size()));
+    P.h_rp = rp; P.h_col = col; P.h_blk = blk; P.h_blk_big = blk_big;
     CHK(dev_upload(&P.row_ptr, rp.data(), rp.size()));
     CHK(dev_upload(&P.col, col.data(), col.size(), 8));
     CHK(dev_upload(&P.val, val.data(), val.size(), 8));
     CHK(dev_upload(&P.blk_row, blk.data(), blk.size()));
     if (rows) CHK(dev_upload(&P.rows, rows->data(), rows->size()));
+    return SGPU_OK;
+}
+
+// Column tiles of plan k (0: CAP, 1: CAP_BIG): distinct sorted columns per block + 16-bit local ids.
+// Fails softly (tile_ok stays false) when a block holds a row longer than the tile.
+int build_tiles(CsrPart &P, int k) {
+    if (P.tile_ok[k] || P.h_rp.empty()) return SGPU_OK;
+    const std::vector<int> &blk = k ? P.h_blk_big : P.h_blk;
+    const int cap = k ? sk::CAP_BIG : sk::CAP;
+    const int nblk = (int)blk.size() - 1;
+    std::vector<int> ucp((size_t)nblk + 1, 0), ucol;
+    std::vector<unsigned short> lcol(P.h_col.size() + 8, 0);
+    std::vector<int> tmp;
+    for (int b = 0; b < nblk; ++b) {
+        const int p0 = P.h_rp[blk[b]], p1 = P.h_rp[blk[b + 1]];
+        if (p1 - p0 > cap) return SGPU_OK;                       // long row: this plan cannot be tiled
+        tmp.assign(P.h_col.begin() + p0, P.h_col.begin() + p1);
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        for (int p = p0; p < p1; ++p)
+            lcol[p] = (unsigned short)(std::lower_bound(tmp.begin(), tmp.end(), P.h_col[p]) - tmp.begin());
+        ucol.insert(ucol.end(), tmp.begin(), tmp.end());
+        ucp[b + 1] = (int)ucol.size();
+    }
+    CHK(dev_upload(&P.uc_ptr[k], ucp.data(), ucp.size()));
+    CHK(dev_upload(&P.ucol[k], ucol.data(), ucol.size(), 8));
+    CHK(dev_upload(&P.lcol[k], lcol.data(), lcol.size()));
+    P.tile_ok[k] = true;
+    return SGPU_OK;
+}
+
+// 16-bit compressed columns of plan k: (slot << 12) | (col & 4095) with <= 16 segment bases per block.
+int build_cc16(CsrPart &P, int k) {
+    if (P.cc_ok[k] || P.h_rp.empty()) return SGPU_OK;
+    const std::vector<int> &blk = k ? P.h_blk_big : P.h_blk;
+    const int cap = k ? sk::CAP_BIG : sk::CAP;
+    const int nblk = (int)blk.size() - 1;
+    std::vector<int> segtab((size_t)nblk * 16, 0);
+    std::vector<unsigned short> ccol(P.h_col.size() + 8, 0);
+    for (int b = 0; b < nblk; ++b) {
+        const int p0 = P.h_rp[blk[b]], p1 = P.h_rp[blk[b + 1]];
+        if (p1 - p0 > cap) return SGPU_OK;                       // long-row blocks keep the 32-bit kernel
+        int nseg = 0;
+        int *tab = &segtab[(size_t)b * 16];
+        for (int p = p0; p < p1; ++p) {
+            const int sgm = P.h_col[p] >> 12;
+            int slot = -1;
+            for (int t = nseg - 1; t >= 0; --t) if (tab[t] == (sgm << 12)) { slot = t; break; }
+            if (slot < 0) {
+                if (nseg == 16) return SGPU_OK;                   // too scattered for 4-bit slots
+                tab[nseg] = sgm << 12; slot = nseg++;
+            }
+            ccol[p] = (unsigned short)((slot << 12) | (P.h_col[p] & 4095));
+        }
+    }
+    CHK(dev_upload(&P.segtab[k], segtab.data(), segtab.size()));
+    CHK(dev_upload(&P.ccol[k], ccol.data(), ccol.size()));
+    P.cc_ok[k] = true;
     return SGPU_OK;
 }
 
@@ -160,7 +230,7 @@ struct sgpu_op {
     std::vector<int> sendRank, sendCount, sendDispl, recvRank, recvCount, recvDispl;
     int     halo_fp32 = 0;
     bool    injected = false;     // test hook: halo supplied by sgpu_debug_inject_halo
-    std::vector<int> h_rp, h_col; std::vector<double> h_val;   // host copy of small local parts (coarsest-level factorisation)
+    std::vector<double> h_val;   // host copy of the values of small local parts (coarsest-level factorisation)
     hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
 };
 
@@ -215,6 +285,54 @@ VecKernelFn pick_vec_g(int lanes) {
         default: return sk::k_csr_vector<EPI, 64>;
     }
 }
+template <int EPI, int CAPV>
+KernelFn pick_tile_g(int lanes) {
+    switch (lanes) {
+        case 1:  return sk::k_csr_tile<EPI, 1, CAPV>;
+        case 2:  return sk::k_csr_tile<EPI, 2, CAPV>;
+        case 4:  return sk::k_csr_tile<EPI, 4, CAPV>;
+        case 8:  return sk::k_csr_tile<EPI, 8, CAPV>;
+        case 16: return sk::k_csr_tile<EPI, 16, CAPV>;
+        case 32: return sk::k_csr_tile<EPI, 32, CAPV>;
+        default: return sk::k_csr_tile<EPI, 64, CAPV>;
+    }
+}
+template <int EPI, int CAPV>
+KernelFn pick_cc_g(int lanes) {
+    switch (lanes) {
+        case 1:  return sk::k_csr_cc16<EPI, 1, CAPV>;
+        case 2:  return sk::k_csr_cc16<EPI, 2, CAPV>;
+        case 4:  return sk::k_csr_cc16<EPI, 4, CAPV>;
+        case 8:  return sk::k_csr_cc16<EPI, 8, CAPV>;
+        case 16: return sk::k_csr_cc16<EPI, 16, CAPV>;
+        case 32: return sk::k_csr_cc16<EPI, 32, CAPV>;
+        default: return sk::k_csr_cc16<EPI, 64, CAPV>;
+    }
+}
+KernelFn pick_cc(int epi, int lanes, bool big) {
+#define SGPU_CC_CASE(E) case E: return big ? pick_cc_g<E, sk::CAP_BIG>(lanes) : pick_cc_g<E, sk::CAP>(lanes)
+    switch (epi) {
+        SGPU_CC_CASE(sk::EPI_SPMV);
+        SGPU_CC_CASE(sk::EPI_RESIDUAL);
+        SGPU_CC_CASE(sk::EPI_JACOBI);
+        SGPU_CC_CASE(sk::EPI_CHEBY0);
+        SGPU_CC_CASE(sk::EPI_CHEBYK);
+        default: return big ? pick_cc_g<sk::EPI_SUB, sk::CAP_BIG>(lanes) : pick_cc_g<sk::EPI_SUB, sk::CAP>(lanes);
+    }
+#undef SGPU_CC_CASE
+}
+KernelFn pick_tile(int epi, int lanes, bool big) {
+#define SGPU_TILE_CASE(E) case E: return big ? pick_tile_g<E, sk::CAP_BIG>(lanes) : pick_tile_g<E, sk::CAP>(lanes)
+    switch (epi) {
+        SGPU_TILE_CASE(sk::EPI_SPMV);
+        SGPU_TILE_CASE(sk::EPI_RESIDUAL);
+        SGPU_TILE_CASE(sk::EPI_JACOBI);
+        SGPU_TILE_CASE(sk::EPI_CHEBY0);
+        SGPU_TILE_CASE(sk::EPI_CHEBYK);
+        default: return big ? pick_tile_g<sk::EPI_SUB, sk::CAP_BIG>(lanes) : pick_tile_g<sk::EPI_SUB, sk::CAP>(lanes);
+    }
+#undef SGPU_TILE_CASE
+}
 VecKernelFn pick_vec(int epi, int lanes) {
     switch (epi) {
         case sk::EPI_SPMV:     return pick_vec_g<sk::EPI_SPMV>(lanes);
@@ -238,7 +356,22 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.row_ptr = P.row_ptr; a.col = P.col; a.val = P.val;
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
     a.c0 = e.c0; a.c1 = e.c1; a.rows = P.rows;
-    if (P.variant == 3) {
+    a.uc_ptr = nullptr; a.ucol = nullptr; a.lcol = nullptr; a.segtab = nullptr; a.ccol = nullptr;
+    if (P.variant == 10 || P.variant == 11) {
+        const int k = P.variant - 10;
+        if (!P.cc_ok[k]) return fail(SGPU_ERR_STATE, "compressed columns of plan %d were not built", k);
+        a.blk_row = k ? P.blk_row_big : P.blk_row;
+        a.nblk = k ? P.nblk_big : P.nblk;
+        a.segtab = P.segtab[k]; a.ccol = P.ccol[k];
+        hipLaunchKernelGGL(pick_cc(epi, P.lanes, k == 1), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+    } else if (P.variant == 8 || P.variant == 9) {
+        const int k = P.variant - 8;
+        if (!P.tile_ok[k]) return fail(SGPU_ERR_STATE, "column tiles of plan %d were not built", k);
+        a.blk_row = k ? P.blk_row_big : P.blk_row;
+        a.nblk = k ? P.nblk_big : P.nblk;
+        a.uc_ptr = P.uc_ptr[k]; a.ucol = P.ucol[k]; a.lcol = P.lcol[k];
+        hipLaunchKernelGGL(pick_tile(epi, P.lanes, k == 1), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+    } else if (P.variant == 3) {
         const int rpb = sk::BLOCK / P.lanes;
         a.blk_row = nullptr; a.nblk = 0;
         hipLaunchKernelGGL(pick_vec(epi, P.lanes), dim3((P.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
@@ -509,7 +642,7 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         }
         std::vector<double> val(d->val_local, d->val_local + d->nnz_l_local);
         CHK(build_part(op->loc, rp, col, val, nullptr));
-        if (d->M <= sk::CG_MAXN) { op->h_rp = rp; op->h_col = col; op->h_val = val; }
+        if (d->M <= sk::CG_MAXN) op->h_val = val;
     }
     // remote part: CSC over the receive buffer -> CSR over the halo buffer on the rows that own remote entries
     if (d->nnz_l_remote > 0) {
@@ -607,9 +740,26 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
     return SGPU_OK;
 }
 
+int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
+    if (!op) return fail(SGPU_ERR_ARG, "null op");
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<16KiB,hoisted>", "k_csr_stream<32KiB,hoisted>", "k_csr_vector",
+                                  "k_csr_stream<16KiB,pair>", "k_csr_stream<16KiB,single>", "k_csr_stream<32KiB,pair>", "k_csr_stream<32KiB,single>",
+                                  "k_csr_tile<16KiB>", "k_csr_tile<32KiB>", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>"};
+    if (variant) *variant = op->loc.variant;
+    if (kernel_name) *kernel_name = names[op->loc.variant];
+    return SGPU_OK;
+}
+
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 7) return fail(SGPU_ERR_ARG, "variant must be 0..7");
+    if (variant < 0 || variant > 11) return fail(SGPU_ERR_ARG, "variant must be 0..11");
+    if (variant >= 10) {
+        CHK(build_cc16(op->loc, variant - 10));
+        if (!op->loc.cc_ok[variant - 10]) return fail(SGPU_ERR_ARG, "this operator's blocks touch more than 16 column segments (or hold a long row)");
+    } else if (variant >= 8) {
+        CHK(build_tiles(op->loc, variant - 8));
+        if (!op->loc.tile_ok[variant - 8]) return fail(SGPU_ERR_ARG, "this operator has rows longer than the column tile");
+    }
     op->loc.variant = variant;
     return SGPU_OK;
 }
@@ -630,8 +780,10 @@ int sgpu_op_autotune(sgpu_op *op) {
     const int kind = op->inv_diag ? 1 : 0;
     float best = 1e30f;
     int bv = 0, bg = g0;
+    std::vector<int> variants = {0, 2, 3};
+    for (int k = 0; k < 2; ++k) { CHK(build_cc16(op->loc, k)); if (op->loc.cc_ok[k]) variants.push_back(10 + k); }
     for (int round = 0; round < 2; ++round)
-        for (int v : {0, 2, 3})
+        for (int v : variants)
             for (int gl : lanes) {
                 op->loc.variant = v; op->loc.lanes = gl;
                 float ms = 0;
@@ -639,6 +791,11 @@ int sgpu_op_autotune(sgpu_op *op) {
                 if (round == 1 && ms < best) { best = ms; bv = v; bg = gl; }
             }
     op->loc.variant = bv; op->loc.lanes = bg;
+    for (int k = 0; k < 2; ++k)                       // free the compressed arrays of the plans that lost
+        if (op->loc.cc_ok[k] && bv != 10 + k) {
+            hipFree(op->loc.segtab[k]); hipFree(op->loc.ccol[k]);
+            op->loc.segtab[k] = nullptr; op->loc.ccol[k] = nullptr; op->loc.cc_ok[k] = false;
+        }
     return SGPU_OK;
 }
 
@@ -926,11 +1083,11 @@ int sgpu_amg_create(int nlevels, sgpu_op *const *A, sgpu_op *const *P, sgpu_op *
         // dense inverse by Gauss-Jordan with partial pivoting (host, once)
         sgpu_op *Ac = A[nlevels - 1];
         const int n = Ac->M;
-        if (n > sk::CG_MAXN || (n > 0 && Ac->h_rp.empty())) return fail(SGPU_ERR_ARG, "coarsest level too large for the dense direct solve (%d rows)", n);
+        if (n > sk::CG_MAXN || (n > 0 && Ac->h_val.empty())) return fail(SGPU_ERR_ARG, "coarsest level too large for the dense direct solve (%d rows)", n);
         std::vector<double> a((size_t)n * n, 0.0), inv((size_t)n * n, 0.0);
         for (int i = 0; i < n; ++i) {
             inv[(size_t)i * n + i] = 1.0;
-            for (int k = Ac->h_rp[i]; k < Ac->h_rp[i + 1]; ++k) a[(size_t)i * n + Ac->h_col[k]] = Ac->h_val[k];
+            for (int k = Ac->loc.h_rp[i]; k < Ac->loc.h_rp[i + 1]; ++k) a[(size_t)i * n + Ac->loc.h_col[k]] = Ac->h_val[k];
         }
         for (int c = 0; c < n; ++c) {
             int piv = c;

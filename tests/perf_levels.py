@@ -10,7 +10,7 @@ import numpy as np
 
 from saena_amd import capi, host
 
-VARIANTS = {0: "q16K", 2: "q32Kh", 3: "vec", 4: "pair16K", 5: "one16K", 6: "pair32K", 7: "one32K"}
+VARIANTS = {0: "q16K", 2: "q32Kh", 3: "vec", 10: "cc16K", 11: "cc32K"}
 
 
 def sweep(name, op, kind, x, rhs, y, lanes_list, reps):
@@ -19,7 +19,11 @@ def sweep(name, op, kind, x, rhs, y, lanes_list, reps):
     for rnd in range(2):
         for v in VARIANTS:
             for g in lanes_list:
-                op.set_variant(v)
+                try:
+                    op.set_variant(v)
+                except capi.SgpuError:
+                    res.setdefault((v, g), []).append(1e9)
+                    continue
                 op.set_lanes_per_row(g)
                 op.time_kernel(kind, x, rhs, y, 3)
                 us = op.time_kernel(kind, x, rhs, y, reps) * 1e3

@@ -37,7 +37,7 @@ def main():
         us_s = opA.time_kernel(kind, x, rhs, y, 50) * 1e3
         us_r = opA.time_kernel(2, x, rhs, y, 50) * 1e3
         Bs, Br = opA.algorithmic_bytes(kind), opA.algorithmic_bytes(2)
-        line = (f"L{l}: rows {info['rows']:8d} nnz {info['nnzA']:9d} ({info['nnzA'] / info['rows']:6.1f}/row) G={opA.info()['lanes_per_row']:2d} "
+        line = (f"L{l}: rows {info['rows']:8d} nnz {info['nnzA']:9d} ({info['nnzA'] / info['rows']:6.1f}/row) G={opA.info()['lanes_per_row']:2d} v{opA.variant()[0]:2d} "
                 f"| smooth {us_s:8.1f} us {Bs / us_s / 1e3:7.1f} GB/s | resid {us_r:8.1f} us {Br / us_r / 1e3:7.1f} GB/s")
         lvl_us, lvl_b = 0.0, 0
         if l < nl - 1:
