@@ -155,7 +155,10 @@ def main():
         split = np.array([r * n * n * n for r in range(world + 1)], np.int32)
         A.assemble(split)                                # even z-slabs: 126 planes per rank
     op = host.device_operator(A)
-    op.autotune()                                        # plan-time choice among the kernel variants
+    if os.environ.get("SAENA_BENCH_VARIANT"):            # pin the kernel (rocprofv3 --pmc perturbs the autotune's timings)
+        op.set_variant(int(os.environ["SAENA_BENCH_VARIANT"]))
+    else:
+        op.autotune()                                    # plan-time choice among the kernel variants
     info = op.info()
     variant, kernel_name = op.variant()
     M = info["M"]
