@@ -98,7 +98,8 @@ void  saena_amg_free(saena_amg_h *S);
 int   saena_amg_set_matrix(saena_amg_h *S, saena_matrix_h *A, const saena_options_c *opts);
 int   saena_amg_num_levels(saena_amg_h *S);                               /* max_level + 1 */
 int   saena_amg_level_info(saena_amg_h *S, int level, index_t *rows, nnz_t *nnzA, nnz_t *nnzP, double *eig_max);
-/* which: 0 = A_l, 1 = P_l, 2 = R_l */
+int   saena_amg_level_split(saena_amg_h *S, int level, index_t *split_out /* nranks+1 */);   /* row partition of a level */
+/* which: 0 = A_l, 1 = P_l, 2 = R_l (this rank's share when the communicator has more than one rank) */
 int   saena_amg_level_desc(saena_amg_h *S, int level, int which, sgpu_op_desc *out);
 /* [GPU] upload every level (sgpu_op_create) and build the device hierarchy (sgpu_amg_create) */
 int   saena_amg_to_device(saena_amg_h *S);

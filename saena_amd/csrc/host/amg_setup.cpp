@@ -234,7 +234,7 @@ void amg_hierarchy::strength_graph(const saena_matrix &A, float connStrength, st
 // node itself it becomes a root, if it is a root it joins it.  Then aggregate_index_update
 // (setup1:2103-2260): roots are renumbered 0..n-1 in ascending order of their fine index.
 index_t amg_hierarchy::aggregate(const saena_matrix &A, const std::vector<nnz_t> &ptr, const std::vector<index_t> &col,
-                                 std::vector<index_t> &agg) {
+                                 std::vector<index_t> &agg, std::vector<index_t> *roots) {
     const index_t size = A.M;
     agg.resize((size_t)size);
     std::vector<index_t> aggregate2((size_t)size);
@@ -271,6 +271,7 @@ index_t amg_hierarchy::aggregate(const saena_matrix &A, const std::vector<nnz_t>
     std::sort(aggArray.begin(), aggArray.end());
     for (index_t i = 0; i < size; ++i)
         agg[i] = (index_t)(std::lower_bound(aggArray.begin(), aggArray.end(), agg[i]) - aggArray.begin());
+    if (roots) *roots = aggArray;
     return (index_t)aggArray.size();
 }
 
@@ -391,7 +392,7 @@ int amg_hierarchy::coarsen(int l) {
     std::vector<nnz_t> sptr;
     std::vector<index_t> scol, agg;
     strength_graph(A, opts.connStrength, sptr, scol);
-    const index_t new_size = aggregate(A, sptr, scol, agg);
+    const index_t new_size = aggregate(A, sptr, scol, agg, &g.roots);
     sptr = {}; scol = {};
     int ret_val = 0;
     if (opts.dynamic_levels) {                                           // setup1:385-405
@@ -490,6 +491,79 @@ int amg_hierarchy::setup(saena_matrix *A, const amg_options &o) {
         if (opts.smoother == "chebyshev") levels[i + 1].A->eig_max_of_invdiagXA = find_eig(*levels[i + 1].A);   // :315
     }
     levels.resize((size_t)max_level + 1);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// multi-rank: redundant one-rank setup, then row-partition every level
+
+namespace {
+// rows [lo,hi) of a one-rank layout as global-id entries, column-major sorted
+std::vector<cooEntry> slice_entries(const DistLayout &L, index_t lo, index_t hi) {
+    std::vector<nnz_t> ptr((size_t)L.M + 1, 0);
+    for (index_t i = 0; i < L.M; ++i) ptr[i + 1] = ptr[i] + L.nnzPerRow_local[i];
+    std::vector<cooEntry> e;
+    e.reserve((size_t)(ptr[hi] - ptr[lo]));
+    for (index_t i = lo; i < hi; ++i)
+        for (nnz_t k = ptr[i]; k < ptr[i + 1]; ++k) e.emplace_back(i, L.col_local[k], L.val_local[k]);
+    std::sort(e.begin(), e.end(), col_major);
+    return e;
+}
+} // namespace
+
+void amg_hierarchy::distribute(Comm &c, const std::vector<index_t> &split0) {
+    const int np = c.nranks, n = max_level + 1;
+    dist.clear();
+    dist.resize((size_t)n);
+    dist[0].split = split0;
+    for (int l = 1; l < n; ++l) {
+        const index_t rows = levels[l].A->Mbig;
+        std::vector<index_t> sp((size_t)np + 1, rows);
+        sp[0] = 0;
+        if (rows > shrink_rows) {
+            const auto &roots = levels[l - 1].roots;            // splitNew[r] = #roots below the fine boundary
+            for (int r = 1; r < np; ++r)
+                sp[r] = (index_t)(std::lower_bound(roots.begin(), roots.end(), dist[l - 1].split[r]) - roots.begin());
+        }                                                       // else: everything on rank 0 (sp = 0, rows, rows, ...)
+        dist[l].split = sp;
+    }
+    for (int l = 0; l < n; ++l) {
+        dist_level &d = dist[l];
+        const amg_level &g = levels[l];
+        const index_t lo = d.split[c.rank], hi = d.split[c.rank + 1];
+        d.Mbig = g.A->Mbig; d.nnzA = g.A->nnz_g; d.eig_max = g.A->eig_max_of_invdiagXA;
+        d.A.build(c, slice_entries(g.A->L, lo, hi), d.split, d.split);
+        d.inv_diag.assign(g.A->inv_diag.begin() + lo, g.A->inv_diag.begin() + hi);
+        if (l < n - 1) {
+            const std::vector<index_t> &spc = dist[l + 1].split;
+            d.nnzP = g.P.nnz_g;
+            d.P.build(c, slice_entries(g.P.L, lo, hi), d.split, spc);                        // fine rows, coarse columns
+            d.R.build(c, slice_entries(g.R.L, spc[c.rank], spc[c.rank + 1]), spc, d.split);  // coarse rows, fine columns
+        }
+    }
+}
+
+int amg_hierarchy::setup_distributed(saena_matrix *Ad, const amg_options &o) {
+    Comm &c = *Ad->comm;
+    if (!Ad->assembled) throw std::runtime_error("amg setup: the matrix is not assembled");
+    if (c.nranks == 1) { setup(Ad, o); dist.clear(); return 0; }
+    // gather the fine operator on every rank (entries carry global ids)
+    std::vector<int> counts = c.allgather_one((int)Ad->entry.size());
+    std::vector<size_t> sc((size_t)c.nranks, Ad->entry.size() * sizeof(cooEntry)), sd((size_t)c.nranks, 0), rc((size_t)c.nranks), rd((size_t)c.nranks);
+    size_t tot = 0;
+    for (int p = 0; p < c.nranks; ++p) { rc[p] = (size_t)counts[p] * sizeof(cooEntry); rd[p] = tot; tot += rc[p]; }
+    std::vector<cooEntry> all(tot / sizeof(cooEntry));
+    c.alltoallv(Ad->entry.data(), sc.data(), sd.data(), all.data(), rc.data(), rd.data());
+    self_comm.reset(new SelfComm());
+    A_global.reset(new saena_matrix(self_comm.get()));
+    A_global->remove_boundary = false;
+    for (const auto &e : all) A_global->set(e.row, e.col, e.val);
+    all.clear(); all.shrink_to_fit();
+    A_global->assemble();
+    A_global->eig_max_of_invdiagXA = Ad->eig_max_of_invdiagXA;
+    setup(A_global.get(), o);
+    Ad->eig_max_of_invdiagXA = A_global->eig_max_of_invdiagXA;
+    distribute(c, Ad->split);
     return 0;
 }
 

@@ -40,6 +40,17 @@ struct amg_level {
     saena_matrix *A = nullptr;                   // level 0: the caller's matrix; l > 0: owned by `Ac_store` of level l-1
     transfer_matrix P, R;                        // empty on the coarsest level
     std::unique_ptr<saena_matrix> Ac_store;      // A of level l+1
+    std::vector<index_t> roots;                  // fine index of the root of every aggregate, ascending (= coarse numbering)
+};
+
+// One rank's share of a hierarchy that was built at one rank and then row-partitioned.
+struct dist_level {
+    std::vector<index_t> split;                  // row partition of this level over the ranks
+    DistLayout A, P, R;                          // P/R empty on the coarsest level
+    std::vector<value_t> inv_diag;
+    double eig_max = 0;
+    index_t Mbig = 0;
+    nnz_t nnzA = 0, nnzP = 0;
 };
 
 class amg_hierarchy {
@@ -54,13 +65,25 @@ public:
     // saena_object::setup (saena_object.cpp:175-406)
     int setup(saena_matrix *A, const amg_options &o);
 
+    // Multi-rank use (this round): the SpGEMM of the setup is single-rank, so every rank gathers the fine
+    // operator, builds the SAME hierarchy redundantly and keeps its row blocks.  Partition per level: the
+    // fine split is A's; a coarse level inherits it through the aggregates (splitNew[r] = number of roots
+    // below split[r], aggregate_index_update setup1:2115-2122); levels with <= shrink_rows rows live
+    // entirely on rank 0 (the reference shrinks coarse levels onto fewer ranks, saena_matrix_shrink.cpp:167-265).
+    std::vector<dist_level> dist;
+    std::unique_ptr<saena_matrix> A_global;      // the gathered fine operator (one-rank replica)
+    std::unique_ptr<Comm> self_comm;
+    index_t shrink_rows = 4096;
+    int setup_distributed(saena_matrix *A_dist, const amg_options &o);
+    void distribute(Comm &c, const std::vector<index_t> &split0);
+
     // pieces, public for tests ------------------------------------------------
     // create_strength_matrix + strength_matrix::setup_matrix (setup1:520-719, strength_matrix.cpp:233-453):
     // CSR of the strong connections (local rows, global columns), diagonal included
     static void strength_graph(const saena_matrix &A, float connStrength, std::vector<nnz_t> &ptr, std::vector<index_t> &col);
     // aggregation_1_dist + aggregate_index_update (setup1:724-995, :2103-2260); returns the number of aggregates
     static index_t aggregate(const saena_matrix &A, const std::vector<nnz_t> &ptr, const std::vector<index_t> &col,
-                             std::vector<index_t> &agg);
+                             std::vector<index_t> &agg, std::vector<index_t> *roots = nullptr);
     // find_eig (saena_object.cpp:572-592, lamlan_saena.h): largest eigenvalue of D^-1 A by 20 Lanczos steps, x 1.0001
     static double find_eig(const saena_matrix &A);
 

@@ -216,19 +216,25 @@ int amg::set_matrix(saena::matrix *A, saena::options *opts) {
     o.filter_thre = opts->get_filter_thre(); o.filter_max = opts->get_filter_max(); o.filter_start = opts->get_filter_start();
     o.filter_rate = opts->get_filter_rate();
     H_ = new saena_host::amg_hierarchy();
-    H_->setup(A->get_internal_matrix(), o);
+    H_->setup_distributed(A->get_internal_matrix(), o);      // one rank: plain setup; more: redundant setup + row partition
     const int n = H_->max_level + 1;
+    const bool multi = !H_->dist.empty();
     std::vector<double> eig;
     for (int l = 0; l < n; ++l) {
         const saena_host::amg_level &g = H_->levels[l];
         sgpu_op_desc d; sgpu_op *op = nullptr;
+        const int f32 = l >= o.float_level ? 1 : 0;          // float_level semantics (saena_object.cpp:241-244,277-285)
         if (l == 0) op = A->device_op();
-        else { fill_desc(g.A->L, &g.A->inv_diag, &d); gchk(sgpu_op_create(&d, &op), "sgpu_op_create(A)"); }
+        else {
+            if (multi) fill_desc(H_->dist[l].A, &H_->dist[l].inv_diag, &d); else fill_desc(g.A->L, &g.A->inv_diag, &d);
+            d.halo_fp32 = f32;
+            gchk(sgpu_op_create(&d, &op), "sgpu_op_create(A)");
+        }
         dA_.push_back(op);
         eig.push_back(g.A->eig_max_of_invdiagXA);
         if (l < n - 1) {
-            fill_desc(g.P.L, nullptr, &d); gchk(sgpu_op_create(&d, &op), "sgpu_op_create(P)"); dP_.push_back(op);
-            fill_desc(g.R.L, nullptr, &d); gchk(sgpu_op_create(&d, &op), "sgpu_op_create(R)"); dR_.push_back(op);
+            fill_desc(multi ? H_->dist[l].P : g.P.L, nullptr, &d); d.halo_fp32 = f32; gchk(sgpu_op_create(&d, &op), "sgpu_op_create(P)"); dP_.push_back(op);
+            fill_desc(multi ? H_->dist[l].R : g.R.L, nullptr, &d); d.halo_fp32 = f32; gchk(sgpu_op_create(&d, &op), "sgpu_op_create(R)"); dR_.push_back(op);
         }
     }
     if (!std::getenv("SAENA_NO_AUTOTUNE"))

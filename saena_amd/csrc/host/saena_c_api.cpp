@@ -197,12 +197,20 @@ int saena_amg_set_matrix(saena_amg_h *S, saena_matrix_h *A, const saena_options_
             d.dynamic_levels = o->dynamic_levels != 0; d.max_level = o->max_level; d.float_level = o->float_level;
             d.filter_thre = o->filter_thre; d.filter_max = o->filter_max; d.filter_start = o->filter_start; d.filter_rate = o->filter_rate;
         }
-        S->H.setup(&A->A, d);
+        S->H.setup_distributed(&A->A, d);
         S->set = true;
     });
 }
 
 int saena_amg_num_levels(saena_amg_h *S) { return S->set ? S->H.max_level + 1 : 0; }
+
+int saena_amg_level_split(saena_amg_h *S, int l, index_t *split_out) {
+    return guard([&] {
+        if (!S->set || l < 0 || l > S->H.max_level) throw std::runtime_error("bad level");
+        if (S->H.dist.empty()) { split_out[0] = 0; split_out[1] = S->H.levels[l].A->Mbig; }
+        else std::copy(S->H.dist[l].split.begin(), S->H.dist[l].split.end(), split_out);
+    });
+}
 
 int saena_amg_level_info(saena_amg_h *S, int l, index_t *rows, nnz_t *nnzA, nnz_t *nnzP, double *eig) {
     return guard([&] {
@@ -218,9 +226,15 @@ int saena_amg_level_info(saena_amg_h *S, int l, index_t *rows, nnz_t *nnzA, nnz_
 int saena_amg_level_desc(saena_amg_h *S, int l, int which, sgpu_op_desc *out) {
     return guard([&] {
         if (!S->set || l < 0 || l > S->H.max_level) throw std::runtime_error("bad level");
+        if (which != 0 && l == S->H.max_level) throw std::runtime_error("the coarsest level has no P/R");
+        if (!S->H.dist.empty()) {                 // multi-rank: this rank's share
+            const dist_level &d = S->H.dist[l];
+            if (which == 0) fill_desc(d.A, &d.inv_diag, out);
+            else fill_desc(which == 1 ? d.P : d.R, nullptr, out);
+            return;
+        }
         const amg_level &g = S->H.levels[l];
         if (which == 0) fill_desc(g.A->L, &g.A->inv_diag, out);
-        else if (l == S->H.max_level) throw std::runtime_error("the coarsest level has no P/R");
         else fill_desc(which == 1 ? g.P.L : g.R.L, nullptr, out);
     });
 }
@@ -248,17 +262,19 @@ int saena_amg_to_device(saena_amg_h *S) {
     std::vector<double> eig;
     for (int l = 0; l < n; ++l) {
         sgpu_op_desc d; sgpu_op *o = nullptr;
-        const amg_level &g = S->H.levels[l];
         // float_level (saena_object.cpp:241-244,277-285): A of level >= float_level, P/R of level >= float_level
         // exchange their halos in fp32 (compute stays fp64).  Only matters with more than one rank.
         const int fl = S->H.opts.float_level;
-        fill_desc(g.A->L, &g.A->inv_diag, &d); d.halo_fp32 = l >= fl ? 1 : 0;
+        if (saena_amg_level_desc(S, l, 0, &d)) return -1;
+        d.halo_fp32 = l >= fl ? 1 : 0;
         if (gchk(sgpu_op_create(&d, &o))) return -2;
         S->dA.push_back(o);
-        eig.push_back(g.A->eig_max_of_invdiagXA);
+        eig.push_back(S->H.levels[l].A->eig_max_of_invdiagXA);
         if (l < n - 1) {
-            fill_desc(g.P.L, nullptr, &d); d.halo_fp32 = l >= fl ? 1 : 0; if (gchk(sgpu_op_create(&d, &o))) return -2; S->dP.push_back(o);
-            fill_desc(g.R.L, nullptr, &d); d.halo_fp32 = l >= fl ? 1 : 0; if (gchk(sgpu_op_create(&d, &o))) return -2; S->dR.push_back(o);
+            if (saena_amg_level_desc(S, l, 1, &d)) return -1;
+            d.halo_fp32 = l >= fl ? 1 : 0; if (gchk(sgpu_op_create(&d, &o))) return -2; S->dP.push_back(o);
+            if (saena_amg_level_desc(S, l, 2, &d)) return -1;
+            d.halo_fp32 = l >= fl ? 1 : 0; if (gchk(sgpu_op_create(&d, &o))) return -2; S->dR.push_back(o);
         }
     }
     if (!std::getenv("SAENA_NO_AUTOTUNE"))
@@ -281,7 +297,7 @@ sgpu_op *saena_amg_device_op(saena_amg_h *S, int l, int which) {
 
 static int solve_host(saena_amg_h *S, bool pcg, const value_t *rhs_host, value_t *u_host, int *iters, value_t *hist, int cap) {
     if (!S->damg) { h_err = "saena_amg_to_device has not been called"; return -1; }
-    const size_t n = (size_t)S->H.levels[0].A->M;
+    const size_t n = S->H.dist.empty() ? (size_t)S->H.levels[0].A->M : (size_t)S->H.dist[0].A.M;
     value_t *u = nullptr, *rhs = nullptr;
     if (gchk(sgpu_vec_alloc(&u, n)) || gchk(sgpu_vec_alloc(&rhs, n))) return -2;
     int s = gchk(sgpu_vec_upload(rhs, rhs_host, n));

@@ -906,6 +906,7 @@ struct sgpu_amg {
     // the ~70 launch gaps of a V-cycle, which weigh as much as a whole coarse level
     struct Captured { double *u; const double *rhs; hipGraph_t graph; hipGraphExec_t exec; };
     double *Ainv = nullptr;   // dense inverse of the coarsest operator (coarse_solver == 1)
+    bool coarse_local = true; // the coarsest operator has no halo on any rank
     std::vector<Captured> graphs;
 };
 
@@ -969,7 +970,10 @@ int coarse_solve(sgpu_amg *h, double *u, const double *rhs, int *iters) {
         if (iters) *iters = 0;
         return SGPU_OK;
     }
-    if (g.nranks == 1) return coarse_cg_single(h, A, u, rhs, iters);
+    if (h->coarse_local) {
+        if (A->M == 0) { if (iters) *iters = 0; return SGPU_OK; }      // this rank holds no coarsest rows
+        return coarse_cg_single(h, A, u, rhs, iters);
+    }
     return coarse_cg_dist(h, A, u, rhs, iters);
 }
 
@@ -1079,7 +1083,20 @@ int sgpu_amg_create(int nlevels, sgpu_op *const *A, sgpu_op *const *P, sgpu_op *
         if (l < nlevels - 1) HIPCHK(alloc(&h->res[l], n));
         if (l >= 1) { HIPCHK(alloc(&h->rhs[l], n)); HIPCHK(alloc(&h->u[l], n)); HIPCHK(alloc(&h->alt[l], n)); }
     }
-    if (h->prm.coarse_solver == 1 && g.nranks == 1) {
+    // direct coarsest solve: one rank, or a coarsest level that lives whole on one rank (no halo on any rank:
+    // the setup shrinks small levels onto rank 0, ranks holding zero rows have nothing to solve)
+    bool coarse_local = g.nranks == 1;
+    if (g.nranks > 1) {
+        sgpu_op *Ac = A[nlevels - 1];
+        int has_halo = (Ac->vIndexSize || Ac->recvSize) ? 1 : 0;
+        HIPCHK(hipMemcpyAsync(g.dint, &has_halo, sizeof(int), hipMemcpyHostToDevice, g.cs));
+        NCCLCHK(ncclAllReduce(g.dint, g.dint, 1, ncclInt, ncclSum, g.comm, g.cs));
+        HIPCHK(hipMemcpyAsync(g.hint, g.dint, sizeof(int), hipMemcpyDeviceToHost, g.cs));
+        HIPCHK(hipStreamSynchronize(g.cs));
+        coarse_local = g.hint[0] == 0;
+    }
+    h->coarse_local = coarse_local;
+    if (h->prm.coarse_solver == 1 && coarse_local && A[nlevels - 1]->M > 0) {
         // dense inverse by Gauss-Jordan with partial pivoting (host, once)
         sgpu_op *Ac = A[nlevels - 1];
         const int n = Ac->M;

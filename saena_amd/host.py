@@ -75,6 +75,7 @@ HOST_SYMBOLS.update({
     "saena_amg_num_levels": (C.c_int, [_VP]),
     "saena_amg_level_info": (C.c_int, [_VP, C.c_int, _PI, C.POINTER(C.c_long), C.POINTER(C.c_long), _PD]),
     "saena_amg_level_desc": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(OpDesc)]),
+    "saena_amg_level_split": (C.c_int, [_VP, C.c_int, _PI]),
     "saena_amg_to_device": (C.c_int, [_VP]),
     "saena_amg_device_handle": (_VP, [_VP]),
     "saena_amg_device_op": (_VP, [_VP, C.c_int, C.c_int]),
@@ -381,6 +382,11 @@ class AmgSolver:
         rows, na, npp, eig = C.c_int(), C.c_long(), C.c_long(), C.c_double()
         _check(self.L, self.L.saena_amg_level_info(self.h, l, C.byref(rows), C.byref(na), C.byref(npp), C.byref(eig)))
         return dict(rows=rows.value, nnzA=na.value, nnzP=npp.value, eig_max=eig.value)
+
+    def level_split(self, l):
+        s = np.zeros(self.A.comm.nranks + 1, np.int32)
+        _check(self.L, self.L.saena_amg_level_split(self.h, l, s.ctypes.data_as(_PI)))
+        return s
 
     def level_layout(self, l, which):
         d = OpDesc()

@@ -86,3 +86,65 @@ def test_chebyshev_eig_estimate():
     n = 14
     exact = 1 + np.cos(np.pi / (n + 1))        # lambda_max(D^-1 A) of the n^3 Dirichlet Laplacian
     assert 0.97 * exact < e <= 1.0002 * exact
+
+
+# ---- multi-rank: redundant setup + per-level row partition (over gloo, no GPU) ----
+def _dist_worker(rank, world, port, m, ret):
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        from tests.test_host_layout import assert_layout_equal, oracle_layout
+        L = host.load("host")
+        comm = host.Comm("host", "dist", dist)
+        A = host.Matrix(comm).laplacian3D(m).assemble()
+        S = host.AmgSolver(A, host.options(L, **host.OPTIONS001))
+        # the same hierarchy at one rank, in this process
+        A1 = host.Matrix(host.Comm("host", "self")).laplacian3D(m).assemble()
+        S1 = host.AmgSolver(A1, host.options(L, **host.OPTIONS001))
+        assert S.num_levels == S1.num_levels
+        splits = [S.level_split(l) for l in range(S.num_levels)]
+        np.testing.assert_array_equal(splits[0], A.split)
+        assert any(np.all(s[1:] == s[-1]) for s in splits[1:]), "small levels must shrink onto rank 0"
+        assert any(len(set(s.tolist())) == world + 1 for s in splits[1:]), "a large coarse level must stay distributed"
+        for l in range(S.num_levels):
+            assert splits[l][-1] == S1.level_info(l)["rows"]
+            for which in ((0, 1, 2) if l < S.num_levels - 1 else (0,)):
+                glob = S1.level_layout(l, which)
+                ent = coo_from_layout(glob)
+                rs = splits[l] if which != 2 else splits[l + 1]
+                cs = splits[l] if which == 0 else (splits[l + 1] if which == 1 else splits[l])
+                nrows, ncols = rs[-1], cs[-1]
+                O = orc.OracleOp(ent, nrows, ncols, rs, cs, square=(which == 0))
+                want = oracle_layout(O, rank)
+                want.pop("col_remote")
+                assert_layout_equal(S.level_layout(l, which), want, f"level {l} op {which} rank {rank}")
+        ret[rank] = "ok"
+    except BaseException as e:      # noqa
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_hierarchy_gloo():
+    import torch.multiprocessing as mp
+    from tests.test_host_layout import _free_port
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 24, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        res = dict(ret)
+    for r in range(world):
+        assert res.get(r) == "ok", f"rank {r}: {res.get(r)}"

@@ -33,6 +33,8 @@ def oracle_layout(A, r):
 def assert_layout_equal(got, want, what):
     for k, w in want.items():
         g = got[k]
+        if g is None and len(w) == 0:       # a rank that owns no rows of this operator
+            continue
         assert g is not None, f"{what}: {k} missing"
         np.testing.assert_array_equal(g, w, err_msg=f"{what}: {k}")
 
