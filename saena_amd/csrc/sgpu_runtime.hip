@@ -782,14 +782,27 @@ int sgpu_op_autotune(sgpu_op *op) {
     int bv = 0, bg = g0;
     std::vector<int> variants = {0, 2, 3};
     for (int k = 0; k < 2; ++k) { CHK(build_cc16(op->loc, k)); if (op->loc.cc_ok[k]) variants.push_back(10 + k); }
+    // Only the LOCAL part is timed, without the halo exchange: ranks may end up with different candidate
+    // lists (a rank's blocks may be too scattered for 16-bit columns), so no collective may run in here.
+    EpiArgs e; e.rhs = r.p; e.inv_diag = op->inv_diag; e.u = x.p; e.c0 = JACOBI_OMEGA_REF;
+    const int epi = kind == 1 ? sk::EPI_JACOBI : sk::EPI_SPMV;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     for (int round = 0; round < 2; ++round)
         for (int v : variants)
             for (int gl : lanes) {
                 op->loc.variant = v; op->loc.lanes = gl;
+                const int reps = round == 0 ? 2 : 6;
+                HIPCHK(hipEventRecord(e0, g.cs));
+                for (int i = 0; i < reps; ++i) CHK(launch_part(op->loc, epi, x.p, y.p, e));
+                HIPCHK(hipEventRecord(e1, g.cs));
+                HIPCHK(hipEventSynchronize(e1));
                 float ms = 0;
-                CHK(sgpu_time_kernel(op, kind, x.p, r.p, y.p, round == 0 ? 2 : 6, &ms));
+                HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                ms /= reps;
                 if (round == 1 && ms < best) { best = ms; bv = v; bg = gl; }
             }
+    hipEventDestroy(e0); hipEventDestroy(e1);
     op->loc.variant = bv; op->loc.lanes = bg;
     for (int k = 0; k < 2; ++k)                       // free the compressed arrays of the plans that lost
         if (op->loc.cc_ok[k] && bv != 10 + k) {
