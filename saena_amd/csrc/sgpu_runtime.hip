@@ -387,7 +387,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
 
 // Start the halo exchange of x on the halo stream (pack on cs, send/recv on hs).
 int halo_begin(sgpu_op *op, const double *x) {
-    if (g.nranks == 1 || (op->vIndexSize == 0 && op->recvSize == 0)) return SGPU_OK;
+    if (!g.comm || op->injected || (op->vIndexSize == 0 && op->recvSize == 0)) return SGPU_OK;
     const bool f32 = op->halo_fp32 && op->send_f && op->recv_f;
     if (op->vIndexSize) {
         const dim3 grid((op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK);
@@ -415,8 +415,8 @@ int halo_begin(sgpu_op *op, const double *x) {
 int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     CHK(halo_begin(op, x));
     CHK(launch_part(op->loc, epi, x, y, e));
-    if (op->has_remote && (g.nranks > 1 || op->injected)) {
-        if (g.nranks > 1) {
+    if (op->has_remote && (g.comm || op->injected)) {
+        if (g.comm && !op->injected) {
             HIPCHK(hipStreamWaitEvent(g.cs, op->ev_halo, 0));
             if (op->halo_fp32 && op->recv_f && op->recvSize) {      // half the bytes crossed xGMI; widen for the remote part
                 hipLaunchKernelGGL(sk::k_widen_f32, dim3((op->recvSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
@@ -525,7 +525,7 @@ int sgpu_init(int device_id, int rank, int nranks, const void *uid) {
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&g.hscalar), 16 * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&g.dint), 16 * sizeof(int)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&g.hint), 16 * sizeof(int), hipHostMallocDefault));
-    if (nranks > 1) {
+    if (uid) {      // also with one rank when an id is given: the RCCL paths (self send/recv included) then run for real
         ncclUniqueId id;
         memcpy(&id, uid, sizeof id);
         NCCLCHK(ncclCommInitRank(&g.comm, nranks, id, rank));
@@ -556,7 +556,7 @@ int sgpu_device_sync(void) {
 
 int sgpu_barrier(void) {
     CHK(sgpu_device_sync());
-    if (g.nranks > 1) {
+    if (g.comm) {
         HIPCHK(hipMemsetAsync(g.dint, 0, sizeof(int), g.cs));
         NCCLCHK(ncclAllReduce(g.dint, g.dint, 1, ncclInt, ncclSum, g.comm, g.cs));
         HIPCHK(hipStreamSynchronize(g.cs));
@@ -608,7 +608,7 @@ int sgpu_vec_axpby(value_t a, const value_t *x, value_t b, value_t *y, size_t n)
 int sgpu_dot(const value_t *x, const value_t *y, size_t n, value_t *out) {
     CHK(need_ctx());
     CHK(dot_local_async(x, y, n, g.dscalar));
-    if (g.nranks > 1) NCCLCHK(ncclAllReduce(g.dscalar, g.dscalar, 1, ncclDouble, ncclSum, g.comm, g.cs));
+    if (g.comm) NCCLCHK(ncclAllReduce(g.dscalar, g.dscalar, 1, ncclDouble, ncclSum, g.comm, g.cs));
     HIPCHK(hipMemcpyAsync(g.hscalar, g.dscalar, sizeof(double), hipMemcpyDeviceToHost, g.cs));
     HIPCHK(hipStreamSynchronize(g.cs));
     *out = g.hscalar[0];
@@ -685,9 +685,10 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
     }
     if (sd != d->vIndexSize) return fail(SGPU_ERR_ARG, "sum(sendProcCount)=%d != vIndexSize=%d", sd, d->vIndexSize);
     if (rd != d->col_remote_size) return fail(SGPU_ERR_ARG, "sum(recvProcCount)=%d != col_remote_size=%d", rd, d->col_remote_size);
-    if (g.nranks > 1) {   // (a 1-rank context may hold plans of a larger world for the single-GPU halo tests)
-        for (int r : op->sendRank) if (r < 0 || r >= g.nranks || r == g.rank) return fail(SGPU_ERR_ARG, "bad send rank %d", r);
-        for (int r : op->recvRank) if (r < 0 || r >= g.nranks || r == g.rank) return fail(SGPU_ERR_ARG, "bad recv rank %d", r);
+    if (g.comm) {   // (a context without a communicator may hold plans of a larger world for the single-GPU halo tests)
+        const bool loopback = g.nranks == 1;        // one rank with a communicator: self send/recv, for RCCL path tests
+        for (int r : op->sendRank) if (r < 0 || r >= g.nranks || (r == g.rank && !loopback)) return fail(SGPU_ERR_ARG, "bad send rank %d", r);
+        for (int r : op->recvRank) if (r < 0 || r >= g.nranks || (r == g.rank && !loopback)) return fail(SGPU_ERR_ARG, "bad recv rank %d", r);
     }
     if (d->vIndexSize) {
         for (index_t i = 0; i < d->vIndexSize; ++i)
@@ -699,7 +700,7 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->recv_buf), (size_t)op->recvSize * sizeof(double)));
         HIPCHK(hipMemsetAsync(op->recv_buf, 0, (size_t)op->recvSize * sizeof(double), g.cs));
     }
-    if (op->halo_fp32 && g.nranks > 1) {
+    if (op->halo_fp32 && g.comm) {
         if (op->vIndexSize) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->send_f), (size_t)op->vIndexSize * sizeof(float)));
         if (op->recvSize) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->recv_f), (size_t)op->recvSize * sizeof(float)));
     }
@@ -1036,7 +1037,7 @@ int vcycle0_eager(sgpu_amg *h, double *u, const double *rhs) {
 }
 
 int vcycle0(sgpu_amg *h, double *u, const double *rhs) {
-    if (!h->prm.use_graph || g.nranks > 1) return vcycle0_eager(h, u, rhs);
+    if (!h->prm.use_graph || g.comm) return vcycle0_eager(h, u, rhs);
     for (auto &c : h->graphs)
         if (c.u == u && c.rhs == rhs) { HIPCHK(hipGraphLaunch(c.exec, g.cs)); return SGPU_OK; }
     sgpu_amg::Captured c{u, rhs, nullptr, nullptr};
@@ -1098,8 +1099,8 @@ int sgpu_amg_create(int nlevels, sgpu_op *const *A, sgpu_op *const *P, sgpu_op *
     }
     // direct coarsest solve: one rank, or a coarsest level that lives whole on one rank (no halo on any rank:
     // the setup shrinks small levels onto rank 0, ranks holding zero rows have nothing to solve)
-    bool coarse_local = g.nranks == 1;
-    if (g.nranks > 1) {
+    bool coarse_local = !g.comm;
+    if (g.comm) {
         sgpu_op *Ac = A[nlevels - 1];
         int has_halo = (Ac->vIndexSize || Ac->recvSize) ? 1 : 0;
         HIPCHK(hipMemcpyAsync(g.dint, &has_halo, sizeof(int), hipMemcpyHostToDevice, g.cs));
@@ -1311,7 +1312,7 @@ struct RcclHostComm : saena_host::Comm {
     static int do_allreduce(T *d, int n, ncclDataType_t t) { NCCLCHK(ncclAllReduce(d, d, (size_t)n, t, ncclSum, g.comm, g.cs)); return SGPU_OK; }
 
     void allgather(const void *send, void *recv, size_t bytes) override {
-        if (nranks == 1) { memcpy(recv, send, bytes); return; }
+        if (!g.comm) { memcpy(recv, send, bytes); return; }
         Buf s(bytes), r(bytes * nranks);
         ok(h2d(s.p, send, bytes), "allgather h2d");
         ok(do_allgather(s.p, r.p, bytes), "ncclAllGather");
@@ -1320,21 +1321,21 @@ struct RcclHostComm : saena_host::Comm {
     void alltoallv(const void *send, const size_t *sc, const size_t *sd, void *recv, const size_t *rc, const size_t *rd) override {
         size_t sbytes = 0, rbytes = 0;
         for (int p = 0; p < nranks; ++p) { sbytes = std::max(sbytes, sd[p] + sc[p]); rbytes = std::max(rbytes, rd[p] + rc[p]); }
-        if (nranks == 1) { memcpy(static_cast<char *>(recv) + rd[0], static_cast<const char *>(send) + sd[0], sc[0]); return; }
+        if (!g.comm) { memcpy(static_cast<char *>(recv) + rd[0], static_cast<const char *>(send) + sd[0], sc[0]); return; }
         Buf s(sbytes), r(rbytes);
         ok(h2d(s.p, send, sbytes), "alltoallv h2d");
         ok(do_alltoallv(static_cast<const char *>(s.p), sc, sd, static_cast<char *>(r.p), rc, rd), "alltoallv send/recv");
         ok(d2h(recv, r.p, rbytes), "alltoallv d2h");
     }
     void allreduce_sum_i64(long *v, int n) override {
-        if (nranks == 1 || n == 0) return;
+        if (!g.comm || n == 0) return;
         Buf b(sizeof(long) * n);
         ok(h2d(b.p, v, sizeof(long) * n), "allreduce h2d");
         ok(do_allreduce(static_cast<long *>(b.p), n, ncclInt64), "ncclAllReduce");
         ok(d2h(v, b.p, sizeof(long) * n), "allreduce d2h");
     }
     void allreduce_sum_f64(double *v, int n) override {
-        if (nranks == 1 || n == 0) return;
+        if (!g.comm || n == 0) return;
         Buf b(sizeof(double) * n);
         ok(h2d(b.p, v, sizeof(double) * n), "allreduce h2d");
         ok(do_allreduce(static_cast<double *>(b.p), n, ncclDouble), "ncclAllReduce");
