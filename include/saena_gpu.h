@@ -116,10 +116,9 @@ int sgpu_op_info(const sgpu_op *op, index_t *M, index_t *N_local, nnz_t *nnz_loc
                  int *n_row_blocks, int *lanes_per_row);
 /* kernel variant override (tuning/tests): lanes_per_row in {0=auto,1,2,4,...,64} */
 int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
-/* kernel variant of the local part (tuning): 0 stream/16 KiB LDS, 1 = 0 with all loads hoisted,
- * 2 = 1 with 32 KiB LDS blocks, 3 vector CSR (no LDS staging), 4-7 narrower lane ownership (experiments),
- * 8/9 column tile (distinct columns of a block staged in LDS, 16-bit local column ids) on the 16/32 KiB plan,
- * 10/11 16-bit compressed column ids (<= 16 column segments per block; 10 B/nnz) on the 16/32 KiB plan */
+/* kernel variant of the local part: 0 k_csr_stream with 16 KiB tiles, 1 with 32 KiB tiles, 2 k_csr_vector
+ * (no LDS staging), 3 / 4 k_csr_cc16 (16-bit compressed column ids, 10 B/nnz) on the 16 / 32 KiB plan;
+ * 3 and 4 are refused when a block touches more than 16 column segments or holds a row longer than the tile */
 int sgpu_op_set_variant(sgpu_op *op, int variant);
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name);
 /* time a few (variant, lanes) candidates on this operator and keep the fastest (plan-time autotune) */

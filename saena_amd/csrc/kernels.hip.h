@@ -58,11 +58,6 @@ struct SpmvArgs {
     double        c1;        // d1
     int           nblk;
     const int    *rows;      // remote part: compact list of rows that own remote entries (else nullptr)
-    // column-tile form (k_csr_tile): per block the sorted distinct columns it touches, and per nnz the
-    // 16-bit position of its column in that list
-    const int            *uc_ptr;   // [nblk+1]
-    const int            *ucol;     // [uc_ptr[nblk]]
-    const unsigned short *lcol;     // [nnz] (padded)
     // 16-bit compressed columns (k_csr_cc16): per block 16 segment bases (multiples of 4096), per nnz
     // (segment slot << 12) | (column & 4095)
     const int            *segtab;   // [nblk*16]
@@ -131,18 +126,17 @@ __device__ __forceinline__ double group_sum(double v) {
 
 // ---------------------------------------------------------------------------
 // K1: row-block CSR SpMV with fused epilogue.
-//   phase 1: the block streams its nnz range [p0,p1) with 16-B loads, gathers
-//            x and writes val*x to LDS (one rounding, like the CPU's mul);
+//   phase 1: the block streams its nnz range [p0,p1) with 16-B loads (a lane owns 4 consecutive
+//            nnz), gathers x and writes val*x to LDS (one rounding, like the CPU's mul);
 //   phase 2: G lanes per row add the row's products in column order (G = 1
 //            reproduces the reference's sequential sum bit for bit) and the
 //            group leader applies the epilogue.
 // A row block with a single row longer than CAPV takes the long-row path.
-// CAPV = products staged per block (LDS = 8 CAPV bytes); P1 = phase-1 flavour:
-//   0  one quad at a time (load, gather, store per iteration)
-//   1  every val/col load of the block is issued before the first gather, then all
-//      gathers, then the LDS stores: 3x the bytes in flight per wave, which is what
-//      an operator larger than the 256 MiB Infinity Cache needs to cover HBM latency.
-template <int EPI, int G, int CAPV, int P1>
+// CAPV = products staged per block (LDS = 8 CAPV bytes).
+// Measured and dropped (profiles/r01_variant_sweep_128*.log): issuing every load of the block
+// before the first gather (no gain), 1- or 2-nnz lane ownership (more VMEM instructions, -10..-35 %),
+// staging the block's distinct x columns in LDS (two barriers + 32 KiB LDS, -40 % on the 67-nnz/row level).
+template <int EPI, int G, int CAPV>
 __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
     constexpr int LDSN = CAPV + 8;
     __shared__ __attribute__((aligned(16))) double lds[LDSN];
@@ -167,159 +161,30 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
         return;
     }
 
-    // ---- phase 1: coalesced loads of val/col, gather x, products to LDS
-    // P1 = 0/1: a lane owns 4 consecutive nnz (16-B val/col loads);  P1 = 2: 2 consecutive nnz
-    // (16-B val, 8-B col);  P1 = 3: 1 nnz, lane-stride 1.  Narrower ownership makes the 64
-    // lanes of one x-gather instruction touch consecutive nnz = neighbouring columns = few
-    // cache lines, which is what bounds operators with scattered columns (the TA walks one
-    // line per clock); wide ownership minimises load instructions for band-like rows.
-    constexpr int OWN = (P1 == 2) ? 2 : (P1 == 3) ? 1 : 4;
-    const int a0 = p0 & ~(OWN - 1);
-    if constexpr (P1 == 2 || P1 == 3) {
-        const int nu = (p1 - a0 + OWN - 1) / OWN;    // units of OWN nnz
-        constexpr int ITER = (LDSN / OWN + BLOCK - 1) / BLOCK;
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int q = tid + it * BLOCK;
-            if (q < nu) {
-                const int idx = a0 + OWN * q;
-                if constexpr (OWN == 2) {
-                    const double2 v = *reinterpret_cast<const double2 *>(a.val + idx);
-                    const int2    c = *reinterpret_cast<const int2 *>(a.col + idx);
-                    double2 o;
-                    o.x = v.x * a.x[c.x];
-                    o.y = v.y * a.x[c.y];
-                    *reinterpret_cast<double2 *>(&lds[2 * q]) = o;
-                } else {
-                    lds[q] = a.val[idx] * a.x[a.col[idx]];
-                }
-            }
-        }
-    } else {
+    // ---- phase 1: coalesced 16-B loads of val/col, gather x, products to LDS
+    const int a0 = p0 & ~3;
     const int nq = (p1 - a0 + 3) >> 2;                // quads of 4 nnz
     constexpr int ITER = (LDSN / 4 + BLOCK - 1) / BLOCK;
-    if constexpr (P1 == 0) {
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int q = tid + it * BLOCK;
-            if (q < nq) {
-                const int idx = a0 + 4 * q;
-                const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
-                const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
-                const int4    c   = *reinterpret_cast<const int4 *>(a.col + idx);
-                double2 o01, o23;
-                o01.x = v01.x * a.x[c.x];
-                o01.y = v01.y * a.x[c.y];
-                o23.x = v23.x * a.x[c.z];
-                o23.y = v23.y * a.x[c.w];
-                *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
-                *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
-            }
-        }
-    } else {
-        double2 v01[ITER], v23[ITER];
-        int4    c[ITER];
-        const int qlast = nq > 0 ? nq - 1 : 0;        // clamp: out-of-range lanes re-read the last quad (padded arrays)
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            int q = tid + it * BLOCK;
-            q = q < qlast ? q : qlast;
-            const int idx = a0 + 4 * q;
-            v01[it] = *reinterpret_cast<const double2 *>(a.val + idx);
-            v23[it] = *reinterpret_cast<const double2 *>(a.val + idx + 2);
-            c[it]   = *reinterpret_cast<const int4 *>(a.col + idx);
-        }
-        double2 o01[ITER], o23[ITER];
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            o01[it].x = a.x[c[it].x];
-            o01[it].y = a.x[c[it].y];
-            o23[it].x = a.x[c[it].z];
-            o23[it].y = a.x[c[it].w];
-        }
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int q = tid + it * BLOCK;
-            if (q < nq) {
-                double2 w01, w23;
-                w01.x = v01[it].x * o01[it].x;
-                w01.y = v01[it].y * o01[it].y;
-                w23.x = v23[it].x * o23[it].x;
-                w23.y = v23[it].y * o23[it].y;
-                *reinterpret_cast<double2 *>(&lds[4 * q])     = w01;
-                *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = w23;
-            }
-        }
-    }
-    }
-    __syncthreads();
-
-    // ---- phase 2: G lanes per row
-    constexpr int ROWS_PER_PASS = BLOCK / G;
-    const int g = tid / G, l = tid % G;
-    for (int r = r0 + g; r < r1; r += ROWS_PER_PASS) {
-        const int s = a.row_ptr[r] - a0, e = a.row_ptr[r + 1] - a0;
-        double sum = 0.0;
-        for (int k = s + l; k < e; k += G) sum += lds[k];
-        sum = group_sum<G>(sum);
-        if (l == 0) {
-            if (a.rows) epilogue_remote<EPI>(a, a.rows[r], sum); else epilogue<EPI>(a, r, sum);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K1c: column-tile SpMV.  PMC counters show that the 8-byte x[col] gather issues about one lane per
-// clock per CU in the vector L1 (TCP), which caps operators with scattered columns (67 nnz/row coarse
-// levels) near 4.8 TB/s, below the HBM read ceiling.  Here each block first stages the DISTINCT columns
-// it touches (sorted, so the global gather coalesces into runs and each x element is fetched once per
-// block instead of once per nonzero) into an LDS tile, then gathers from LDS (32 lanes/clk) through
-// 16-bit tile-local column ids.  val/lcol stream with 16-B/8-B loads exactly like k_csr_stream, issued
-// before the barrier so they overlap the tile fill.  Bytes per nnz: 8 (val) + 2 (lcol) + 4 nu/nnz (ucol).
-template <int EPI, int G, int CAPV>
-__global__ __launch_bounds__(BLOCK) void k_csr_tile(const SpmvArgs a) {
-    constexpr int LDSN = CAPV + 8;
-    __shared__ __attribute__((aligned(16))) double lds[LDSN];
-    __shared__ __attribute__((aligned(16))) double xt[CAPV];
-    const int tid = threadIdx.x;
-    const int b   = xcd_remap(blockIdx.x, a.nblk);
-    const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
-    const int p0 = a.row_ptr[r0], p1 = a.row_ptr[r1];
-    const int u0 = a.uc_ptr[b], nu = a.uc_ptr[b + 1] - u0;
-
-    // the planner never gives a long row (> CAPV products) to this kernel
-    const int a0 = p0 & ~3;
-    const int nq = (p1 - a0 + 3) >> 2;
-    constexpr int ITER = (LDSN / 4 + BLOCK - 1) / BLOCK;
-    double2 v01[ITER], v23[ITER];
-    uint2   lc[ITER];
-    const int qlast = nq > 0 ? nq - 1 : 0;
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {               // val / lcol stream: issued first, consumed after the barrier
-        int q = tid + it * BLOCK;
-        q = q < qlast ? q : qlast;
-        const int idx = a0 + 4 * q;
-        v01[it] = *reinterpret_cast<const double2 *>(a.val + idx);
-        v23[it] = *reinterpret_cast<const double2 *>(a.val + idx + 2);
-        lc[it]  = *reinterpret_cast<const uint2 *>(a.lcol + idx);
-    }
-    for (int t = tid; t < nu; t += BLOCK) xt[t] = a.x[a.ucol[u0 + t]];     // tile fill: sorted columns
-    __syncthreads();
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int q = tid + it * BLOCK;
         if (q < nq) {
-            double2 w01, w23;
-            w01.x = v01[it].x * xt[lc[it].x & 0xffffu];
-            w01.y = v01[it].y * xt[lc[it].x >> 16];
-            w23.x = v23[it].x * xt[lc[it].y & 0xffffu];
-            w23.y = v23[it].y * xt[lc[it].y >> 16];
-            *reinterpret_cast<double2 *>(&lds[4 * q])     = w01;
-            *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = w23;
+            const int idx = a0 + 4 * q;
+            const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
+            const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
+            const int4    c   = *reinterpret_cast<const int4 *>(a.col + idx);
+            double2 o01, o23;
+            o01.x = v01.x * a.x[c.x];
+            o01.y = v01.y * a.x[c.y];
+            o23.x = v23.x * a.x[c.z];
+            o23.y = v23.y * a.x[c.w];
+            *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
+            *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
         }
     }
     __syncthreads();
 
+    // ---- phase 2: G lanes per row
     constexpr int ROWS_PER_PASS = BLOCK / G;
     const int g = tid / G, l = tid % G;
     for (int r = r0 + g; r < r1; r += ROWS_PER_PASS) {

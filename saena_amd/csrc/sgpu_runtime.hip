@@ -92,20 +92,14 @@ struct CsrPart {
     double *val = nullptr;
     int     nblk = 0, nblk_big = 0;
     int     lanes = 1;            // G
-    int     variant = 0;          // 0 stream CAP/quad, 1 quad+hoist, 2 CAP_BIG quad+hoist, 3 vector CSR,
-                                  // 4 CAP/pair, 5 CAP/single, 6 CAP_BIG/pair, 7 CAP_BIG/single, 8 column tile CAP, 9 column tile CAP_BIG
-    // column-tile form (built on demand by build_tiles): [0] for the CAP plan, [1] for the CAP_BIG plan
-    int            *uc_ptr[2] = {nullptr, nullptr}, *ucol[2] = {nullptr, nullptr};
-    unsigned short *lcol[2] = {nullptr, nullptr};
-    bool            tile_ok[2] = {false, false};
-    // 16-bit compressed columns (variants 10/11): per plan a segment table and packed column ids
+    int     variant = 0;          // 0 stream 16 KiB, 1 stream 32 KiB, 2 vector CSR, 3 cc16 16 KiB, 4 cc16 32 KiB
+    // 16-bit compressed columns (variants 3/4): per plan ([0] 16 KiB, [1] 32 KiB) a segment table and packed column ids
     int            *segtab[2] = {nullptr, nullptr};
     unsigned short *ccol[2] = {nullptr, nullptr};
     bool            cc_ok[2] = {false, false};
-    std::vector<int> h_rp, h_col, h_blk, h_blk_big;   // host copies kept for build_tiles / the coarsest factorisation
+    std::vector<int> h_rp, h_col, h_blk, h_blk_big;   // host copies kept for build_cc16 / the coarsest factorisation
     void free_all() {
         hipFree(row_ptr); hipFree(col); hipFree(blk_row); hipFree(blk_row_big); hipFree(rows); hipFree(val);
-        for (int k = 0; k < 2; ++k) { hipFree(uc_ptr[k]); hipFree(ucol[k]); hipFree(lcol[k]); uc_ptr[k] = ucol[k] = nullptr; lcol[k] = nullptr; }
         for (int k = 0; k < 2; ++k) { hipFree(segtab[k]); hipFree(ccol[k]); segtab[k] = nullptr; ccol[k] = nullptr; }
         row_ptr = col = blk_row = blk_row_big = rows = nullptr; val = nullptr;
     }
@@ -152,34 +146,6 @@ int build_part(CsrPart &P, const std::vector<int> &rp, const std::vector<int> &c
     CHK(dev_upload(&P.val, val.data(), val.size(), 8));
     CHK(dev_upload(&P.blk_row, blk.data(), blk.size()));
     if (rows) CHK(dev_upload(&P.rows, rows->data(), rows->size()));
-    return SGPU_OK;
-}
-
-// Column tiles of plan k (0: CAP, 1: CAP_BIG): distinct sorted columns per block + 16-bit local ids.
-// Fails softly (tile_ok stays false) when a block holds a row longer than the tile.
-int build_tiles(CsrPart &P, int k) {
-    if (P.tile_ok[k] || P.h_rp.empty()) return SGPU_OK;
-    const std::vector<int> &blk = k ? P.h_blk_big : P.h_blk;
-    const int cap = k ? sk::CAP_BIG : sk::CAP;
-    const int nblk = (int)blk.size() - 1;
-    std::vector<int> ucp((size_t)nblk + 1, 0), ucol;
-    std::vector<unsigned short> lcol(P.h_col.size() + 8, 0);
-    std::vector<int> tmp;
-    for (int b = 0; b < nblk; ++b) {
-        const int p0 = P.h_rp[blk[b]], p1 = P.h_rp[blk[b + 1]];
-        if (p1 - p0 > cap) return SGPU_OK;                       // long row: this plan cannot be tiled
-        tmp.assign(P.h_col.begin() + p0, P.h_col.begin() + p1);
-        std::sort(tmp.begin(), tmp.end());
-        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-        for (int p = p0; p < p1; ++p)
-            lcol[p] = (unsigned short)(std::lower_bound(tmp.begin(), tmp.end(), P.h_col[p]) - tmp.begin());
-        ucol.insert(ucol.end(), tmp.begin(), tmp.end());
-        ucp[b + 1] = (int)ucol.size();
-    }
-    CHK(dev_upload(&P.uc_ptr[k], ucp.data(), ucp.size()));
-    CHK(dev_upload(&P.ucol[k], ucol.data(), ucol.size(), 8));
-    CHK(dev_upload(&P.lcol[k], lcol.data(), lcol.size()));
-    P.tile_ok[k] = true;
     return SGPU_OK;
 }
 
@@ -239,38 +205,35 @@ namespace {
 using KernelFn = void (*)(const sk::SpmvArgs);
 using VecKernelFn = void (*)(const sk::SpmvArgs, int);
 
-template <int EPI, int CAPV, int P1>
+// kernel family F: 0 k_csr_stream, 1 k_csr_cc16
+template <int F, int EPI, int CAPV, int G>
+constexpr KernelFn kernel_of() {
+    if constexpr (F == 0) return sk::k_csr_stream<EPI, G, CAPV>;
+    else return sk::k_csr_cc16<EPI, G, CAPV>;
+}
+template <int F, int EPI, int CAPV>
 KernelFn pick_g(int lanes) {
     switch (lanes) {
-        case 1:  return sk::k_csr_stream<EPI, 1, CAPV, P1>;
-        case 2:  return sk::k_csr_stream<EPI, 2, CAPV, P1>;
-        case 4:  return sk::k_csr_stream<EPI, 4, CAPV, P1>;
-        case 8:  return sk::k_csr_stream<EPI, 8, CAPV, P1>;
-        case 16: return sk::k_csr_stream<EPI, 16, CAPV, P1>;
-        case 32: return sk::k_csr_stream<EPI, 32, CAPV, P1>;
-        default: return sk::k_csr_stream<EPI, 64, CAPV, P1>;
+        case 1:  return kernel_of<F, EPI, CAPV, 1>();
+        case 2:  return kernel_of<F, EPI, CAPV, 2>();
+        case 4:  return kernel_of<F, EPI, CAPV, 4>();
+        case 8:  return kernel_of<F, EPI, CAPV, 8>();
+        case 16: return kernel_of<F, EPI, CAPV, 16>();
+        case 32: return kernel_of<F, EPI, CAPV, 32>();
+        default: return kernel_of<F, EPI, CAPV, 64>();
     }
 }
-template <int EPI>
-KernelFn pick_v(int lanes, int variant) {
-    switch (variant) {
-        case 1:  return pick_g<EPI, sk::CAP, 1>(lanes);
-        case 2:  return pick_g<EPI, sk::CAP_BIG, 1>(lanes);
-        case 4:  return pick_g<EPI, sk::CAP, 2>(lanes);
-        case 5:  return pick_g<EPI, sk::CAP, 3>(lanes);
-        case 6:  return pick_g<EPI, sk::CAP_BIG, 2>(lanes);
-        case 7:  return pick_g<EPI, sk::CAP_BIG, 3>(lanes);
-        default: return pick_g<EPI, sk::CAP, 0>(lanes);
-    }
-}
-KernelFn pick(int epi, int lanes, int variant) {
+template <int F, int EPI>
+KernelFn pick_cap(int lanes, bool big) { return big ? pick_g<F, EPI, sk::CAP_BIG>(lanes) : pick_g<F, EPI, sk::CAP>(lanes); }
+template <int F>
+KernelFn pick(int epi, int lanes, bool big) {
     switch (epi) {
-        case sk::EPI_SPMV:     return pick_v<sk::EPI_SPMV>(lanes, variant);
-        case sk::EPI_RESIDUAL: return pick_v<sk::EPI_RESIDUAL>(lanes, variant);
-        case sk::EPI_JACOBI:   return pick_v<sk::EPI_JACOBI>(lanes, variant);
-        case sk::EPI_CHEBY0:   return pick_v<sk::EPI_CHEBY0>(lanes, variant);
-        case sk::EPI_CHEBYK:   return pick_v<sk::EPI_CHEBYK>(lanes, variant);
-        default:               return pick_v<sk::EPI_SUB>(lanes, variant);
+        case sk::EPI_SPMV:     return pick_cap<F, sk::EPI_SPMV>(lanes, big);
+        case sk::EPI_RESIDUAL: return pick_cap<F, sk::EPI_RESIDUAL>(lanes, big);
+        case sk::EPI_JACOBI:   return pick_cap<F, sk::EPI_JACOBI>(lanes, big);
+        case sk::EPI_CHEBY0:   return pick_cap<F, sk::EPI_CHEBY0>(lanes, big);
+        case sk::EPI_CHEBYK:   return pick_cap<F, sk::EPI_CHEBYK>(lanes, big);
+        default:               return pick_cap<F, sk::EPI_SUB>(lanes, big);
     }
 }
 template <int EPI>
@@ -284,54 +247,6 @@ VecKernelFn pick_vec_g(int lanes) {
         case 32: return sk::k_csr_vector<EPI, 32>;
         default: return sk::k_csr_vector<EPI, 64>;
     }
-}
-template <int EPI, int CAPV>
-KernelFn pick_tile_g(int lanes) {
-    switch (lanes) {
-        case 1:  return sk::k_csr_tile<EPI, 1, CAPV>;
-        case 2:  return sk::k_csr_tile<EPI, 2, CAPV>;
-        case 4:  return sk::k_csr_tile<EPI, 4, CAPV>;
-        case 8:  return sk::k_csr_tile<EPI, 8, CAPV>;
-        case 16: return sk::k_csr_tile<EPI, 16, CAPV>;
-        case 32: return sk::k_csr_tile<EPI, 32, CAPV>;
-        default: return sk::k_csr_tile<EPI, 64, CAPV>;
-    }
-}
-template <int EPI, int CAPV>
-KernelFn pick_cc_g(int lanes) {
-    switch (lanes) {
-        case 1:  return sk::k_csr_cc16<EPI, 1, CAPV>;
-        case 2:  return sk::k_csr_cc16<EPI, 2, CAPV>;
-        case 4:  return sk::k_csr_cc16<EPI, 4, CAPV>;
-        case 8:  return sk::k_csr_cc16<EPI, 8, CAPV>;
-        case 16: return sk::k_csr_cc16<EPI, 16, CAPV>;
-        case 32: return sk::k_csr_cc16<EPI, 32, CAPV>;
-        default: return sk::k_csr_cc16<EPI, 64, CAPV>;
-    }
-}
-KernelFn pick_cc(int epi, int lanes, bool big) {
-#define SGPU_CC_CASE(E) case E: return big ? pick_cc_g<E, sk::CAP_BIG>(lanes) : pick_cc_g<E, sk::CAP>(lanes)
-    switch (epi) {
-        SGPU_CC_CASE(sk::EPI_SPMV);
-        SGPU_CC_CASE(sk::EPI_RESIDUAL);
-        SGPU_CC_CASE(sk::EPI_JACOBI);
-        SGPU_CC_CASE(sk::EPI_CHEBY0);
-        SGPU_CC_CASE(sk::EPI_CHEBYK);
-        default: return big ? pick_cc_g<sk::EPI_SUB, sk::CAP_BIG>(lanes) : pick_cc_g<sk::EPI_SUB, sk::CAP>(lanes);
-    }
-#undef SGPU_CC_CASE
-}
-KernelFn pick_tile(int epi, int lanes, bool big) {
-#define SGPU_TILE_CASE(E) case E: return big ? pick_tile_g<E, sk::CAP_BIG>(lanes) : pick_tile_g<E, sk::CAP>(lanes)
-    switch (epi) {
-        SGPU_TILE_CASE(sk::EPI_SPMV);
-        SGPU_TILE_CASE(sk::EPI_RESIDUAL);
-        SGPU_TILE_CASE(sk::EPI_JACOBI);
-        SGPU_TILE_CASE(sk::EPI_CHEBY0);
-        SGPU_TILE_CASE(sk::EPI_CHEBYK);
-        default: return big ? pick_tile_g<sk::EPI_SUB, sk::CAP_BIG>(lanes) : pick_tile_g<sk::EPI_SUB, sk::CAP>(lanes);
-    }
-#undef SGPU_TILE_CASE
 }
 VecKernelFn pick_vec(int epi, int lanes) {
     switch (epi) {
@@ -356,30 +271,23 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.row_ptr = P.row_ptr; a.col = P.col; a.val = P.val;
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
     a.c0 = e.c0; a.c1 = e.c1; a.rows = P.rows;
-    a.uc_ptr = nullptr; a.ucol = nullptr; a.lcol = nullptr; a.segtab = nullptr; a.ccol = nullptr;
-    if (P.variant == 10 || P.variant == 11) {
-        const int k = P.variant - 10;
+    a.segtab = nullptr; a.ccol = nullptr;
+    if (P.variant == 3 || P.variant == 4) {                       // 16-bit compressed columns
+        const int k = P.variant - 3;
         if (!P.cc_ok[k]) return fail(SGPU_ERR_STATE, "compressed columns of plan %d were not built", k);
         a.blk_row = k ? P.blk_row_big : P.blk_row;
         a.nblk = k ? P.nblk_big : P.nblk;
         a.segtab = P.segtab[k]; a.ccol = P.ccol[k];
-        hipLaunchKernelGGL(pick_cc(epi, P.lanes, k == 1), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
-    } else if (P.variant == 8 || P.variant == 9) {
-        const int k = P.variant - 8;
-        if (!P.tile_ok[k]) return fail(SGPU_ERR_STATE, "column tiles of plan %d were not built", k);
-        a.blk_row = k ? P.blk_row_big : P.blk_row;
-        a.nblk = k ? P.nblk_big : P.nblk;
-        a.uc_ptr = P.uc_ptr[k]; a.ucol = P.ucol[k]; a.lcol = P.lcol[k];
-        hipLaunchKernelGGL(pick_tile(epi, P.lanes, k == 1), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
-    } else if (P.variant == 3) {
+        hipLaunchKernelGGL(pick<1>(epi, P.lanes, k == 1), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+    } else if (P.variant == 2) {                                  // vector CSR
         const int rpb = sk::BLOCK / P.lanes;
         a.blk_row = nullptr; a.nblk = 0;
         hipLaunchKernelGGL(pick_vec(epi, P.lanes), dim3((P.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
-    } else {
-        const bool big = P.variant == 2 || P.variant == 6 || P.variant == 7;
+    } else {                                                      // 32-bit columns, 16 / 32 KiB tiles
+        const bool big = P.variant == 1;
         a.blk_row = big ? P.blk_row_big : P.blk_row;
         a.nblk = big ? P.nblk_big : P.nblk;
-        hipLaunchKernelGGL(pick(epi, P.lanes, P.variant), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+        hipLaunchKernelGGL(pick<0>(epi, P.lanes, big), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
     }
     HIPCHK(hipGetLastError());
     return SGPU_OK;
@@ -743,9 +651,7 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<16KiB,hoisted>", "k_csr_stream<32KiB,hoisted>", "k_csr_vector",
-                                  "k_csr_stream<16KiB,pair>", "k_csr_stream<16KiB,single>", "k_csr_stream<32KiB,pair>", "k_csr_stream<32KiB,single>",
-                                  "k_csr_tile<16KiB>", "k_csr_tile<32KiB>", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>"};
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>"};
     if (variant) *variant = op->loc.variant;
     if (kernel_name) *kernel_name = names[op->loc.variant];
     return SGPU_OK;
@@ -753,13 +659,10 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 11) return fail(SGPU_ERR_ARG, "variant must be 0..11");
-    if (variant >= 10) {
-        CHK(build_cc16(op->loc, variant - 10));
-        if (!op->loc.cc_ok[variant - 10]) return fail(SGPU_ERR_ARG, "this operator's blocks touch more than 16 column segments (or hold a long row)");
-    } else if (variant >= 8) {
-        CHK(build_tiles(op->loc, variant - 8));
-        if (!op->loc.tile_ok[variant - 8]) return fail(SGPU_ERR_ARG, "this operator has rows longer than the column tile");
+    if (variant < 0 || variant > 4) return fail(SGPU_ERR_ARG, "variant must be 0..4");
+    if (variant >= 3) {
+        CHK(build_cc16(op->loc, variant - 3));
+        if (!op->loc.cc_ok[variant - 3]) return fail(SGPU_ERR_ARG, "this operator's blocks touch more than 16 column segments (or hold a long row)");
     }
     op->loc.variant = variant;
     return SGPU_OK;
@@ -781,8 +684,8 @@ int sgpu_op_autotune(sgpu_op *op) {
     const int kind = op->inv_diag ? 1 : 0;
     float best = 1e30f;
     int bv = 0, bg = g0;
-    std::vector<int> variants = {0, 2, 3};
-    for (int k = 0; k < 2; ++k) { CHK(build_cc16(op->loc, k)); if (op->loc.cc_ok[k]) variants.push_back(10 + k); }
+    std::vector<int> variants = {0, 1, 2};
+    for (int k = 0; k < 2; ++k) { CHK(build_cc16(op->loc, k)); if (op->loc.cc_ok[k]) variants.push_back(3 + k); }
     // Only the LOCAL part is timed, without the halo exchange: ranks may end up with different candidate
     // lists (a rank's blocks may be too scattered for 16-bit columns), so no collective may run in here.
     EpiArgs e; e.rhs = r.p; e.inv_diag = op->inv_diag; e.u = x.p; e.c0 = JACOBI_OMEGA_REF;
@@ -806,7 +709,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     hipEventDestroy(e0); hipEventDestroy(e1);
     op->loc.variant = bv; op->loc.lanes = bg;
     for (int k = 0; k < 2; ++k)                       // free the compressed arrays of the plans that lost
-        if (op->loc.cc_ok[k] && bv != 10 + k) {
+        if (op->loc.cc_ok[k] && bv != 3 + k) {
             hipFree(op->loc.segtab[k]); hipFree(op->loc.ccol[k]);
             op->loc.segtab[k] = nullptr; op->loc.ccol[k] = nullptr; op->loc.cc_ok[k] = false;
         }

@@ -38,7 +38,7 @@ def main():
                                inv_diag=lay["inv_diag"])
             B = op.algorithmic_bytes(1)
             line = f"L{lvl} {name:22s}:"
-            for v, g in ((0, 4), (0, 8), (2, 8), (2, 16)):
+            for v, g in ((0, 4), (0, 8), (1, 8), (1, 16)):
                 op.set_variant(v); op.set_lanes_per_row(g)
                 op.time_kernel(1, x, rhs, y, 3)
                 us = min(op.time_kernel(1, x, rhs, y, 20) for _ in range(2)) * 1e3

@@ -109,17 +109,17 @@ def test_spmv_lane_variants(capi, name, lanes):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_kernel_variants(capi, name, variant):
-    """hoisted-load / 32 KiB / vector-CSR variants of the local kernel: same results"""
+    """32 KiB tiles / vector CSR / 16-bit compressed columns (16 and 32 KiB): same results as the default kernel"""
     entries, M = get_problem(name)
     A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
     G = util.gpu_operator(A)
-    if variant >= 8:
+    if variant >= 3:
         try:
             G.set_variant(variant)
         except capi.SgpuError:
-            # refused, not mis-computed: rows longer than the tile, or (16-bit columns) blocks touching > 16 segments
+            # refused, not mis-computed: rows longer than the tile, or blocks touching > 16 column segments
             assert name in ("band3000_1400", "irregular5000")
             return
     else:
@@ -131,7 +131,7 @@ def test_kernel_variants(capi, name, variant):
         G.set_lanes_per_row(lanes)
         G.spmv(dx, dy)
         got, want = dy.download(), A.matvec(x)
-        if lanes == 1 and variant != 3 and (name != "band3000_1400" or variant in (9, 11)):
+        if lanes == 1 and variant != 2 and (name != "band3000_1400" or variant in (1, 4)):
             np.testing.assert_array_equal(got, want)          # stream variants keep the sequential row sum
         else:
             assert np.all(np.abs(got - want) <= TOL_SPMV * bound + 1e-300)
