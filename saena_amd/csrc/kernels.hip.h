@@ -134,7 +134,7 @@ __device__ __forceinline__ double group_sum(double v) {
 // A row block with a single row longer than CAPV takes the long-row path.
 // CAPV = products staged per block (LDS = 8 CAPV bytes).
 // Measured and dropped (profiles/r01_variant_sweep_128*.log): issuing every load of the block
-// before the first gather (no gain), 1- or 2-nnz lane ownership (more VMEM instructions, -10..-35 %),
+// before the first gather on 16 KiB tiles (no gain there; kept for 32 KiB tiles), 1- or 2-nnz lane ownership (more VMEM instructions, -10..-35 %),
 // staging the block's distinct x columns in LDS (two barriers + 32 KiB LDS, -40 % on the 67-nnz/row level).
 template <int EPI, int G, int CAPV>
 __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
@@ -165,21 +165,60 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
     const int a0 = p0 & ~3;
     const int nq = (p1 - a0 + 3) >> 2;                // quads of 4 nnz
     constexpr int ITER = (LDSN / 4 + BLOCK - 1) / BLOCK;
+    if constexpr (CAPV <= CAP) {
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int q = tid + it * BLOCK;
-        if (q < nq) {
+        for (int it = 0; it < ITER; ++it) {
+            const int q = tid + it * BLOCK;
+            if (q < nq) {
+                const int idx = a0 + 4 * q;
+                const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
+                const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
+                const int4    c   = *reinterpret_cast<const int4 *>(a.col + idx);
+                double2 o01, o23;
+                o01.x = v01.x * a.x[c.x];
+                o01.y = v01.y * a.x[c.y];
+                o23.x = v23.x * a.x[c.z];
+                o23.y = v23.y * a.x[c.w];
+                *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
+                *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
+            }
+        }
+    } else {
+        // 32 KiB tiles run 5 blocks per CU: to keep enough bytes in flight every val/col load of the block is
+        // issued before the first gather (out-of-range lanes re-read the last quad; the arrays are padded).
+        // Measured on the 263-nnz/row level of the 256^3 hierarchy (2.4 GB, HBM-resident): 838 -> 647 us.
+        double2 v01[ITER], v23[ITER];
+        int4    c[ITER];
+        const int qlast = nq > 0 ? nq - 1 : 0;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            int q = tid + it * BLOCK;
+            q = q < qlast ? q : qlast;
             const int idx = a0 + 4 * q;
-            const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
-            const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
-            const int4    c   = *reinterpret_cast<const int4 *>(a.col + idx);
-            double2 o01, o23;
-            o01.x = v01.x * a.x[c.x];
-            o01.y = v01.y * a.x[c.y];
-            o23.x = v23.x * a.x[c.z];
-            o23.y = v23.y * a.x[c.w];
-            *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
-            *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
+            v01[it] = *reinterpret_cast<const double2 *>(a.val + idx);
+            v23[it] = *reinterpret_cast<const double2 *>(a.val + idx + 2);
+            c[it]   = *reinterpret_cast<const int4 *>(a.col + idx);
+        }
+        double2 o01[ITER], o23[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            o01[it].x = a.x[c[it].x];
+            o01[it].y = a.x[c[it].y];
+            o23[it].x = a.x[c[it].z];
+            o23[it].y = a.x[c[it].w];
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int q = tid + it * BLOCK;
+            if (q < nq) {
+                double2 w01, w23;
+                w01.x = v01[it].x * o01[it].x;
+                w01.y = v01[it].y * o01[it].y;
+                w23.x = v23[it].x * o23[it].x;
+                w23.y = v23[it].y * o23[it].y;
+                *reinterpret_cast<double2 *>(&lds[4 * q])     = w01;
+                *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = w23;
+            }
         }
     }
     __syncthreads();
@@ -220,22 +259,59 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
     const int a0 = p0 & ~3;
     const int nq = (p1 - a0 + 3) >> 2;
     constexpr int ITER = (LDSN / 4 + BLOCK - 1) / BLOCK;
+    if constexpr (CAPV <= CAP) {
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int q = tid + it * BLOCK;
-        if (q < nq) {
+        for (int it = 0; it < ITER; ++it) {
+            const int q = tid + it * BLOCK;
+            if (q < nq) {
+                const int idx = a0 + 4 * q;
+                const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
+                const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
+                const uint2   c   = *reinterpret_cast<const uint2 *>(a.ccol + idx);
+                const unsigned c0 = c.x & 0xffffu, c1 = c.x >> 16, c2 = c.y & 0xffffu, c3 = c.y >> 16;
+                double2 o01, o23;
+                o01.x = v01.x * a.x[seg[c0 >> 12] + (int)(c0 & 4095u)];
+                o01.y = v01.y * a.x[seg[c1 >> 12] + (int)(c1 & 4095u)];
+                o23.x = v23.x * a.x[seg[c2 >> 12] + (int)(c2 & 4095u)];
+                o23.y = v23.y * a.x[seg[c3 >> 12] + (int)(c3 & 4095u)];
+                *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
+                *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
+            }
+        }
+    } else {                                          // 32 KiB tiles: all stream loads first (see k_csr_stream)
+        double2 v01[ITER], v23[ITER];
+        uint2   c[ITER];
+        const int qlast = nq > 0 ? nq - 1 : 0;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            int q = tid + it * BLOCK;
+            q = q < qlast ? q : qlast;
             const int idx = a0 + 4 * q;
-            const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
-            const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
-            const uint2   c   = *reinterpret_cast<const uint2 *>(a.ccol + idx);
-            const unsigned c0 = c.x & 0xffffu, c1 = c.x >> 16, c2 = c.y & 0xffffu, c3 = c.y >> 16;
-            double2 o01, o23;
-            o01.x = v01.x * a.x[seg[c0 >> 12] + (int)(c0 & 4095u)];
-            o01.y = v01.y * a.x[seg[c1 >> 12] + (int)(c1 & 4095u)];
-            o23.x = v23.x * a.x[seg[c2 >> 12] + (int)(c2 & 4095u)];
-            o23.y = v23.y * a.x[seg[c3 >> 12] + (int)(c3 & 4095u)];
-            *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
-            *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
+            v01[it] = *reinterpret_cast<const double2 *>(a.val + idx);
+            v23[it] = *reinterpret_cast<const double2 *>(a.val + idx + 2);
+            c[it]   = *reinterpret_cast<const uint2 *>(a.ccol + idx);
+        }
+        double2 o01[ITER], o23[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const unsigned c0 = c[it].x & 0xffffu, c1 = c[it].x >> 16, c2 = c[it].y & 0xffffu, c3 = c[it].y >> 16;
+            o01[it].x = a.x[seg[c0 >> 12] + (int)(c0 & 4095u)];
+            o01[it].y = a.x[seg[c1 >> 12] + (int)(c1 & 4095u)];
+            o23[it].x = a.x[seg[c2 >> 12] + (int)(c2 & 4095u)];
+            o23[it].y = a.x[seg[c3 >> 12] + (int)(c3 & 4095u)];
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int q = tid + it * BLOCK;
+            if (q < nq) {
+                double2 w01, w23;
+                w01.x = v01[it].x * o01[it].x;
+                w01.y = v01[it].y * o01[it].y;
+                w23.x = v23[it].x * o23[it].x;
+                w23.y = v23[it].y * o23[it].y;
+                *reinterpret_cast<double2 *>(&lds[4 * q])     = w01;
+                *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = w23;
+            }
         }
     }
     __syncthreads();
