@@ -194,6 +194,7 @@ public:
     // (allocated here when null; free it with saena::free_vector)
     int solve(value_t *&u, saena::options *opts);
     int solve_pCG(value_t *&u, saena::options *opts, bool print_info = true);
+    int solve_CG(value_t *&u, saena::options *opts);          // CG without the multigrid preconditioner
 
     int  set_verbose(bool verb);
     bool verbose = false;
@@ -215,7 +216,7 @@ private:
     bool dynamic_levels_ = true;
     int max_level_override_ = -1;
     void drop_device();
-    int run(value_t *&u, saena::options *opts, bool pcg, bool print_info);
+    int run(value_t *&u, saena::options *opts, int which, bool print_info);   // which: 0 solve, 1 solve_pCG, 2 solve_CG
 };
 
 void free_vector(value_t *u);

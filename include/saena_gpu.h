@@ -193,6 +193,8 @@ int sgpu_vcycle(sgpu_amg *h, value_t *u, const value_t *rhs);
 int sgpu_solve(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *res_hist, int hist_cap);
 /* saena_object::solve_pCG (saena_object_solve.cpp:2389-2801) */
 int sgpu_solve_pCG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *res_hist, int hist_cap);
+/* saena_object::solve_CG (saena_object_solve.cpp:2119-2387): plain CG on A[0], no V-cycle */
+int sgpu_solve_CG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *res_hist, int hist_cap);
 /* solve_coarsest_CG on the last level only (for tests) */
 int sgpu_coarsest_solve(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters);
 

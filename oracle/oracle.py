@@ -113,7 +113,7 @@ def lib():
         L.orc_solve_coarsest_CG.restype = C.c_int
         L.orc_solve_coarsest_CG.argtypes = [C.POINTER(Amg), C.POINTER(Op), _PD, _PD]
         L.orc_vcycle.argtypes = [C.POINTER(Amg), C.POINTER(Grid), _PD, _PD]
-        for f in ("orc_solve", "orc_solve_pCG"):
+        for f in ("orc_solve", "orc_solve_pCG", "orc_solve_CG"):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [C.POINTER(Amg), _PD, _PD, _PD, C.c_int]
         L.orc_time_matvec.restype = C.c_double
@@ -300,3 +300,6 @@ class OracleAmg:
 
     def solve_pCG(self, rhs):
         return self._solve(lib().orc_solve_pCG, rhs)
+
+    def solve_CG(self, rhs, cap=2048):
+        return self._solve(lib().orc_solve_CG, rhs, cap)

@@ -636,6 +636,39 @@ int orc_solve_pCG(const orc_amg *h, value_t *u, const value_t *rhs, double *hist
     return i + 1;
 }
 
+/* saena_object_solve.cpp:2119-2387: solve_pCG with rho := r (no V-cycle) */
+int orc_solve_CG(const orc_amg *h, value_t *u, const value_t *rhs, double *hist, int cap) {
+    orc_op *A = h->grids[0].A;
+    const index_t sz = A->Mbig;
+    const index_t *split = A->split_row; const int np = A->nprocs;
+    for (index_t i = 0; i < sz; ++i) u[i] = 0;
+    value_t *r = xcalloc((size_t)sz, sizeof *r), *hh = xcalloc((size_t)sz, sizeof *hh), *p = xcalloc((size_t)sz, sizeof *p);
+    orc_residual(A, u, rhs, r);
+    const double init_dot = orc_dot(r, r, split, np);
+    double current_dot = init_dot;
+    if (hist && cap > 0) hist[0] = sqrt(init_dot);
+    memcpy(p, r, (size_t)sz * sizeof *p);                 /* rho = r; p = rho */
+    const double THRSHLD = init_dot * h->solver_tol * h->solver_tol;
+    double rho_res = 0.0, pdoth = 0.0, alpha = 0.0, beta = 0.0;
+    int i;
+    for (i = 0; i < h->solver_max_iter; i++) {
+        orc_matvec(A, p, hh);
+        rho_res = orc_dot(r, r, split, np);               /* dotProduct(r, rho) with rho == r */
+        pdoth   = orc_dot(p, hh, split, np);
+        alpha = rho_res / pdoth;
+        for (index_t j = 0; j < sz; ++j) { u[j] -= alpha * p[j]; r[j] -= alpha * hh[j]; }
+        current_dot = orc_dot(r, r, split, np);
+        if (hist && i + 1 < cap) hist[i + 1] = sqrt(current_dot);
+        if (current_dot < THRSHLD) break;
+        beta = orc_dot(r, r, split, np);
+        beta /= rho_res;
+        for (index_t j = 0; j < sz; ++j) p[j] = r[j] + beta * p[j];
+    }
+    if (i == h->solver_max_iter) i--;
+    free(r); free(hh); free(p);
+    return i + 1;
+}
+
 /* ------------------------------------------------------------------ */
 /* threaded baseline: ranks run concurrently, barrier-separated phases  */
 

@@ -161,6 +161,9 @@ int  orc_solve(const orc_amg *h, value_t *u, const value_t *rhs, double *res_his
 /* src/saena_object_solve.cpp:2389-2801 */
 int  orc_solve_pCG(const orc_amg *h, value_t *u, const value_t *rhs, double *res_hist, int hist_cap);
 
+/* src/saena_object_solve.cpp:2119-2387: CG without a preconditioner (rho aliases r) */
+int  orc_solve_CG(const orc_amg *h, value_t *u, const value_t *rhs, double *res_hist, int hist_cap);
+
 /* ---- threaded baseline: run P simulated ranks on P pthreads ---- */
 /* times `reps` matvecs (or jacobi sweeps) with the ranks running
  * concurrently like `mpirun -np P`; returns seconds per repetition. */

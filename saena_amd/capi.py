@@ -84,6 +84,7 @@ SYMBOLS = {
     "sgpu_vcycle": (C.c_int, [_VP, _VP, _VP]),
     "sgpu_solve": (C.c_int, [_VP, _VP, _VP, _PI, _PD, C.c_int]),
     "sgpu_solve_pCG": (C.c_int, [_VP, _VP, _VP, _PI, _PD, C.c_int]),
+    "sgpu_solve_CG": (C.c_int, [_VP, _VP, _VP, _PI, _PD, C.c_int]),
     "sgpu_coarsest_solve": (C.c_int, [_VP, _VP, _VP, _PI]),
     "sgpu_time_kernel": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.POINTER(C.c_float)]),
     "sgpu_algorithmic_bytes": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64)]),
@@ -345,6 +346,9 @@ class Amg:
 
     def solve_pCG(self, u, rhs):
         return self._solve(lib().sgpu_solve_pCG, u, rhs)
+
+    def solve_CG(self, u, rhs):
+        return self._solve(lib().sgpu_solve_CG, u, rhs, cap=2048)
 
     def destroy(self):
         if self.h:

@@ -266,7 +266,7 @@ int amg::set_rhs(const value_t *rhs_local, index_t size) {
     return 0;
 }
 
-int amg::run(value_t *&u, saena::options *opts, bool pcg, bool print_info) {
+int amg::run(value_t *&u, saena::options *opts, int which, bool print_info) {
     if (!damg_) throw std::runtime_error("saena::amg: set_matrix first");
     const size_t n = (size_t)A_->get_num_local_rows();
     if (rhs_.size() != n) throw std::runtime_error("saena::amg: set_rhs first");
@@ -274,11 +274,12 @@ int amg::run(value_t *&u, saena::options *opts, bool pcg, bool print_info) {
     value_t *du = nullptr, *dr = nullptr;
     gchk(sgpu_vec_alloc(&du, n), "alloc"); gchk(sgpu_vec_alloc(&dr, n), "alloc");
     gchk(sgpu_vec_upload(dr, rhs_.data(), n), "upload");
-    hist_.assign(1024, 0.0);
-    int st = pcg ? sgpu_solve_pCG(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size())
-                 : sgpu_solve(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size());
+    hist_.assign(4096, 0.0);
+    int st = which == 1 ? sgpu_solve_pCG(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size())
+           : which == 2 ? sgpu_solve_CG(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size())
+                        : sgpu_solve(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size());
     if (st != SGPU_OK && st != SGPU_ERR_NOCONV) { sgpu_vec_free(du); sgpu_vec_free(dr); gchk(st, "solve"); }
-    hist_.resize((size_t)std::min<int>(iters_ + 1, 1024));
+    hist_.resize((size_t)std::min<int>(iters_ + 1, 4096));
     if (!u) u = static_cast<value_t *>(std::malloc(std::max<size_t>(1, n) * sizeof(value_t)));   // saena_aligned_alloc in the reference
     gchk(sgpu_vec_download(u, du, n), "download");
     sgpu_vec_free(du); sgpu_vec_free(dr);
@@ -289,8 +290,9 @@ int amg::run(value_t *&u, saena::options *opts, bool pcg, bool print_info) {
     }
     return st == SGPU_OK ? 0 : 1;
 }
-int amg::solve(value_t *&u, saena::options *opts) { return run(u, opts, false, true); }
-int amg::solve_pCG(value_t *&u, saena::options *opts, bool print_info) { return run(u, opts, true, print_info); }
+int amg::solve(value_t *&u, saena::options *opts) { return run(u, opts, 0, true); }
+int amg::solve_pCG(value_t *&u, saena::options *opts, bool print_info) { return run(u, opts, 1, print_info); }
+int amg::solve_CG(value_t *&u, saena::options *opts) { return run(u, opts, 2, true); }
 
 void free_vector(value_t *u) { std::free(u); }
 

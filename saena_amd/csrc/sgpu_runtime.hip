@@ -1141,6 +1141,41 @@ int sgpu_solve_pCG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, valu
     return conv ? SGPU_OK : SGPU_ERR_NOCONV;
 }
 
+// saena_object::solve_CG (src/saena_object_solve.cpp:2119-2387): CG without a preconditioner (rho aliases r)
+int sgpu_solve_CG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *hist, int cap) {
+    CHK(need_ctx());
+    if (!h || !u || !rhs) return fail(SGPU_ERR_ARG, "null argument");
+    sgpu_op *A = h->A[0];
+    const size_t sz = (size_t)A->M;
+    double *r = h->r, *hh = h->hh, *p = h->p;
+    CHK(sgpu_vec_fill(u, 0.0, sz));
+    CHK(sgpu_residual(A, u, rhs, r));
+    double init_dot = 0, current_dot = 0, rho_res = 0, pdoth = 0, beta = 0;
+    CHK(sgpu_dot(r, r, sz, &init_dot));
+    if (hist && cap > 0) hist[0] = std::sqrt(init_dot);
+    CHK(sgpu_vec_copy(p, r, sz));
+    const double THRSHLD = init_dot * h->prm.solver_tol * h->prm.solver_tol;
+    current_dot = init_dot;
+    int i = 0;
+    for (i = 0; i < h->prm.solver_max_iter; i++) {
+        CHK(sgpu_spmv(A, p, hh));
+        CHK(sgpu_dot(r, r, sz, &rho_res));
+        CHK(sgpu_dot(p, hh, sz, &pdoth));
+        const double alpha = rho_res / pdoth;
+        hipLaunchKernelGGL(sk::k_pcg_update, dim3(grid_for(2 * sz)), dim3(sk::BLOCK), 0, g.cs, alpha, p, hh, u, r, sz);
+        HIPCHK(hipGetLastError());
+        CHK(sgpu_dot(r, r, sz, &current_dot));
+        if (hist && i + 1 < cap) hist[i + 1] = std::sqrt(current_dot);
+        if (current_dot < THRSHLD) break;
+        beta = current_dot / rho_res;
+        CHK(sgpu_vec_axpby(1.0, r, beta, p, sz));
+    }
+    const bool conv = current_dot < THRSHLD;
+    if (i == h->prm.solver_max_iter) i--;
+    if (iters) *iters = i + 1;
+    return conv ? SGPU_OK : SGPU_ERR_NOCONV;
+}
+
 // ---- measurement ----
 int sgpu_algorithmic_bytes(const sgpu_op *op, int kind, int64_t *bytes) {
     if (!op || !bytes) return fail(SGPU_ERR_ARG, "null argument");

@@ -123,6 +123,20 @@ def test_graph_replay_equals_eager(capi, hier, smoother):
         np.testing.assert_array_equal(dug.download(), due.download())
 
 
+def test_plain_cg(capi, hier):
+    """saena::amg::solve_CG: CG without the V-cycle (rho aliases r); same iteration count and residuals as the oracle"""
+    O, G, (OA, _, _), _ = build(capi, hier, "jacobi", max_iter=400)
+    n = OA[0].Mbig
+    rhs = inputs.rhs2(n)             # (the Poisson rhs is an eigenvector of the stencil: CG would stop after one step)
+    du, dr = capi.DeviceVector(n), capi.DeviceVector(n, rhs)
+    u_o, it_o, hist_o = O.solve_CG(rhs)
+    it_g, hist_g, conv = G.solve_CG(du, dr)
+    assert conv and abs(it_g - it_o) <= 1 and it_g > 10
+    m_ = min(len(hist_g), len(hist_o)) - 1
+    assert np.all(np.abs(hist_g[:m_] - hist_o[:m_]) <= 1e-8 * hist_o[0])
+    assert rel(du.download(), u_o) <= 1e-7
+
+
 def test_two_level_and_single_level(capi):
     """max_level = 1 and max_level = 0 (`only using the direct solver`, saena_object_solve.cpp:2504-2520)"""
     As, Ps, Rs = hierarchy.poisson_hierarchy(8, 2)       # 216 -> 27
