@@ -157,6 +157,9 @@ int sgpu_chebyshev_host(sgpu_op *op, int iter, value_t eig_max, value_t *u_host,
  * buffer and makes the following applies use the remote part without any
  * exchange.  Tests route the buffers between operators on the host. */
 int sgpu_debug_pack(sgpu_op *op, const value_t *v, value_t *send_host);
+/* diagnostic: time of the x[col] gather alone over the local part, mode 0 = production lane mapping (4 consecutive
+ * nnz per lane), 1 = 64 consecutive nnz per gather instruction */
+int sgpu_debug_gather_probe(sgpu_op *op, int mode, const value_t *x, int reps, float *ms);
 int sgpu_debug_inject_halo(sgpu_op *op, const value_t *recv_host);
 
 /* ---- multigrid hierarchy --------------------------------------------------

@@ -74,6 +74,7 @@ SYMBOLS = {
     "sgpu_chebyshev": (C.c_int, [_VP, C.c_int, C.c_double, _VP, _VP]),
     "sgpu_prolong_correct": (C.c_int, [_VP, _VP, _VP]),
     "sgpu_debug_pack": (C.c_int, [_VP, _VP, _PD]),
+    "sgpu_debug_gather_probe": (C.c_int, [_VP, C.c_int, _VP, C.c_int, C.POINTER(C.c_float)]),
     "sgpu_debug_inject_halo": (C.c_int, [_VP, _PD]),
     "sgpu_spmv_host": (C.c_int, [_VP, _PD, _PD]),
     "sgpu_jacobi_host": (C.c_int, [_VP, C.c_int, C.c_double, _PD, _PD]),
@@ -263,6 +264,11 @@ class Operator:
 
     def prolong_correct(self, e_coarse, u):
         check(lib().sgpu_prolong_correct(self.h, e_coarse.ptr, u.ptr))
+
+    def debug_gather_probe(self, mode, x, reps=20):
+        ms = C.c_float()
+        check(lib().sgpu_debug_gather_probe(self.h, mode, x.ptr, reps, C.byref(ms)))
+        return ms.value
 
     def debug_pack(self, v, n_send):
         out = np.empty(n_send)

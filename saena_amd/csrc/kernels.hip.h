@@ -135,7 +135,8 @@ __device__ __forceinline__ double group_sum(double v) {
 // CAPV = products staged per block (LDS = 8 CAPV bytes).
 // Measured and dropped (profiles/r01_variant_sweep_128*.log): issuing every load of the block
 // before the first gather on 16 KiB tiles (no gain there; kept for 32 KiB tiles), 1- or 2-nnz lane ownership (more VMEM instructions, -10..-35 %),
-// staging the block's distinct x columns in LDS (two barriers + 32 KiB LDS, -40 % on the 67-nnz/row level).
+// staging the block's distinct x columns in LDS (-40 % with 16/32 KiB tiles, -22 % with 1024-product tiles and
+// 16-bit ids on the 67-nnz/row level: the extra dependent phase costs more than the saved gather lanes).
 template <int EPI, int G, int CAPV>
 __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
     constexpr int LDSN = CAPV + 8;
@@ -520,6 +521,24 @@ __global__ __launch_bounds__(CG_BLOCK) void k_coarse_cg(const CoarseCGArgs a) {
     for (int j = tid; j < n; j += CG_BLOCK) a.u[j] = uu[j];
     if (i == max_iter && max_iter != 0) i--;
     if (tid == 0 && a.iters_out) *a.iters_out = i;
+}
+
+// Diagnostic (not on any product path): cost of the x[col] gather alone under two lane->nnz mappings.
+// mode 0: a lane owns 4 consecutive nnz (the production mapping; one gather instruction = a stride-4 comb
+// over 256 nnz); mode 1: lane l of a wave takes nnz base + e*64 + l (one instruction = 64 consecutive nnz).
+// Measured on the 67-nnz/row level of the 128^3 hierarchy: 150 us / 134 us for the gather alone, while the whole
+// operator streams in ~115 us: the texture addresser retires about one scattered 8-byte lane per clock per CU.
+__global__ __launch_bounds__(BLOCK) void k_gather_probe(const int *__restrict__ col, const double *__restrict__ x,
+                                                        double *__restrict__ out, long nnz, int mode) {
+    const long chunk = (long)blockIdx.x * (BLOCK * 4);          // 1024 nnz per block
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long k = mode == 0 ? chunk + 4L * tid + e : chunk + 256L * wave + 64L * e + lane;
+        if (k < nnz) s += x[col[k]];
+    }
+    if (s == 1.2345e-300) out[0] = s;
 }
 
 // Coarsest-level direct solve: u = Ainv rhs with the dense inverse computed once on the host

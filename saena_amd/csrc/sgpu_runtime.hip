@@ -767,6 +767,24 @@ int sgpu_debug_pack(sgpu_op *op, const value_t *v, value_t *send_host) {
     return sgpu_vec_download(send_host, op->send_buf, (size_t)op->vIndexSize);
 }
 
+int sgpu_debug_gather_probe(sgpu_op *op, int mode, const value_t *x, int reps, float *ms) {
+    CHK(need_ctx());
+    if (!op || !x || !ms || reps < 1) return fail(SGPU_ERR_ARG, "bad argument");
+    const long nnz = op->loc.nnz;
+    const int grid = (int)((nnz + sk::BLOCK * 4 - 1) / (sk::BLOCK * 4));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g.cs));
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(sk::k_gather_probe, dim3(grid), dim3(sk::BLOCK), 0, g.cs, op->loc.col, x, g.dscalar, nnz, mode);
+    HIPCHK(hipEventRecord(e1, g.cs));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    *ms /= reps;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return SGPU_OK;
+}
+
 int sgpu_debug_inject_halo(sgpu_op *op, const value_t *recv_host) {
     CHK(need_ctx());
     if (!op) return fail(SGPU_ERR_ARG, "null argument");

@@ -33,6 +33,11 @@ def main():
         order = np.lexsort((rnd, rows))
         variants["sorted random"] = rnd[order]
         x, y, rhs = capi.DeviceVector(M, np.ones(M)), capi.DeviceVector(M), capi.DeviceVector(M, np.ones(M))
+        opr = S.to_device().device_op(lvl, 0) if lvl == 1 else S.device_op(lvl, 0)
+        for mode in (0, 1):
+            opr.debug_gather_probe(mode, x, 3)
+            print(f"L{lvl} gather only, mode {mode} ({'4 consecutive nnz per lane' if mode == 0 else '64 consecutive nnz per instruction'}): "
+                  f"{opr.debug_gather_probe(mode, x, 20) * 1e3:.1f} us", flush=True)
         for name, col in variants.items():
             op = capi.Operator(M=M, N_local=M, col_offset=0, nnzPerRow_local=npr, col_local=col, val_local=lay["val_local"],
                                inv_diag=lay["inv_diag"])
