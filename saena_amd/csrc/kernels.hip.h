@@ -136,7 +136,9 @@ __device__ __forceinline__ double group_sum(double v) {
 // Measured and dropped (profiles/r01_variant_sweep_128*.log): issuing every load of the block
 // before the first gather on 16 KiB tiles (no gain there; kept for 32 KiB tiles), 1- or 2-nnz lane ownership (more VMEM instructions, -10..-35 %),
 // staging the block's distinct x columns in LDS (-40 % with 16/32 KiB tiles, -22 % with 1024-product tiles and
-// 16-bit ids on the 67-nnz/row level: the extra dependent phase costs more than the saved gather lanes).
+// 16-bit ids on the 67-nnz/row level: the extra dependent phase costs more than the saved gather lanes), and a
+// persistent workgroup that prefetches the next block's stream during the reduce (-20 %: eight independent
+// one-shot blocks per CU overlap better than a hand-pipelined loop with two barriers per block).
 template <int EPI, int G, int CAPV>
 __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
     constexpr int LDSN = CAPV + 8;
