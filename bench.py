@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--m", type=int, default=128, help="grid points per side (reference laplacian3D argument)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
+    ap.add_argument("--vcycle-timeout", type=float, default=300.0, help="watchdog of the multi-rank V-cycle leg, seconds")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -62,12 +63,19 @@ def cpu_baseline(m, seconds):
                       f"(oracle/saena_oracle.c, -O2), {t * 1e3:.3f} ms each"}
 
 
-def vcycle_leg(capi, host, A, m):
+def vcycle_leg(capi, host, A, m, dist=None):
     """Second half of BASELINE.json's metric: V-cycle iterations/s of solve_pCG (options001: Jacobi 3+3,
-    tol 1e-8) on the same operator, hierarchy from the host SA setup, everything device-resident."""
+    tol 1e-8) on the same operator, hierarchy from the host SA setup, everything device-resident.
+    With more than one rank every rank calls this (the solve is collective over RCCL); the times are
+    rank 0's between barriers."""
     import ctypes as C
     import numpy as np
     L = host.load("gpu")
+
+    def barrier():
+        capi.check(capi.lib().sgpu_barrier())
+        if dist is not None:
+            dist.barrier()
     t0 = time.perf_counter()
     S = host.AmgSolver(A, host.options(L, **host.OPTIONS001)).to_device()
     t_setup = time.perf_counter() - t0
@@ -80,7 +88,7 @@ def vcycle_leg(capi, host, A, m):
     PD = C.POINTER(C.c_double)
     best = None
     for _ in range(3):                                   # first pass warms up; keep the best of the rest
-        capi.check(lib.sgpu_device_sync())
+        barrier()
         t0 = time.perf_counter()
         st = lib.sgpu_solve_pCG(h, du.ptr, dr.ptr, C.byref(it), hist.ctypes.data_as(PD), 64)
         capi.check(lib.sgpu_device_sync())
@@ -91,12 +99,12 @@ def vcycle_leg(capi, host, A, m):
     hh = hist[~np.isnan(hist)]
     for _ in range(3):
         capi.check(lib.sgpu_vcycle(h, du.ptr, dr.ptr))
-    capi.check(lib.sgpu_device_sync())
+    barrier()
     n = 20
     t0 = time.perf_counter()
     for _ in range(n):
         capi.check(lib.sgpu_vcycle(h, du.ptr, dr.ptr))
-    capi.check(lib.sgpu_device_sync())
+    barrier()
     t_v = (time.perf_counter() - t0) / n
     levels = [S.level_info(l) for l in range(S.num_levels)]
     return {"levels": S.num_levels, "rows": [x["rows"] for x in levels], "nnz": [x["nnzA"] for x in levels],
@@ -137,10 +145,14 @@ def main():
     from saena_amd import capi, host
 
     uid = None
+    # SAENA_BENCH_FORCE_COMM=1: one rank WITH an RCCL communicator (self send/recv), to rehearse the N>1 code on one GPU
+    multi = world > 1 or bool(os.environ.get("SAENA_BENCH_FORCE_COMM"))
     if world > 1:
         box = [capi.get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
+    elif multi:
+        uid = capi.get_unique_id()
     capi.init(device=local_rank, rank=rank, nranks=world, unique_id=uid)
 
     # ---- operator through the host mirror of saena::matrix (product path, no oracle) ----
@@ -223,10 +235,43 @@ def main():
                 "traffic": pmc_traffic(m, world)[0], "traffic_source": pmc_traffic(m, world)[1],
             },
         }
-        if world == 1 and not args.no_vcycle:
+        if world == 1 and not multi and not args.no_vcycle:
             out["vcycle"] = vcycle_leg(capi, host, A, m)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, args.cpu_seconds)
+
+    if multi and not args.no_vcycle:
+        # V-cycle over all ranks: the SAME global Poisson m^3 problem as at N=1 (strong scaling; the host setup is
+        # single-rank per process, so a weak-scaled hierarchy would cost minutes of setup), row blocks from the
+        # reference's nnz-balanced partitioner, halos over RCCL.  It runs under a watchdog: whatever happens in
+        # here, rank 0 still prints the SpMV line measured above.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["vcycle"] = {"error": f"multi-rank V-cycle leg did not finish within {args.vcycle_timeout:.0f} s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.vcycle_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            A2 = host.Matrix(comm)
+            A2.laplacian3D(m).assemble()
+            leg = vcycle_leg(capi, host, A2, m, dist)
+            leg["scaling"] = "strong"
+            leg["partition"] = f"{world} nnz-balanced row blocks of the global Poisson {m}^3 operator"
+            if rank == 0:
+                out["vcycle"] = leg
+        except Exception as e:                              # noqa: BLE001 -- reported, never fatal for the SpMV line
+            if rank == 0:
+                out["vcycle"] = {"error": f"{type(e).__name__}: {e}"}
+                dog.cancel()
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog.cancel()
+
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     capi.finalize()

@@ -198,6 +198,12 @@ struct sgpu_op {
     bool    injected = false;     // test hook: halo supplied by sgpu_debug_inject_halo
     std::vector<double> h_val;   // host copy of the values of small local parts (coarsest-level factorisation)
     hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
+    ~sgpu_op() {                  // also runs when sgpu_op_create bails out half-way: nothing leaks
+        loc.free_all(); rem.free_all();
+        hipFree(inv_diag); hipFree(tmp); hipFree(dvec); hipFree(vIndex); hipFree(send_buf); hipFree(recv_buf); hipFree(send_f); hipFree(recv_f);
+        if (ev_packed) hipEventDestroy(ev_packed);
+        if (ev_halo) hipEventDestroy(ev_halo);
+    }
 };
 
 namespace {
@@ -296,7 +302,9 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
 // Start the halo exchange of x on the halo stream (pack on cs, send/recv on hs).
 int halo_begin(sgpu_op *op, const double *x) {
     if (!g.comm || op->injected || (op->vIndexSize == 0 && op->recvSize == 0)) return SGPU_OK;
-    const bool f32 = op->halo_fp32 && op->send_f && op->recv_f;
+    // both ends of a link must agree on the wire type, so it depends on the flag alone (a rank that only
+    // sends, or only receives, has just one of the two fp32 buffers)
+    const bool f32 = op->halo_fp32 != 0;
     if (op->vIndexSize) {
         const dim3 grid((op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK);
         if (f32) hipLaunchKernelGGL(sk::k_pack_f32, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_f, op->vIndexSize);
@@ -323,14 +331,14 @@ int halo_begin(sgpu_op *op, const double *x) {
 int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     CHK(halo_begin(op, x));
     CHK(launch_part(op->loc, epi, x, y, e));
+    const bool exchanged = g.comm && !op->injected && (op->vIndexSize || op->recvSize);
+    // cs joins the exchange even on a rank that only sends: the next pack must not overwrite a send buffer in flight
+    if (exchanged) HIPCHK(hipStreamWaitEvent(g.cs, op->ev_halo, 0));
     if (op->has_remote && (g.comm || op->injected)) {
-        if (g.comm && !op->injected) {
-            HIPCHK(hipStreamWaitEvent(g.cs, op->ev_halo, 0));
-            if (op->halo_fp32 && op->recv_f && op->recvSize) {      // half the bytes crossed xGMI; widen for the remote part
-                hipLaunchKernelGGL(sk::k_widen_f32, dim3((op->recvSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
-                                   op->recv_f, op->recv_buf, op->recvSize);
-                HIPCHK(hipGetLastError());
-            }
+        if (exchanged && op->halo_fp32 && op->recvSize) {   // half the bytes crossed xGMI; widen for the remote part
+            hipLaunchKernelGGL(sk::k_widen_f32, dim3((op->recvSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
+                               op->recv_f, op->recv_buf, op->recvSize);
+            HIPCHK(hipGetLastError());
         }
         CHK(launch_part(op->rem, epi, op->recv_buf, y, e));
     }
@@ -583,6 +591,8 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
     op->vIndexSize = d->vIndexSize;
     op->recvSize   = d->col_remote_size;
     int sd = 0, rd = 0;
+    if ((d->numSendProc > 0 && (!d->sendProcRank || !d->sendProcCount)) || (d->numRecvProc > 0 && (!d->recvProcRank || !d->recvProcCount)))
+        return fail(SGPU_ERR_ARG, "send/recv plan arrays are null");
     for (int i = 0; i < d->numSendProc; ++i) {
         op->sendRank.push_back(d->sendProcRank[i]); op->sendCount.push_back(d->sendProcCount[i]); op->sendDispl.push_back(sd);
         sd += d->sendProcCount[i];
@@ -591,6 +601,7 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         op->recvRank.push_back(d->recvProcRank[i]); op->recvCount.push_back(d->recvProcCount[i]); op->recvDispl.push_back(rd);
         rd += d->recvProcCount[i];
     }
+    if (d->vIndexSize && !d->vIndex) return fail(SGPU_ERR_ARG, "vIndex is null");
     if (sd != d->vIndexSize) return fail(SGPU_ERR_ARG, "sum(sendProcCount)=%d != vIndexSize=%d", sd, d->vIndexSize);
     if (rd != d->col_remote_size) return fail(SGPU_ERR_ARG, "sum(recvProcCount)=%d != col_remote_size=%d", rd, d->col_remote_size);
     if (g.comm) {   // (a context without a communicator may hold plans of a larger world for the single-GPU halo tests)
@@ -622,10 +633,6 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
 int sgpu_op_destroy(sgpu_op *op) {
     if (!op) return SGPU_OK;
     if (g.live) hipDeviceSynchronize();
-    op->loc.free_all(); op->rem.free_all();
-    hipFree(op->inv_diag); hipFree(op->tmp); hipFree(op->dvec); hipFree(op->vIndex); hipFree(op->send_buf); hipFree(op->recv_buf); hipFree(op->send_f); hipFree(op->recv_f);
-    if (op->ev_packed) hipEventDestroy(op->ev_packed);
-    if (op->ev_halo) hipEventDestroy(op->ev_halo);
     delete op;
     return SGPU_OK;
 }
@@ -842,6 +849,14 @@ struct sgpu_amg {
     struct Captured { double *u; const double *rhs; hipGraph_t graph; hipGraphExec_t exec; };
     double *Ainv = nullptr;   // dense inverse of the coarsest operator (coarse_solver == 1)
     bool coarse_local = true; // the coarsest operator has no halo on any rank
+    ~sgpu_amg() {
+        for (auto p_ : res) hipFree(p_);
+        for (auto p_ : rhs) hipFree(p_);
+        for (auto p_ : u) hipFree(p_);
+        for (auto p_ : alt) hipFree(p_);
+        for (auto &c : graphs) { hipGraphExecDestroy(c.exec); hipGraphDestroy(c.graph); }
+        hipFree(Ainv); hipFree(alt0); hipFree(r); hipFree(rho); hipFree(hh); hipFree(p);
+    }
     std::vector<Captured> graphs;
 };
 
@@ -1069,13 +1084,6 @@ int sgpu_amg_create(int nlevels, sgpu_op *const *A, sgpu_op *const *P, sgpu_op *
 int sgpu_amg_destroy(sgpu_amg *h) {
     if (!h) return SGPU_OK;
     if (g.live) hipDeviceSynchronize();
-    for (auto p : h->res) hipFree(p);
-    for (auto p : h->rhs) hipFree(p);
-    for (auto p : h->u) hipFree(p);
-    for (auto p : h->alt) hipFree(p);
-    for (auto &c : h->graphs) { hipGraphExecDestroy(c.exec); hipGraphDestroy(c.graph); }
-    hipFree(h->Ainv);
-    hipFree(h->alt0); hipFree(h->r); hipFree(h->rho); hipFree(h->hh); hipFree(h->p);
     delete h;
     return SGPU_OK;
 }
