@@ -1,5 +1,5 @@
 // poisson.cpp -- the reference's experiments/Poisson.cpp flow on the MI355X path:
-//   ./poisson <mx> [options.xml]
+//   ./poisson <mx> [options.xml] [all]
 // 3D 7-point Poisson on an mx^3 grid: generate, assemble, AMG setup, 1 warm-up + timed solve_pCG.
 // Prints the residual lines the reference prints (src/saena_object_solve.cpp:2502,2681-2682).
 #include "saena.hpp"
@@ -44,6 +44,21 @@ int main(int argc, char **argv) {
     solver.solve_pCG(u, &opts);
     t1 = std::chrono::steady_clock::now();
     if (!rank) printf("solve_pCG: %.3f ms, %d iterations\n", 1e3 * std::chrono::duration<double>(t1 - t0).count(), solver.last_iterations());
+
+    if (argc > 3) {                                       // the rest of the live saena::amg surface
+        solver.profile_matvecs();                         // saena_object.cpp:618-638
+        saena::options sm(opts);
+        sm.set_max_iter(10);
+        solver.solve_smoother(u, &sm);                    // 10 x preSmooth sweeps, no coarse grids
+        if (!rank) printf("solve_smoother: %d iterations, residual %e -> %e\n", solver.last_iterations(),
+                          solver.residual_history().front(), solver.residual_history().back());
+        solver.solve(u, &opts);                           // stationary V-cycle iteration
+        if (!rank) printf("solve: %d iterations\n", solver.last_iterations());
+        saena::matrix C(comm);
+        solver.matmat(&A, &A, &C, true, true);
+        if (!rank) printf("matmat: C = A*A has %d rows, %ld nnz\n", C.get_num_rows(), (long)C.get_nnz());
+        C.destroy();
+    }
 
     saena::free_vector(u);
     free(rhs_std);

@@ -195,6 +195,10 @@ public:
     int solve(value_t *&u, saena::options *opts);
     int solve_pCG(value_t *&u, saena::options *opts, bool print_info = true);
     int solve_CG(value_t *&u, saena::options *opts);          // CG without the multigrid preconditioner
+    int solve_smoother(value_t *&u, saena::options *opts);    // the smoother alone (preSmooth sweeps per iteration)
+    // C = A B (host SpGEMM, one rank in this round); C is erased first and assembled unless assemble == false
+    void matmat(saena::matrix *A, saena::matrix *B, saena::matrix *C, bool assemble = true, bool print_timing = false);
+    void profile_matvecs();                                   // average matvec time of every level's A
 
     int  set_verbose(bool verb);
     bool verbose = false;
@@ -216,7 +220,7 @@ private:
     bool dynamic_levels_ = true;
     int max_level_override_ = -1;
     void drop_device();
-    int run(value_t *&u, saena::options *opts, int which, bool print_info);   // which: 0 solve, 1 solve_pCG, 2 solve_CG
+    int run(value_t *&u, saena::options *opts, int which, bool print_info);   // which: 0 solve, 1 solve_pCG, 2 solve_CG, 3 solve_smoother
 };
 
 void free_vector(value_t *u);

@@ -64,6 +64,10 @@ int   saena_laplacian3D(saena_matrix_h *A, index_t mx, index_t my, index_t mz);
 int   saena_laplacian3D_set_rhs(saena_matrix_h *A, index_t mx, index_t my, index_t mz, value_t *rhs_local);
 int   saena_band_matrix(saena_matrix_h *A, index_t M, unsigned int bandwidth);
 
+/* saena::amg::matmat (reference saena.hpp:313, saena_object_setup_matmat.cpp:1164-1487): C = A B on the host,
+ * A and B assembled, one rank in this round; C (a fresh handle's contents are replaced) is assembled on return */
+int   saena_matmat(saena_matrix_h *A, saena_matrix_h *B, saena_matrix_h *C);
+
 /* ---- transfer operators (prolong_matrix / restrict_matrix) ---- */
 typedef struct saena_transfer_h saena_transfer_h;
 /* rows/cols are GLOBAL ids of this rank's fine rows; split_row = fine partition, split_col = coarse partition */

@@ -196,6 +196,16 @@ int sgpu_vcycle(sgpu_amg *h, value_t *u, const value_t *rhs);
 int sgpu_solve(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *res_hist, int hist_cap);
 /* saena_object::solve_pCG (saena_object_solve.cpp:2389-2801) */
 int sgpu_solve_pCG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *res_hist, int hist_cap);
+/* saena_object::set_solve_params (called by every saena::amg::solve* before the solve, saena.cpp:751-790):
+ * replaces the iteration limit, tolerance, smoother (0 jacobi, 1 chebyshev) and sweep counts of an existing
+ * hierarchy.  Captured V-cycle graphs are dropped when the V-cycle shape changes. */
+int sgpu_amg_set_solve_params(sgpu_amg *h, int solver_max_iter, double solver_tol, int smoother, int preSmooth, int postSmooth);
+/* saena_object::profile_matvecs (saena_object.cpp:618-638): average time of `iter` matvecs with A of every level;
+ * us_per_level[nlevels] receives microseconds (this rank, HIP events around the launches, halo included). */
+int sgpu_amg_profile_matvecs(sgpu_amg *h, int iter, double *us_per_level);
+/* saena_object::solve_smoother (saena_object_solve.cpp:2017-2117): preSmooth sweeps of the configured
+ * smoother on A[0] per iteration, no coarse-grid correction */
+int sgpu_solve_smoother(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *res_hist, int hist_cap);
 /* saena_object::solve_CG (saena_object_solve.cpp:2119-2387): plain CG on A[0], no V-cycle */
 int sgpu_solve_CG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *res_hist, int hist_cap);
 /* solve_coarsest_CG on the last level only (for tests) */

@@ -113,7 +113,7 @@ def lib():
         L.orc_solve_coarsest_CG.restype = C.c_int
         L.orc_solve_coarsest_CG.argtypes = [C.POINTER(Amg), C.POINTER(Op), _PD, _PD]
         L.orc_vcycle.argtypes = [C.POINTER(Amg), C.POINTER(Grid), _PD, _PD]
-        for f in ("orc_solve", "orc_solve_pCG", "orc_solve_CG"):
+        for f in ("orc_solve", "orc_solve_pCG", "orc_solve_CG", "orc_solve_smoother"):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [C.POINTER(Amg), _PD, _PD, _PD, C.c_int]
         L.orc_time_matvec.restype = C.c_double
@@ -277,6 +277,9 @@ class OracleAmg:
             _LIB.orc_amg_free(self.p)
             self.p = None
 
+    def set_solver(self, max_iter, tol):
+        self.p.contents.solver_max_iter, self.p.contents.solver_tol = max_iter, tol
+
     def vcycle(self, u, rhs):
         u = np.array(u, np.float64)
         rhs = np.ascontiguousarray(rhs, np.float64)
@@ -303,3 +306,6 @@ class OracleAmg:
 
     def solve_CG(self, rhs, cap=2048):
         return self._solve(lib().orc_solve_CG, rhs, cap)
+
+    def solve_smoother(self, rhs, cap=2048):
+        return self._solve(lib().orc_solve_smoother, rhs, cap)

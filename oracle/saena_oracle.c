@@ -599,6 +599,29 @@ int orc_solve(const orc_amg *h, value_t *u, const value_t *rhs, double *hist, in
     return i + 1;
 }
 
+/* saena_object_solve.cpp:2017-2117: the smoother alone as the iteration (preSmooth sweeps per step) */
+int orc_solve_smoother(const orc_amg *h, value_t *u, const value_t *rhs, double *hist, int cap) {
+    orc_op *A = h->grids[0].A;
+    const index_t sz = A->Mbig;
+    for (index_t i = 0; i < sz; ++i) u[i] = 0;           /* :2051 */
+    value_t *r = xcalloc((size_t)sz, sizeof *r);
+    orc_residual(A, u, rhs, r);                           /* :2060 */
+    double init_dot = orc_dot(r, r, A->split_row, A->nprocs), current_dot = init_dot;
+    if (hist && cap > 0) hist[0] = sqrt(init_dot);
+    const double thr = init_dot * h->solver_tol * h->solver_tol;
+    int i = 0;
+    for (; i < h->solver_max_iter; ++i) {                 /* :2072-2081 */
+        smooth(h, &h->grids[0], u, rhs, h->preSmooth);
+        orc_residual(A, u, rhs, r);
+        current_dot = orc_dot(r, r, A->split_row, A->nprocs);
+        if (hist && i + 1 < cap) hist[i + 1] = sqrt(current_dot);
+        if (current_dot < thr) break;
+    }
+    if (i == h->solver_max_iter) i--;
+    free(r);
+    return i + 1;
+}
+
 /* saena_object_solve.cpp:2389-2801 */
 int orc_solve_pCG(const orc_amg *h, value_t *u, const value_t *rhs, double *hist, int cap) {
     orc_op *A = h->grids[0].A;

@@ -158,6 +158,8 @@ int  orc_solve_coarsest_CG(const orc_amg *h, orc_op *A, value_t *u, const value_
 void orc_vcycle(const orc_amg *h, orc_grid *g, value_t *u, const value_t *rhs);
 /* src/saena_object_solve.cpp:1883-2014; res_hist[k] = ||r_k|| (k=0 initial) */
 int  orc_solve(const orc_amg *h, value_t *u, const value_t *rhs, double *res_hist, int hist_cap);
+/* src/saena_object_solve.cpp:2017-2117 */
+int  orc_solve_smoother(const orc_amg *h, value_t *u, const value_t *rhs, double *res_hist, int hist_cap);
 /* src/saena_object_solve.cpp:2389-2801 */
 int  orc_solve_pCG(const orc_amg *h, value_t *u, const value_t *rhs, double *res_hist, int hist_cap);
 

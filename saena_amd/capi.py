@@ -86,6 +86,9 @@ SYMBOLS = {
     "sgpu_solve": (C.c_int, [_VP, _VP, _VP, _PI, _PD, C.c_int]),
     "sgpu_solve_pCG": (C.c_int, [_VP, _VP, _VP, _PI, _PD, C.c_int]),
     "sgpu_solve_CG": (C.c_int, [_VP, _VP, _VP, _PI, _PD, C.c_int]),
+    "sgpu_solve_smoother": (C.c_int, [_VP, _VP, _VP, _PI, _PD, C.c_int]),
+    "sgpu_amg_set_solve_params": (C.c_int, [_VP, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]),
+    "sgpu_amg_profile_matvecs": (C.c_int, [_VP, C.c_int, _PD]),
     "sgpu_coarsest_solve": (C.c_int, [_VP, _VP, _VP, _PI]),
     "sgpu_time_kernel": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.POINTER(C.c_float)]),
     "sgpu_algorithmic_bytes": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64)]),
@@ -355,6 +358,17 @@ class Amg:
 
     def solve_CG(self, u, rhs):
         return self._solve(lib().sgpu_solve_CG, u, rhs, cap=2048)
+
+    def solve_smoother(self, u, rhs):
+        return self._solve(lib().sgpu_solve_smoother, u, rhs, cap=2048)
+
+    def set_solve_params(self, max_iter, tol, smoother, pre, post):
+        check(lib().sgpu_amg_set_solve_params(self.h, int(max_iter), float(tol), 0 if smoother == "jacobi" else 1, int(pre), int(post)))
+
+    def profile_matvecs(self, iters=5):
+        us = np.zeros(len(self.A))
+        check(lib().sgpu_amg_profile_matvecs(self.h, int(iters), us.ctypes.data_as(_PD)))
+        return us
 
     def destroy(self):
         if self.h:

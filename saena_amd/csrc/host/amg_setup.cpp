@@ -188,6 +188,19 @@ Csr spgemm(const Csr &A, const Csr &B) {
 } // namespace
 
 // ---------------------------------------------------------------------------
+std::vector<cooEntry> amg_hierarchy::matmat(const saena_matrix &A, const saena_matrix &B) {
+    if (A.comm->nranks != 1) throw std::runtime_error("matmat: the SpGEMM is single-rank in this round");
+    if (!A.assembled || !B.assembled) throw std::runtime_error("matmat: assemble A and B first");
+    if (A.Mbig != B.Mbig) throw std::runtime_error("matmat: A and B must have the same size");
+    const Csr C = spgemm(csr_of(A.L, A.Mbig), csr_of(B.L, B.Mbig));
+    std::vector<cooEntry> out;
+    out.reserve(C.col.size());
+    for (index_t i = 0; i < C.nrows; ++i)
+        for (nnz_t k = C.ptr[i]; k < C.ptr[i + 1]; ++k) out.emplace_back(i, C.col[k], C.val[k]);
+    return out;
+}
+
+// ---------------------------------------------------------------------------
 // strength of connection (setup1:520-719) + threshold (strength_matrix.cpp:242-258)
 void amg_hierarchy::strength_graph(const saena_matrix &A, float connStrength, std::vector<nnz_t> &ptr, std::vector<index_t> &col) {
     if (A.comm->nranks != 1) throw std::runtime_error("strength_graph: multi-rank setup is not implemented in this round");

@@ -84,6 +84,10 @@ public:
     // aggregation_1_dist + aggregate_index_update (setup1:724-995, :2103-2260); returns the number of aggregates
     static index_t aggregate(const saena_matrix &A, const std::vector<nnz_t> &ptr, const std::vector<index_t> &col,
                              std::vector<index_t> &agg, std::vector<index_t> *roots = nullptr);
+    // saena_object::matmat (saena_object_setup_matmat.cpp:1164-1487): C = A B for two assembled one-rank matrices;
+    // products with |v| <= 1e-14 are dropped unless on the diagonal, the rule of the reference's SpGEMM output.
+    // Returns the entries of C (row, col, val), row-major.
+    static std::vector<cooEntry> matmat(const saena_matrix &A, const saena_matrix &B);
     // find_eig (saena_object.cpp:572-592, lamlan_saena.h): largest eigenvalue of D^-1 A by 20 Lanczos steps, x 1.0001
     static double find_eig(const saena_matrix &A);
 

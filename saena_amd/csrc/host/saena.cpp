@@ -7,6 +7,7 @@
 #include "saena_matrix.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -270,13 +271,16 @@ int amg::run(value_t *&u, saena::options *opts, int which, bool print_info) {
     if (!damg_) throw std::runtime_error("saena::amg: set_matrix first");
     const size_t n = (size_t)A_->get_num_local_rows();
     if (rhs_.size() != n) throw std::runtime_error("saena::amg: set_rhs first");
-    (void)opts;    // solve parameters were fixed by set_matrix (the reference re-reads max_iter/tol/smoother here)
+    if (opts)      // saena.cpp:751-790: every solve* first re-reads the solve parameters from the options
+        gchk(sgpu_amg_set_solve_params(damg_, opts->get_max_iter(), opts->get_tol(), opts->get_smoother() == "jacobi" ? 0 : 1,
+                                       opts->get_preSmooth(), opts->get_postSmooth()), "set_solve_params");
     value_t *du = nullptr, *dr = nullptr;
     gchk(sgpu_vec_alloc(&du, n), "alloc"); gchk(sgpu_vec_alloc(&dr, n), "alloc");
     gchk(sgpu_vec_upload(dr, rhs_.data(), n), "upload");
     hist_.assign(4096, 0.0);
     int st = which == 1 ? sgpu_solve_pCG(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size())
            : which == 2 ? sgpu_solve_CG(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size())
+           : which == 3 ? sgpu_solve_smoother(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size())
                         : sgpu_solve(damg_, du, dr, &iters_, hist_.data(), (int)hist_.size());
     if (st != SGPU_OK && st != SGPU_ERR_NOCONV) { sgpu_vec_free(du); sgpu_vec_free(dr); gchk(st, "solve"); }
     hist_.resize((size_t)std::min<int>(iters_ + 1, 4096));
@@ -293,6 +297,29 @@ int amg::run(value_t *&u, saena::options *opts, int which, bool print_info) {
 int amg::solve(value_t *&u, saena::options *opts) { return run(u, opts, 0, true); }
 int amg::solve_pCG(value_t *&u, saena::options *opts, bool print_info) { return run(u, opts, 1, print_info); }
 int amg::solve_CG(value_t *&u, saena::options *opts) { return run(u, opts, 2, true); }
+int amg::solve_smoother(value_t *&u, saena::options *opts) { return run(u, opts, 3, true); }
+
+// saena_object::matmat + matmat_assemble (saena_object_setup_matmat.cpp:1164-1487,1640-1708)
+void amg::matmat(saena::matrix *A, saena::matrix *B, saena::matrix *C, bool assemble, bool print_timing) {
+    if (!A || !B || !C) throw std::runtime_error("saena::amg::matmat: null matrix");
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<saena_host::cooEntry> e = saena_host::amg_hierarchy::matmat(*A->get_internal_matrix(), *B->get_internal_matrix());
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    C->erase();
+    C->set_remove_boundary(false);
+    for (const auto &x : e) C->set(x.row, x.col, x.val);
+    if (assemble) C->assemble();
+    if (print_timing && A->get_comm().rank() == 0) printf("matmat: %e s\n", dt);
+}
+
+// saena_object::profile_matvecs (saena_object.cpp:618-638)
+void amg::profile_matvecs() {
+    if (!damg_) throw std::runtime_error("saena::amg: set_matrix first");
+    std::vector<double> us((size_t)get_num_levels(), 0.0);
+    gchk(sgpu_amg_profile_matvecs(damg_, 5, us.data()), "profile_matvecs");
+    if (A_->get_comm().rank() == 0)
+        for (size_t l = 0; l < us.size(); ++l) printf("matvec level %zu: %e s\n", l, us[l] * 1e-6);
+}
 
 void free_vector(value_t *u) { std::free(u); }
 

@@ -122,6 +122,17 @@ int saena_matrix_get_layout_extra(saena_matrix_h *A, const index_t **col_remote,
 int saena_laplacian3D(saena_matrix_h *A, index_t mx, index_t my, index_t mz) { return guard([&] { laplacian3D(&A->A, mx, my, mz); }); }
 int saena_band_matrix(saena_matrix_h *A, index_t M, unsigned int bw) { return guard([&] { band_matrix(&A->A, M, bw); }); }
 
+int saena_matmat(saena_matrix_h *A, saena_matrix_h *B, saena_matrix_h *C) {
+    return guard([&] {
+        std::vector<cooEntry> e = amg_hierarchy::matmat(A->A, B->A);
+        Comm *c = A->A.comm;
+        C->A = saena_matrix(c);
+        C->A.remove_boundary = false;
+        for (const auto &x : e) C->A.set(x.row, x.col, x.val);
+        C->A.assemble();
+    });
+}
+
 int saena_laplacian3D_set_rhs(saena_matrix_h *Ah, index_t mx, index_t my, index_t mz, value_t *rhs_local) {
     return guard([&] {
         saena_matrix &A = Ah->A;

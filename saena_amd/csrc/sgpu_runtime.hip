@@ -1088,6 +1088,42 @@ int sgpu_amg_destroy(sgpu_amg *h) {
     return SGPU_OK;
 }
 
+int sgpu_amg_set_solve_params(sgpu_amg *h, int solver_max_iter, double solver_tol, int smoother, int preSmooth, int postSmooth) {
+    CHK(need_ctx());
+    if (!h) return fail(SGPU_ERR_ARG, "null hierarchy");
+    if (solver_max_iter < 0 || preSmooth < 0 || postSmooth < 0 || (smoother != 0 && smoother != 1) || !(solver_tol >= 0.0))
+        return fail(SGPU_ERR_ARG, "bad solve parameters");
+    if (smoother == 1)
+        for (int l = 0; l < h->nlevels - 1; ++l) {
+            if (!(h->eig[l] > 0.0)) return fail(SGPU_ERR_ARG, "chebyshev needs eig_max[%d] > 0", l);
+            CHK(ensure_d(h->A[l]));                      // no allocation may happen inside a graph capture
+        }
+    if (smoother != h->prm.smoother || preSmooth != h->prm.preSmooth || postSmooth != h->prm.postSmooth) {
+        HIPCHK(hipStreamSynchronize(g.cs));
+        for (auto &c : h->graphs) { hipGraphExecDestroy(c.exec); hipGraphDestroy(c.graph); }
+        h->graphs.clear();
+    }
+    h->prm.solver_max_iter = solver_max_iter; h->prm.solver_tol = solver_tol;
+    h->prm.smoother = smoother; h->prm.preSmooth = preSmooth; h->prm.postSmooth = postSmooth;
+    return SGPU_OK;
+}
+
+int sgpu_amg_profile_matvecs(sgpu_amg *h, int iter, double *us_per_level) {
+    CHK(need_ctx());
+    if (!h || !us_per_level || iter < 1) return fail(SGPU_ERR_ARG, "bad argument");
+    for (int l = 0; l < h->nlevels; ++l) {
+        sgpu_op *A = h->A[l];
+        DevBuf v, w;
+        CHK(v.alloc(A->M)); CHK(w.alloc(A->M));
+        CHK(sgpu_vec_fill(v.p, 1.0, A->M));              // saena_object.cpp:625
+        CHK(sgpu_spmv(A, v.p, w.p));                     // warm-up launch (code object load)
+        float ms = 0;
+        CHK(sgpu_time_kernel(A, 0, v.p, nullptr, w.p, iter, &ms));
+        us_per_level[l] = (double)ms * 1e3;
+    }
+    return SGPU_OK;
+}
+
 int sgpu_vcycle(sgpu_amg *h, value_t *u, const value_t *rhs) {
     CHK(need_ctx());
     if (!h || !u || !rhs) return fail(SGPU_ERR_ARG, "null argument");
@@ -1115,6 +1151,37 @@ int sgpu_solve(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t 
     int i = 0;
     for (; i < h->prm.solver_max_iter; ++i) {                         // :1957-1970
         CHK(vcycle0(h, u, rhs));
+        CHK(sgpu_residual(A, u, rhs, h->r));
+        CHK(sgpu_dot(h->r, h->r, sz, &current_dot));
+        if (hist && i + 1 < cap) hist[i + 1] = std::sqrt(current_dot);
+        if (current_dot < THRSHLD) break;
+    }
+    const bool conv = current_dot < THRSHLD;
+    if (i == h->prm.solver_max_iter) --i;
+    if (iters) *iters = i + 1;
+    return conv ? SGPU_OK : SGPU_ERR_NOCONV;
+}
+
+// saena_object::solve_smoother (src/saena_object_solve.cpp:2017-2117)
+int sgpu_solve_smoother(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *hist, int cap) {
+    CHK(need_ctx());
+    if (!h || !u || !rhs) return fail(SGPU_ERR_ARG, "null argument");
+    sgpu_op *A = h->A[0];
+    const size_t sz = (size_t)A->M;
+    if (h->prm.smoother == 1 && !(h->eig[0] > 0.0)) return fail(SGPU_ERR_ARG, "chebyshev needs eig_max[0] > 0");
+    if (h->prm.smoother == 1) CHK(ensure_d(A));
+    CHK(sgpu_vec_fill(u, 0.0, sz));                                   // :2051
+    CHK(sgpu_residual(A, u, rhs, h->r));                              // :2060
+    double init_dot = 0, current_dot = 0;
+    CHK(sgpu_dot(h->r, h->r, sz, &init_dot));
+    current_dot = init_dot;
+    if (hist && cap > 0) hist[0] = std::sqrt(init_dot);
+    const double THRSHLD = init_dot * h->prm.solver_tol * h->prm.solver_tol;
+    int i = 0;
+    for (; i < h->prm.solver_max_iter; ++i) {                         // :2072-2081
+        double *out = nullptr;
+        CHK(smooth_pp(h, 0, h->prm.preSmooth, u, h->alt0, rhs, &out));
+        if (out != u) HIPCHK(hipMemcpyAsync(u, out, sz * sizeof(double), hipMemcpyDeviceToDevice, g.cs));
         CHK(sgpu_residual(A, u, rhs, h->r));
         CHK(sgpu_dot(h->r, h->r, sz, &current_dot));
         if (hist && i + 1 < cap) hist[i + 1] = std::sqrt(current_dot);

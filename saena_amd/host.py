@@ -49,6 +49,7 @@ HOST_SYMBOLS = {
     "saena_laplacian3D": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
     "saena_laplacian3D_set_rhs": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _PD]),
     "saena_band_matrix": (C.c_int, [_VP, C.c_int, C.c_uint]),
+    "saena_matmat": (C.c_int, [_VP, _VP, _VP]),
     "saena_prolong_new": (_VP, [_VP, C.c_int, C.c_int, _PI, _PI, _PI, _PI, _PD, C.c_long]),
     "saena_restrict_from_prolong": (_VP, [_VP]),
     "saena_transfer_free": (None, [_VP]),
@@ -256,6 +257,12 @@ class Matrix:
             s = _ai(split)
             _check(self.L, self.L.saena_matrix_assemble_with_split(self.h, s.ctypes.data_as(_PI)))
         return self
+
+    def matmat(self, B):
+        """saena::amg::matmat: C = self * B (host SpGEMM, one rank)"""
+        Cm = Matrix(self.comm)
+        _check(self.L, self.L.saena_matmat(self.h, B.h, Cm.h))
+        return Cm
 
     def laplacian3D_rhs(self):
         mx, my, mz = self._grid

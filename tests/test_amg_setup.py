@@ -148,3 +148,23 @@ def test_distributed_hierarchy_gloo():
         res = dict(ret)
     for r in range(world):
         assert res.get(r) == "ok", f"rank {r}: {res.get(r)}"
+
+
+def test_matmat_against_scipy():
+    """saena::amg::matmat (host SpGEMM): C = A B equals scipy's product; exact zeros off the diagonal are dropped"""
+    import scipy.sparse as sp
+    comm = host.Comm("host", "self")
+    A = host.Matrix(comm).laplacian3D(9).assemble()
+    B = host.Matrix(comm).band_matrix(A.num_rows, 3).assemble()
+    Cm = A.matmat(B)
+
+    def to_scipy(Mx):
+        d = Mx.layout()
+        rows = np.repeat(np.arange(d["M"]), d["nnzPerRow_local"])
+        return sp.csr_matrix((d["val_local"], (rows, d["col_local"])), shape=(d["M"], d["M"]))
+    want = (to_scipy(A) @ to_scipy(B)).tocsr()
+    got = to_scipy(Cm)
+    assert Cm.num_rows == A.num_rows
+    diff = (got - want)
+    assert abs(diff).max() <= 1e-12 * abs(want).max()
+    assert got.nnz <= want.nnz and got.nnz >= want.nnz - (abs(want.data) <= 1e-14).sum()

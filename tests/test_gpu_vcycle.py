@@ -137,6 +137,50 @@ def test_plain_cg(capi, hier):
     assert rel(du.download(), u_o) <= 1e-7
 
 
+@pytest.mark.parametrize("smoother", ["jacobi", "chebyshev"])
+def test_solve_smoother(capi, hier, smoother):
+    """saena::amg::solve_smoother (saena_object_solve.cpp:2017-2117): preSmooth sweeps per iteration, no coarse grids"""
+    O, G, (OA, _, _), _ = build(capi, hier, smoother, pre=3, max_iter=25, tol=1e-2)
+    n = OA[0].Mbig
+    rhs = inputs.rhs2(n)
+    du, dr = capi.DeviceVector(n), capi.DeviceVector(n, rhs)
+    u_o, it_o, hist_o = O.solve_smoother(rhs)
+    it_g, hist_g, conv = G.solve_smoother(du, dr)
+    assert it_g == it_o and len(hist_g) == len(hist_o)
+    assert hist_g[-1] < hist_g[0]
+    assert np.all(np.abs(hist_g - hist_o) <= TOL_HIST * hist_o[0])
+    assert rel(du.download(), u_o) <= 1e-11
+
+
+def test_set_solve_params(capi, hier):
+    """sgpu_amg_set_solve_params = saena_object::set_solve_params: a hierarchy re-parameterised in place behaves like one
+    created with those parameters (captured graphs of the old V-cycle shape are dropped)"""
+    _, G33, (OA, _, _), _ = build(capi, hier, "jacobi", pre=3, post=3, max_iter=60)
+    _, G12, _, _ = build(capi, hier, "chebyshev", pre=1, post=2, max_iter=7, tol=1e-30)
+    n = OA[0].Mbig
+    rhs = inputs.rhs2(n)
+    du, dv, dr = capi.DeviceVector(n), capi.DeviceVector(n), capi.DeviceVector(n, rhs)
+    G33.vcycle(du, dr)                                   # captures the (3,3) Jacobi graph for (du, dr)
+    G33.set_solve_params(7, 1e-30, "chebyshev", 1, 2)
+    du.upload(np.zeros(n)); dv.upload(np.zeros(n))
+    G33.vcycle(du, dr)
+    G12.vcycle(dv, dr)
+    np.testing.assert_array_equal(du.download(), dv.download())
+    it_a, hist_a, conv_a = G33.solve_pCG(du, dr)
+    it_b, hist_b, conv_b = G12.solve_pCG(dv, dr)
+    assert it_a == it_b == 7 and not conv_a and not conv_b
+    np.testing.assert_array_equal(hist_a, hist_b)
+    with pytest.raises(RuntimeError):
+        G33.set_solve_params(5, 1e-8, "jacobi", -1, 1)
+
+
+def test_profile_matvecs(capi, hier):
+    """saena_object::profile_matvecs: one positive average time per level"""
+    _, G, (OA, _, _), _ = build(capi, hier, "jacobi")
+    us = G.profile_matvecs(5)
+    assert len(us) == len(OA) and np.all(us > 0) and np.all(us < 1e5)
+
+
 def test_two_level_and_single_level(capi):
     """max_level = 1 and max_level = 0 (`only using the direct solver`, saena_object_solve.cpp:2504-2520)"""
     As, Ps, Rs = hierarchy.poisson_hierarchy(8, 2)       # 216 -> 27
@@ -193,7 +237,7 @@ def test_cpp_surface_poisson_driver(capi, tmp_path):
                    '\tsmoother="jacobi"\n\tpreSmooth="3"\n\tpostSmooth="3"\n\tPSmoother="jacobi"\n\tconn_str="0.2"\n\tdynamic_levels="1"\n'
                    '\tmax_level="20"\n\tfloat_level="3"\n\tfilter_thre="1e-14"\n\tfilter_max="1e-8"\n\tfilter_start="1"\n\tfilter_rate="2"\n'
                    '\tswitch_to_dense="0"\n\tdense_thre="0.1"\n\tdense_sz_thre="5000"\n\tpetsc=""/>\n</SAENA>\n')
-    out = subprocess.run([exe, "32", str(xml)], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, "32", str(xml), "all"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     txt = out.stdout
     assert "number of levels = << 4 >>" in txt
@@ -202,6 +246,16 @@ def test_cpp_surface_poisson_driver(capi, tmp_path):
     assert re.search(r"stopped at iteration\s+= 7", txt), txt
     assert re.search(r"final absolute residual = 2\.24625\de-05", txt), txt
     assert re.search(r"relative residual\s+= 3\.10799\de-09", txt), txt
+    # the rest of the live amg surface: profile_matvecs, solve_smoother, solve, matmat
+    assert len(re.findall(r"matvec level \d+: ", txt)) == 5, txt
+    m_ = re.search(r"solve_smoother: 10 iterations, residual (\S+) -> (\S+)", txt)
+    assert m_ and float(m_.group(2)) < float(m_.group(1)), txt
+    m_ = re.search(r"\nsolve: (\d+) iterations", txt)
+    assert m_ and 5 <= int(m_.group(1)) <= 20, txt
+    import scipy.sparse as sp
+    e, M = orc.laplacian3d(32)
+    A = sp.csr_matrix((e["val"], (e["row"], e["col"])), shape=(M, M))
+    assert f"matmat: C = A*A has {M} rows, {(A @ A).nnz} nnz" in txt, txt
 
 
 def test_multirank_vcycle_emulated_on_one_gpu(capi, hier):

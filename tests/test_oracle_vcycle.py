@@ -38,3 +38,22 @@ def test_stationary_solve_matches_manual_vcycles():
     for _ in range(it):
         v = amg.vcycle(v, rhs)
     np.testing.assert_array_equal(u, v)
+
+
+def test_solve_smoother_is_repeated_sweeps():
+    """orc_solve_smoother (saena_object_solve.cpp:2017-2117) = preSmooth sweeps + residual per iteration, built from
+    the smoother / residual restatements that are pinned against the compiled reference (test_oracle_pins.py)"""
+    for smoother in ("jacobi", "chebyshev"):
+        amg, OA = _amg(2, smoother)
+        amg.set_solver(max_iter=6, tol=1e-30)
+        rhs = inputs.rhs2(OA[0].Mbig)
+        u, it, hist = amg.solve_smoother(rhs)
+        assert it == 6 and len(hist) == 7
+        v = np.zeros_like(rhs)
+        want = [np.linalg.norm(OA[0].residual(v, rhs))]
+        for _ in range(6):
+            v = OA[0].jacobi(3, v, rhs) if smoother == "jacobi" else OA[0].chebyshev(3, v, rhs)
+            want.append(np.linalg.norm(OA[0].residual(v, rhs)))
+        np.testing.assert_array_equal(u, v)
+        np.testing.assert_allclose(hist, want, rtol=1e-13)
+        assert hist[-1] < hist[0]
