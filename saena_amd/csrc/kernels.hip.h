@@ -247,6 +247,8 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
 // into the block's table of <= 16 segment bases plus a 12-bit offset: 10 B/nnz instead of 12.  Operators
 // whose blocks touch more than 16 segments keep the 32-bit kernel (decided per operator at plan time).
 // Arithmetic and summation order are those of k_csr_stream (bit-identical results).
+__device__ __forceinline__ bool stray(int k, int p0, int p1) { return k < p0 || k >= p1; }
+
 template <int EPI, int G, int CAPV>
 __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
     constexpr int LDSN = CAPV + 8;
@@ -272,11 +274,19 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
                 const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
                 const uint2   c   = *reinterpret_cast<const uint2 *>(a.ccol + idx);
                 const unsigned c0 = c.x & 0xffffu, c1 = c.x >> 16, c2 = c.y & 0xffffu, c3 = c.y >> 16;
+                int j0 = seg[c0 >> 12] + (int)(c0 & 4095u), j1 = seg[c1 >> 12] + (int)(c1 & 4095u);
+                int j2 = seg[c2 >> 12] + (int)(c2 & 4095u), j3 = seg[c3 >> 12] + (int)(c3 & 4095u);
+                if (q == 0 || q == nq - 1) {          // quads shared with a neighbouring block: its ids were packed
+                    j0 = stray(idx, p0, p1) ? 0 : j0; //  against ANOTHER segment table and may decode past the end of x
+                    j1 = stray(idx + 1, p0, p1) ? 0 : j1;
+                    j2 = stray(idx + 2, p0, p1) ? 0 : j2;
+                    j3 = stray(idx + 3, p0, p1) ? 0 : j3;
+                }
                 double2 o01, o23;
-                o01.x = v01.x * a.x[seg[c0 >> 12] + (int)(c0 & 4095u)];
-                o01.y = v01.y * a.x[seg[c1 >> 12] + (int)(c1 & 4095u)];
-                o23.x = v23.x * a.x[seg[c2 >> 12] + (int)(c2 & 4095u)];
-                o23.y = v23.y * a.x[seg[c3 >> 12] + (int)(c3 & 4095u)];
+                o01.x = v01.x * a.x[j0];
+                o01.y = v01.y * a.x[j1];
+                o23.x = v23.x * a.x[j2];
+                o23.y = v23.y * a.x[j3];
                 *reinterpret_cast<double2 *>(&lds[4 * q])     = o01;
                 *reinterpret_cast<double2 *>(&lds[4 * q + 2]) = o23;
             }
@@ -298,10 +308,21 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const unsigned c0 = c[it].x & 0xffffu, c1 = c[it].x >> 16, c2 = c[it].y & 0xffffu, c3 = c[it].y >> 16;
-            o01[it].x = a.x[seg[c0 >> 12] + (int)(c0 & 4095u)];
-            o01[it].y = a.x[seg[c1 >> 12] + (int)(c1 & 4095u)];
-            o23[it].x = a.x[seg[c2 >> 12] + (int)(c2 & 4095u)];
-            o23[it].y = a.x[seg[c3 >> 12] + (int)(c3 & 4095u)];
+            int j0 = seg[c0 >> 12] + (int)(c0 & 4095u), j1 = seg[c1 >> 12] + (int)(c1 & 4095u);
+            int j2 = seg[c2 >> 12] + (int)(c2 & 4095u), j3 = seg[c3 >> 12] + (int)(c3 & 4095u);
+            int q = tid + it * BLOCK;
+            q = q < qlast ? q : qlast;
+            if (q == 0 || q == qlast) {               // quads shared with a neighbouring block (see above)
+                const int idx = a0 + 4 * q;
+                j0 = stray(idx, p0, p1) ? 0 : j0;
+                j1 = stray(idx + 1, p0, p1) ? 0 : j1;
+                j2 = stray(idx + 2, p0, p1) ? 0 : j2;
+                j3 = stray(idx + 3, p0, p1) ? 0 : j3;
+            }
+            o01[it].x = a.x[j0];
+            o01[it].y = a.x[j1];
+            o23[it].x = a.x[j2];
+            o23[it].y = a.x[j3];
         }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
