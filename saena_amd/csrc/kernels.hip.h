@@ -57,33 +57,50 @@ struct SpmvArgs {
     double        c0;        // omega | c
     double        c1;        // d1
     int           nblk;
-    const int    *rows;      // remote part: compact list of rows that own remote entries (else nullptr)
+    const unsigned *skip;    // bitmask of rows this launch must NOT write (boundary rows, owned by k_csr_boundary), or nullptr
     // 16-bit compressed columns (k_csr_cc16): per block 16 segment bases (multiples of 4096), per nnz
     // (segment slot << 12) | (column & 4095)
     const int            *segtab;   // [nblk*16]
     const unsigned short *ccol;     // [nnz] (padded)
+    // in-kernel fork/join with the halo stream (multi-rank interior launch only, else nullptr):
+    // block 0 stores *flag_x = seq when it starts (stream order: everything earlier on the compute stream
+    // is complete, so the halo stream's pack may read x) and does not exit before *flag_h >= seq (the
+    // boundary-row kernel on the halo stream is done), so the launch's completion IS the join.
+    uint64_t *flag_x;
+    uint64_t *flag_h;
+    uint64_t  seq;
 };
 
-// Remote-part epilogues: the local kernel already applied the epilogue to
-// s_local; every epilogue is affine in s, so the halo contribution is a
-// correction on the rows that have remote entries.
-template <int EPI>
-__device__ __forceinline__ void epilogue_remote(const SpmvArgs &a, int r, double s) {
-    if constexpr (EPI == EPI_SPMV || EPI == EPI_RESIDUAL) {
-        a.y[r] += s;
-    } else if constexpr (EPI == EPI_JACOBI) {
-        a.y[r] -= (a.inv_diag[r] * a.c0) * s;
-    } else if constexpr (EPI == EPI_CHEBY0 || EPI == EPI_CHEBYK) {
-        const double t = (a.c0 * a.inv_diag[r]) * s;
-        a.d[r] -= t;
-        a.y[r] -= t;
-    } else if constexpr (EPI == EPI_SUB) {
-        a.y[r] -= s;
+// ---- flags between the two streams: plain device memory (one 128-B line each), agent-scope atomics.
+// (hipMallocSignalMemory is host-resident: 125 blocks polling it over PCIe took ~40 us per round.) ----
+// The polling loads are RELAXED: an acquire inside the loop would invalidate caches on every iteration
+// (measured: 124 polling blocks tripled the interior kernel's time); one acquire fence follows the loop.
+__device__ __forceinline__ void fork_signal(const SpmvArgs &a) {
+    // stream order already completed (and released) everything earlier on this stream: a plain flag store suffices
+    if (a.flag_x && blockIdx.x == 0 && threadIdx.x == 0)
+        (void)__hip_atomic_exchange(a.flag_x, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an RMW is performed at memory, a plain store may linger in L2
+}
+__device__ __forceinline__ void join_wait(const SpmvArgs &a) {
+    if (a.flag_h && blockIdx.x == 0 && threadIdx.x == 0)
+        while (__hip_atomic_load(a.flag_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.seq) __builtin_amdgcn_s_sleep(32);
+}
+// every thread of the block waits until *flag >= seq.  NO acquire fence follows: on this part an agent-scope
+// acquire is an L2 invalidate per wave (measured: ~46 us for the 500 waves of a pack launch); the caller reads
+// the freshly produced data through agent-scope atomic loads instead (coherent_load below).
+__device__ __forceinline__ void block_wait_flag(const uint64_t *flag, uint64_t seq) {
+    if (flag) {
+        if (threadIdx.x == 0)
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) __builtin_amdgcn_s_sleep(32);
+        __syncthreads();
     }
 }
-
+// a load that must observe what another kernel released at agent scope AFTER this kernel was dispatched
+__device__ __forceinline__ double coherent_load(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int EPI>
 __device__ __forceinline__ void epilogue(const SpmvArgs &a, int r, double s) {
+    if (a.skip && ((a.skip[r >> 5] >> (r & 31)) & 1u)) return;     // a boundary row: the halo stream's kernel writes it
     if constexpr (EPI == EPI_SPMV) {
         a.y[r] = s;
     } else if constexpr (EPI == EPI_RESIDUAL) {
@@ -144,6 +161,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
     constexpr int LDSN = CAPV + 8;
     __shared__ __attribute__((aligned(16))) double lds[LDSN];
     const int tid = threadIdx.x;
+    fork_signal(a);
     const int b   = xcd_remap(blockIdx.x, a.nblk);
     const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
     const int p0 = a.row_ptr[r0], p1 = a.row_ptr[r1];
@@ -158,9 +176,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
             double t = lds[0];
 #pragma unroll
             for (int w = 1; w < BLOCK / 64; ++w) t += lds[w];
-            const int r = a.rows ? a.rows[r0] : r0;
-            if (a.rows) epilogue_remote<EPI>(a, r, t); else epilogue<EPI>(a, r, t);
+            epilogue<EPI>(a, r0, t);
         }
+        join_wait(a);
         return;
     }
 
@@ -235,9 +253,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
         for (int k = s + l; k < e; k += G) sum += lds[k];
         sum = group_sum<G>(sum);
         if (l == 0) {
-            if (a.rows) epilogue_remote<EPI>(a, a.rows[r], sum); else epilogue<EPI>(a, r, sum);
+            epilogue<EPI>(a, r, sum);
         }
     }
+    join_wait(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -255,6 +274,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
     __shared__ __attribute__((aligned(16))) double lds[LDSN];
     __shared__ int seg[16];
     const int tid = threadIdx.x;
+    fork_signal(a);
     const int b   = xcd_remap(blockIdx.x, a.nblk);
     const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
     const int p0 = a.row_ptr[r0], p1 = a.row_ptr[r1];
@@ -348,9 +368,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
         for (int k = s + l; k < e; k += G) sum += lds[k];
         sum = group_sum<G>(sum);
         if (l == 0) {
-            if (a.rows) epilogue_remote<EPI>(a, a.rows[r], sum); else epilogue<EPI>(a, r, sum);
+            epilogue<EPI>(a, r, sum);
         }
     }
+    join_wait(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -361,6 +382,7 @@ template <int EPI, int G>
 __global__ __launch_bounds__(BLOCK) void k_csr_vector(const SpmvArgs a, int nrows) {
     constexpr int RPB = BLOCK / G;
     const int nb = (nrows + RPB - 1) / RPB;
+    fork_signal(a);
     const int b = xcd_remap(blockIdx.x, nb);
     const int tid = threadIdx.x;
     const int r = b * RPB + tid / G, l = tid % G;
@@ -378,33 +400,84 @@ __global__ __launch_bounds__(BLOCK) void k_csr_vector(const SpmvArgs a, int nrow
     }
     sum = group_sum<G>(sum);
     if (r < nrows && l == 0) {
-        if (a.rows) epilogue_remote<EPI>(a, a.rows[r], sum); else epilogue<EPI>(a, r, sum);
+        epilogue<EPI>(a, r, sum);
     }
+    join_wait(a);
 }
 
 // ---------------------------------------------------------------------------
-// K3: halo pack, vSend[i] = v[vIndex[i]] (optionally rounded through float, the
-// reference's matvec_sparse_float halo)
-__global__ __launch_bounds__(BLOCK) void k_pack(const double *__restrict__ v, const int *__restrict__ vIndex,
-                                                double *__restrict__ send, int n, int as_float) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) {
-        double t = v[vIndex[i]];
+// K2: boundary rows.  Rows that own remote entries are left out of the interior launch (SpmvArgs::skip)
+// and computed whole by this kernel on the halo stream, after the exchange: G lanes own one row, add its
+// local products (x) and then its remote products (halo buffer, ascending receive position = the order of
+// the reference's remote loop, src/saena_matrix_matvec.cpp:93-109) and apply the epilogue once.  With
+// G = 1 that is the reference's sum: the local loop first, the remote contributions after it.  Interior
+// and boundary launches touch disjoint rows, so they need no ordering between the two streams.
+struct BoundaryArgs {
+    SpmvArgs      s;         // the local CSR (row_ptr/col/val), x and the epilogue operands; skip == nullptr
+    const int    *rows;      // [nrows] boundary rows, ascending
+    int           nrows;
+    const int    *h_ptr;     // [nrows+1] CSR over the halo buffer, one row per boundary row
+    const int    *h_col;     // position in the receive buffer
+    const double *h_val;
+    const double *halo;      // receive buffer (fp64 wire)
+    const float  *halo_f;    // receive buffer of the fp32 wire (matvec_sparse_float), or nullptr
+};
+
+template <int EPI, int G>
+__global__ __launch_bounds__(BLOCK) void k_csr_boundary(const BoundaryArgs b) {
+    constexpr int RPB = BLOCK / G;
+    const int i = blockIdx.x * RPB + threadIdx.x / G, l = threadIdx.x % G;
+    double sum = 0.0;
+    int r = 0;
+    if (i < b.nrows) {
+        r = b.rows[i];
+        const int p1 = b.s.row_ptr[r + 1];
+        for (int k = b.s.row_ptr[r] + l; k < p1; k += G) sum += b.s.val[k] * b.s.x[b.s.col[k]];
+        const int q1 = b.h_ptr[i + 1];
+        if (b.halo_f) {
+            for (int k = b.h_ptr[i] + l; k < q1; k += G) sum += b.h_val[k] * (double)b.halo_f[b.h_col[k]];
+        } else {
+            for (int k = b.h_ptr[i] + l; k < q1; k += G) sum += b.h_val[k] * b.halo[b.h_col[k]];
+        }
+    }
+    sum = group_sum<G>(sum);
+    if (i < b.nrows && l == 0) epilogue<EPI>(b.s, r, sum);
+}
+
+// ---------------------------------------------------------------------------
+// K3: halo pack, vSend[i] = v[vIndex[i]] (optionally rounded through float, the reference's
+// matvec_sparse_float halo).  Grid-stride over at most PACK_MAX_BLOCKS blocks: with `flag` set every block
+// first waits for *flag >= seq (the interior launch has started, i.e. v is final), so the number of
+// blocks that can sit waiting on the GPU must stay far below what the chip can hold.
+constexpr int PACK_MAX_BLOCKS = 128;
+__global__ __launch_bounds__(BLOCK) void k_pack(const double *v, const int *__restrict__ vIndex, double *__restrict__ send, int n,
+                                                int as_float, const uint64_t *flag, uint64_t seq) {
+    block_wait_flag(flag, seq);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        double t = flag ? coherent_load(v + vIndex[i]) : v[vIndex[i]];
         if (as_float) t = (double)(float)t;
         send[i] = t;
     }
 }
 
-// fp32 halo on the wire (matvec_sparse_float, saena_matrix_matvec.cpp:464,531,538): pack straight to float,
-// widen the received floats back to double before the remote part reads them
-__global__ __launch_bounds__(BLOCK) void k_pack_f32(const double *__restrict__ v, const int *__restrict__ vIndex,
-                                                    float *__restrict__ send, int n) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) send[i] = (float)v[vIndex[i]];
+// fp32 halo on the wire (matvec_sparse_float, saena_matrix_matvec.cpp:464,531,538): pack straight to float;
+// k_csr_boundary widens the received floats as it reads them
+__global__ __launch_bounds__(BLOCK) void k_pack_f32(const double *v, const int *__restrict__ vIndex, float *__restrict__ send, int n,
+                                                    const uint64_t *flag, uint64_t seq) {
+    block_wait_flag(flag, seq);
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        send[i] = (float)(flag ? coherent_load(v + vIndex[i]) : v[vIndex[i]]);
 }
-__global__ __launch_bounds__(BLOCK) void k_widen_f32(const float *__restrict__ in, double *__restrict__ out, int n) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) out[i] = (double)in[i];
+
+// one-wave helpers.  k_flag_set follows the boundary launch on the halo stream: the kernel boundary releases the
+// boundary rows once (a last-block ticket inside k_csr_boundary needs an L2 write-back per block: 40 us for 992
+// blocks, measured).  k_flag_wait serves a receive-only rank, which has no pack launch to do the waiting.
+__global__ void k_flag_wait(const uint64_t *flag, uint64_t seq) {
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) __builtin_amdgcn_s_sleep(32);
+}
+__global__ void k_flag_set(uint64_t *flag, uint64_t seq) {
+    if (threadIdx.x == 0) (void)__hip_atomic_exchange(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------

@@ -61,6 +61,14 @@ struct Ctx {
     int        *dint = nullptr;       // device int scratch (coarse CG iterations, barrier)
     int        *hint = nullptr;       // pinned
     int         n_partials = 1024;
+    // cross-stream dependencies cs <-> hs of the halo exchange.  hipStreamWriteValue64 / hipStreamWaitValue64 on
+    // signal memory cost ~5 us per hop on the GPU, an event record + wait ~11 us (tools/hop_bench.hip,
+    // profiles/r01_hop_bench.log); events remain the fallback where the stream memory operations are unavailable.
+    uint64_t   *flag_x = nullptr, *flag_h = nullptr;
+    uint64_t    seq = 0;
+    bool        value_ops = false;
+    bool        inkernel_sync = false;   // fork/join folded into the interior / pack / boundary kernels (no extra launches)
+    uint64_t   *kflag_x = nullptr, *kflag_h = nullptr;   // their flags: device memory, one cache line each
 };
 Ctx g;
 
@@ -197,11 +205,13 @@ struct sgpu_op {
     int     halo_fp32 = 0;
     bool    injected = false;     // test hook: halo supplied by sgpu_debug_inject_halo
     std::vector<double> h_val;   // host copy of the values of small local parts (coarsest-level factorisation)
-    hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
+    unsigned *skip = nullptr;     // bitmask over the M rows: set = boundary row (has remote entries), written by k_csr_boundary
+    int     bnd_lanes = 1;        // lanes per boundary row
+    hipEvent_t ev_x = nullptr, ev_halo = nullptr;   // cs -> hs: inputs ready; hs -> cs: exchange + boundary rows done
     ~sgpu_op() {                  // also runs when sgpu_op_create bails out half-way: nothing leaks
         loc.free_all(); rem.free_all();
-        hipFree(inv_diag); hipFree(tmp); hipFree(dvec); hipFree(vIndex); hipFree(send_buf); hipFree(recv_buf); hipFree(send_f); hipFree(recv_f);
-        if (ev_packed) hipEventDestroy(ev_packed);
+        hipFree(skip); hipFree(inv_diag); hipFree(tmp); hipFree(dvec); hipFree(vIndex); hipFree(send_buf); hipFree(recv_buf); hipFree(send_f); hipFree(recv_f);
+        if (ev_x) hipEventDestroy(ev_x);
         if (ev_halo) hipEventDestroy(ev_halo);
     }
 };
@@ -271,12 +281,14 @@ struct EpiArgs {
     double        c0 = 0.0, c1 = 0.0;
 };
 
-int launch_part(const CsrPart &P, int epi, const double *x, double *y, const EpiArgs &e) {
+// seq != 0: the launch carries the fork (flag_x = seq at its start) and the join (does not finish before flag_h >= seq)
+int launch_part(const CsrPart &P, int epi, const double *x, double *y, const EpiArgs &e, const unsigned *skip = nullptr, uint64_t seq = 0) {
     if (P.nblk == 0) return SGPU_OK;
     sk::SpmvArgs a;
+    a.flag_x = seq ? g.kflag_x : nullptr; a.flag_h = seq ? g.kflag_h : nullptr; a.seq = seq;
     a.row_ptr = P.row_ptr; a.col = P.col; a.val = P.val;
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
-    a.c0 = e.c0; a.c1 = e.c1; a.rows = P.rows;
+    a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.ccol = nullptr;
     if (P.variant == 3 || P.variant == 4) {                       // 16-bit compressed columns
         const int k = P.variant - 3;
@@ -299,48 +311,128 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     return SGPU_OK;
 }
 
-// Start the halo exchange of x on the halo stream (pack on cs, send/recv on hs).
-int halo_begin(sgpu_op *op, const double *x) {
-    if (!g.comm || op->injected || (op->vIndexSize == 0 && op->recvSize == 0)) return SGPU_OK;
-    // both ends of a link must agree on the wire type, so it depends on the flag alone (a rank that only
-    // sends, or only receives, has just one of the two fp32 buffers)
-    const bool f32 = op->halo_fp32 != 0;
-    if (op->vIndexSize) {
-        const dim3 grid((op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK);
-        if (f32) hipLaunchKernelGGL(sk::k_pack_f32, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_f, op->vIndexSize);
-        else hipLaunchKernelGGL(sk::k_pack, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_buf, op->vIndexSize, op->halo_fp32);
-        HIPCHK(hipGetLastError());
+using BndKernelFn = void (*)(const sk::BoundaryArgs);
+template <int EPI>
+BndKernelFn pick_bnd_g(int lanes) {
+    switch (lanes) {
+        case 1:  return sk::k_csr_boundary<EPI, 1>;
+        case 2:  return sk::k_csr_boundary<EPI, 2>;
+        case 4:  return sk::k_csr_boundary<EPI, 4>;
+        case 8:  return sk::k_csr_boundary<EPI, 8>;
+        case 16: return sk::k_csr_boundary<EPI, 16>;
+        case 32: return sk::k_csr_boundary<EPI, 32>;
+        default: return sk::k_csr_boundary<EPI, 64>;
     }
-    HIPCHK(hipEventRecord(op->ev_packed, g.cs));
-    HIPCHK(hipStreamWaitEvent(g.hs, op->ev_packed, 0));
-    NCCLCHK(ncclGroupStart());
-    for (size_t i = 0; i < op->sendRank.size(); ++i) {
-        if (f32) NCCLCHK(ncclSend(op->send_f + op->sendDispl[i], (size_t)op->sendCount[i], ncclFloat, op->sendRank[i], g.comm, g.hs));
-        else NCCLCHK(ncclSend(op->send_buf + op->sendDispl[i], (size_t)op->sendCount[i], ncclDouble, op->sendRank[i], g.comm, g.hs));
+}
+BndKernelFn pick_bnd(int epi, int lanes) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return pick_bnd_g<sk::EPI_SPMV>(lanes);
+        case sk::EPI_RESIDUAL: return pick_bnd_g<sk::EPI_RESIDUAL>(lanes);
+        case sk::EPI_JACOBI:   return pick_bnd_g<sk::EPI_JACOBI>(lanes);
+        case sk::EPI_CHEBY0:   return pick_bnd_g<sk::EPI_CHEBY0>(lanes);
+        case sk::EPI_CHEBYK:   return pick_bnd_g<sk::EPI_CHEBYK>(lanes);
+        default:               return pick_bnd_g<sk::EPI_SUB>(lanes);
     }
-    for (size_t i = 0; i < op->recvRank.size(); ++i) {
-        if (f32) NCCLCHK(ncclRecv(op->recv_f + op->recvDispl[i], (size_t)op->recvCount[i], ncclFloat, op->recvRank[i], g.comm, g.hs));
-        else NCCLCHK(ncclRecv(op->recv_buf + op->recvDispl[i], (size_t)op->recvCount[i], ncclDouble, op->recvRank[i], g.comm, g.hs));
-    }
-    NCCLCHK(ncclGroupEnd());
-    HIPCHK(hipEventRecord(op->ev_halo, g.hs));
+}
+
+// The rows that own remote entries, computed whole (local + halo products, one epilogue) on `stream`.
+int launch_boundary(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e, bool halo_is_f32, hipStream_t stream) {
+    if (op->rem.nrows == 0) return SGPU_OK;
+    sk::BoundaryArgs b;
+    b.s.flag_x = nullptr; b.s.flag_h = nullptr; b.s.seq = 0;
+    b.s.row_ptr = op->loc.row_ptr; b.s.col = op->loc.col; b.s.val = op->loc.val; b.s.blk_row = nullptr; b.s.nblk = 0;
+    b.s.x = x; b.s.y = y; b.s.rhs = e.rhs; b.s.inv_diag = e.inv_diag; b.s.u = e.u; b.s.d = e.d; b.s.c0 = e.c0; b.s.c1 = e.c1;
+    b.s.skip = nullptr; b.s.segtab = nullptr; b.s.ccol = nullptr;
+    b.rows = op->rem.rows; b.nrows = op->rem.nrows;
+    b.h_ptr = op->rem.row_ptr; b.h_col = op->rem.col; b.h_val = op->rem.val;
+    b.halo = op->recv_buf; b.halo_f = halo_is_f32 ? op->recv_f : nullptr;
+    const int rpb = sk::BLOCK / op->bnd_lanes;
+    hipLaunchKernelGGL(pick_bnd(epi, op->bnd_lanes), dim3((b.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, stream, b);
+    HIPCHK(hipGetLastError());
     return SGPU_OK;
 }
 
-// y = epi(A x): halo on hs || local part on cs, then the remote correction.
+// y = epi(A x).  With a communicator the two streams split the ROWS, not the phases:
+//   cs (compute): interior rows -- every row without remote entries -- straight away;
+//   hs (halo):    wait for the inputs (ev_x) -> pack -> ncclSend/ncclRecv group -> boundary rows whole;
+//   cs joins hs (ev_halo) before anything later on cs can see y or reuse x.
+// The exchange chain has no event hop in its middle (each hop costs ~10 us on this stack, see
+// profiles/r01_halo_loopback_trace.md) and the interior launch never waits for it: this is where the
+// reference overlaps MPI_Isend/Irecv with its local loop (src/saena_matrix_matvec.cpp:32-80).
 int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
-    CHK(halo_begin(op, x));
-    CHK(launch_part(op->loc, epi, x, y, e));
     const bool exchanged = g.comm && !op->injected && (op->vIndexSize || op->recvSize);
-    // cs joins the exchange even on a rank that only sends: the next pack must not overwrite a send buffer in flight
-    if (exchanged) HIPCHK(hipStreamWaitEvent(g.cs, op->ev_halo, 0));
-    if (op->has_remote && (g.comm || op->injected)) {
-        if (exchanged && op->halo_fp32 && op->recvSize) {   // half the bytes crossed xGMI; widen for the remote part
-            hipLaunchKernelGGL(sk::k_widen_f32, dim3((op->recvSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
-                               op->recv_f, op->recv_buf, op->recvSize);
+    if (!exchanged) {
+        if (op->has_remote && op->injected) {           // halo supplied by the caller (tests): same kernels, one stream
+            CHK(launch_part(op->loc, epi, x, y, e, op->skip));
+            return launch_boundary(op, epi, x, y, e, false, g.cs);
+        }
+        return launch_part(op->loc, epi, x, y, e);      // no communicator: the local part is the whole operator
+    }
+    const bool f32 = op->halo_fp32 != 0;                 // both ends of a link must agree: the flag alone decides the wire type
+    const uint64_t n = ++g.seq;
+    const unsigned *skip = op->has_remote ? op->skip : nullptr;
+    // Three ways to express the two dependencies (fork: hs after cs's earlier work; join: cs after hs), fastest first:
+    //  K  folded into the kernels: the interior launch stores flag_x = n when it starts and does not finish before
+    //     flag_h >= n; pack waits for flag_x; the boundary kernel's last block stores flag_h.  No extra launches.
+    //  V  hipStreamWriteValue64 / hipStreamWaitValue64 (each is a ~4 us helper launch, ~5 us per hop)
+    //  E  events (~11 us per hop)
+    // In every mode a wait is enqueued only AFTER its matching write, so no stream is left waiting for nothing;
+    // after the K-mode interior launch every error path still publishes flag_h.
+    const bool K = g.inkernel_sync && op->loc.nblk > 0;
+    const bool V = g.value_ops;
+    if (K) {
+        CHK(launch_part(op->loc, epi, x, y, e, skip, n));
+    } else {
+        if (V) HIPCHK(hipStreamWriteValue64(g.cs, g.flag_x, n, 0));
+        else HIPCHK(hipEventRecord(op->ev_x, g.cs));
+        CHK(launch_part(op->loc, epi, x, y, e, skip));
+    }
+    auto hs_chain = [&]() -> int {
+        const bool pack_waits = K && op->vIndexSize > 0;
+        if (K && !pack_waits) {
+            hipLaunchKernelGGL(sk::k_flag_wait, dim3(1), dim3(64), 0, g.hs, (const uint64_t *)g.kflag_x, n);
+            HIPCHK(hipGetLastError());
+        } else if (!K) {
+            if (V) HIPCHK(hipStreamWaitValue64(g.hs, g.flag_x, n, hipStreamWaitValueGte, ~0ull));
+            else HIPCHK(hipStreamWaitEvent(g.hs, op->ev_x, 0));
+        }
+        if (op->vIndexSize) {
+            const dim3 grid(std::min(sk::PACK_MAX_BLOCKS, (op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK));
+            const uint64_t *flag = pack_waits ? g.kflag_x : nullptr;
+            if (f32) hipLaunchKernelGGL(sk::k_pack_f32, grid, dim3(sk::BLOCK), 0, g.hs, x, op->vIndex, op->send_f, op->vIndexSize, flag, n);
+            else hipLaunchKernelGGL(sk::k_pack, grid, dim3(sk::BLOCK), 0, g.hs, x, op->vIndex, op->send_buf, op->vIndexSize, 0, flag, n);
             HIPCHK(hipGetLastError());
         }
-        CHK(launch_part(op->rem, epi, op->recv_buf, y, e));
+        NCCLCHK(ncclGroupStart());
+        for (size_t i = 0; i < op->sendRank.size(); ++i) {
+            if (f32) NCCLCHK(ncclSend(op->send_f + op->sendDispl[i], (size_t)op->sendCount[i], ncclFloat, op->sendRank[i], g.comm, g.hs));
+            else NCCLCHK(ncclSend(op->send_buf + op->sendDispl[i], (size_t)op->sendCount[i], ncclDouble, op->sendRank[i], g.comm, g.hs));
+        }
+        for (size_t i = 0; i < op->recvRank.size(); ++i) {
+            if (f32) NCCLCHK(ncclRecv(op->recv_f + op->recvDispl[i], (size_t)op->recvCount[i], ncclFloat, op->recvRank[i], g.comm, g.hs));
+            else NCCLCHK(ncclRecv(op->recv_buf + op->recvDispl[i], (size_t)op->recvCount[i], ncclDouble, op->recvRank[i], g.comm, g.hs));
+        }
+        NCCLCHK(ncclGroupEnd());
+        if (op->has_remote) CHK(launch_boundary(op, epi, x, y, e, f32, g.hs));
+        return SGPU_OK;
+    };
+    const int st = hs_chain();
+    // join: nothing later on cs may see y (or overwrite x and the send buffers) before hs is through
+    if (K) {
+        // publish flag_h behind whatever reached hs -- also on an error path: the interior launch is waiting for it
+        const std::string keep = g_err;
+        hipLaunchKernelGGL(sk::k_flag_set, dim3(1), dim3(64), 0, g.hs, g.kflag_h, n);
+        if (hipGetLastError() != hipSuccess && st == SGPU_OK) return fail(SGPU_ERR_HIP, "k_flag_set launch failed");
+        g_err = keep;
+        return st;
+    }
+    CHK(st);
+    if (V) {
+        HIPCHK(hipStreamWriteValue64(g.hs, g.flag_h, n, 0));
+        HIPCHK(hipStreamWaitValue64(g.cs, g.flag_h, n, hipStreamWaitValueGte, ~0ull));
+    } else {
+        HIPCHK(hipEventRecord(op->ev_halo, g.hs));
+        HIPCHK(hipStreamWaitEvent(g.cs, op->ev_halo, 0));
     }
     return SGPU_OK;
 }
@@ -435,12 +527,36 @@ int sgpu_init(int device_id, int rank, int nranks, const void *uid) {
     HIPCHK(hipSetDevice(device_id));
     g.device = device_id; g.rank = rank; g.nranks = nranks;
     HIPCHK(hipStreamCreateWithFlags(&g.cs, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&g.hs, hipStreamNonBlocking));
+    {   // the halo stream's small kernels (pack, RCCL, boundary rows) must not queue behind the interior launch
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int prio = std::getenv("SAENA_HALO_STREAM_PRIORITY") ? std::atoi(std::getenv("SAENA_HALO_STREAM_PRIORITY")) : greatest;
+        HIPCHK(hipStreamCreateWithPriority(&g.hs, hipStreamNonBlocking, prio));
+    }
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&g.partials), g.n_partials * sizeof(double)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&g.dscalar), 16 * sizeof(double)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&g.hscalar), 16 * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&g.dint), 16 * sizeof(int)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&g.hint), 16 * sizeof(int), hipHostMallocDefault));
+    if (!std::getenv("SAENA_NO_STREAM_VALUE_OPS") &&
+        hipExtMallocWithFlags(reinterpret_cast<void **>(&g.flag_x), 8, hipMallocSignalMemory) == hipSuccess &&
+        hipExtMallocWithFlags(reinterpret_cast<void **>(&g.flag_h), 8, hipMallocSignalMemory) == hipSuccess &&
+        hipStreamWriteValue64(g.cs, g.flag_x, 0, 0) == hipSuccess && hipStreamWriteValue64(g.hs, g.flag_h, 0, 0) == hipSuccess &&
+        hipStreamWaitValue64(g.hs, g.flag_x, 0, hipStreamWaitValueGte, ~0ull) == hipSuccess &&
+        hipStreamSynchronize(g.cs) == hipSuccess && hipStreamSynchronize(g.hs) == hipSuccess) {
+        g.value_ops = true;
+    } else {
+        (void)hipGetLastError();
+        if (g.flag_x) { hipFree(g.flag_x); g.flag_x = nullptr; }
+        if (g.flag_h) { hipFree(g.flag_h); g.flag_h = nullptr; }
+    }
+    if (!std::getenv("SAENA_NO_INKERNEL_SYNC")) {
+        char *fl = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&fl), 512));
+        HIPCHK(hipMemset(fl, 0, 512));
+        g.kflag_x = reinterpret_cast<uint64_t *>(fl); g.kflag_h = reinterpret_cast<uint64_t *>(fl + 128);
+        g.inkernel_sync = true;
+    }
     if (uid) {      // also with one rank when an id is given: the RCCL paths (self send/recv included) then run for real
         ncclUniqueId id;
         memcpy(&id, uid, sizeof id);
@@ -455,6 +571,9 @@ int sgpu_finalize(void) {
     hipDeviceSynchronize();
     if (g.comm) { ncclCommDestroy(g.comm); g.comm = nullptr; }
     hipFree(g.partials); hipFree(g.dscalar); hipHostFree(g.hscalar); hipFree(g.dint); hipHostFree(g.hint);
+    if (g.flag_x) hipFree(g.flag_x);
+    if (g.flag_h) hipFree(g.flag_h);
+    if (g.kflag_x) hipFree(g.kflag_x);
     hipStreamDestroy(g.cs); hipStreamDestroy(g.hs);
     g = Ctx();
     return SGPU_OK;
@@ -584,6 +703,19 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
             }
         CHK(build_part(op->rem, rp, col, val, &rows));
         op->has_remote = true;
+        // boundary rows: masked out of the interior launch, computed whole by k_csr_boundary
+        std::vector<unsigned> mask(((size_t)d->M + 31) / 32, 0u);
+        long len = d->nnz_l_remote;
+        for (int r : rows) { mask[(size_t)r >> 5] |= 1u << (r & 31); len += d->nnzPerRow_local[r]; }
+        CHK(dev_upload(&op->skip, mask.data(), mask.size()));
+        // lanes per boundary row: about one lane per entry (a G-lane group then reads its row as one coalesced
+        // segment; one lane per 7-entry row made the launch 2.5x slower).  SAENA_BOUNDARY_LANES=1 restores the
+        // reference's sequential per-row sum on these rows.
+        const long avg = len / (long)rows.size();
+        int gl = 1;
+        while (gl < avg && gl < 64) gl *= 2;
+        if (const char *bl = std::getenv("SAENA_BOUNDARY_LANES")) gl = std::max(1, std::min(64, pow2floor(std::atoi(bl))));
+        op->bnd_lanes = gl;
     }
     if (d->inv_diag) CHK(dev_upload(&op->inv_diag, d->inv_diag, (size_t)d->M));
 
@@ -623,8 +755,9 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         if (op->vIndexSize) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->send_f), (size_t)op->vIndexSize * sizeof(float)));
         if (op->recvSize) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->recv_f), (size_t)op->recvSize * sizeof(float)));
     }
-    HIPCHK(hipEventCreateWithFlags(&op->ev_packed, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&op->ev_halo, hipEventDisableTiming));
+    // same-device dependencies only: no system-scope fence needed (saves ~2 us per hop, tools/hop_bench.hip)
+    HIPCHK(hipEventCreateWithFlags(&op->ev_x, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIPCHK(hipEventCreateWithFlags(&op->ev_halo, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK(hipStreamSynchronize(g.cs));
     *out = op.release();
     return SGPU_OK;
@@ -769,7 +902,7 @@ int sgpu_debug_pack(sgpu_op *op, const value_t *v, value_t *send_host) {
     if (!op || !v) return fail(SGPU_ERR_ARG, "null argument");
     if (op->vIndexSize == 0) return SGPU_OK;
     hipLaunchKernelGGL(sk::k_pack, dim3((op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
-                       v, op->vIndex, op->send_buf, op->vIndexSize, op->halo_fp32);
+                       v, op->vIndex, op->send_buf, op->vIndexSize, op->halo_fp32, (const uint64_t *)nullptr, (uint64_t)0);
     HIPCHK(hipGetLastError());
     return sgpu_vec_download(send_host, op->send_buf, (size_t)op->vIndexSize);
 }

@@ -57,7 +57,15 @@ def main():
                 print(f"  [{p} {label}] one spmv done", flush=True)
             op.time_kernel(0, x, None, y, 20)
             us = op.time_kernel(0, x, None, y, 300) * 1e3
-            line += f" | {label}: {us:7.2f} us"
+            import time
+            capi.check(capi.lib().sgpu_device_sync())
+            t0 = time.perf_counter()
+            for _ in range(300):
+                op.spmv(x, y)
+            t_enq = (time.perf_counter() - t0) / 300 * 1e6          # host time to ENQUEUE one SpMV (no sync)
+            capi.check(capi.lib().sgpu_device_sync())
+            t_all = (time.perf_counter() - t0) / 300 * 1e6
+            line += f" | {label}: {us:7.2f} us (host enqueue {t_enq:.1f}, drained {t_all:.1f})"
             if label == "local only":
                 line = f"{line} ({M} rows, halo 2 x {nhalo // 2} doubles)"
             op.destroy()
