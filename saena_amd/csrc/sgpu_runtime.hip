@@ -1,9 +1,10 @@
 // sgpu_runtime.hip -- C ABI (include/saena_gpu.h) over the gfx950 kernels.
 //
-// One process = one rank = one MI355X.  Two HIP streams per rank: `cs` runs
-// the kernels, `hs` carries the x-vector halo (RCCL send/recv over xGMI) so the
-// exchange overlaps the local SpMV exactly where the reference overlaps
-// MPI_Isend/Irecv with its local loop (src/saena_matrix_matvec.cpp:32-80).
+// One process = one rank = one MI355X.  Two HIP streams per rank: `cs` runs the
+// interior rows of every operator, `hs` carries the x-vector halo (pack, RCCL
+// send/recv over xGMI) and then computes the boundary rows, so the exchange
+// overlaps the local SpMV exactly where the reference overlaps MPI_Isend/Irecv
+// with its local loop (src/saena_matrix_matvec.cpp:32-80).  See apply().
 #include "../../include/saena_gpu.h"
 #include "kernels.hip.h"
 #include "host/comm.h"
