@@ -98,9 +98,12 @@ __device__ __forceinline__ void block_wait_flag(const uint64_t *flag, uint64_t s
 __device__ __forceinline__ double coherent_load(const double *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int EPI>
+// HALO = the launch is the interior half of a multi-rank apply (row mask + in-kernel fork/join); the
+// single-rank instantiations carry none of that code (it cost 1 % of the fine-level SpMV when it was a run-time test)
+template <int EPI, bool HALO>
 __device__ __forceinline__ void epilogue(const SpmvArgs &a, int r, double s) {
-    if (a.skip && ((a.skip[r >> 5] >> (r & 31)) & 1u)) return;     // a boundary row: the halo stream's kernel writes it
+    if constexpr (HALO)
+        if (a.skip && ((a.skip[r >> 5] >> (r & 31)) & 1u)) return;  // a boundary row: the halo stream's kernel writes it
     if constexpr (EPI == EPI_SPMV) {
         a.y[r] = s;
     } else if constexpr (EPI == EPI_RESIDUAL) {
@@ -156,12 +159,12 @@ __device__ __forceinline__ double group_sum(double v) {
 // 16-bit ids on the 67-nnz/row level: the extra dependent phase costs more than the saved gather lanes), and a
 // persistent workgroup that prefetches the next block's stream during the reduce (-20 %: eight independent
 // one-shot blocks per CU overlap better than a hand-pipelined loop with two barriers per block).
-template <int EPI, int G, int CAPV>
+template <int EPI, int G, int CAPV, bool HALO>
 __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
     constexpr int LDSN = CAPV + 8;
     __shared__ __attribute__((aligned(16))) double lds[LDSN];
     const int tid = threadIdx.x;
-    fork_signal(a);
+    if constexpr (HALO) fork_signal(a);
     const int b   = xcd_remap(blockIdx.x, a.nblk);
     const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
     const int p0 = a.row_ptr[r0], p1 = a.row_ptr[r1];
@@ -176,9 +179,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
             double t = lds[0];
 #pragma unroll
             for (int w = 1; w < BLOCK / 64; ++w) t += lds[w];
-            epilogue<EPI>(a, r0, t);
+            epilogue<EPI, HALO>(a, r0, t);
         }
-        join_wait(a);
+        if constexpr (HALO) join_wait(a);
         return;
     }
 
@@ -253,10 +256,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
         for (int k = s + l; k < e; k += G) sum += lds[k];
         sum = group_sum<G>(sum);
         if (l == 0) {
-            epilogue<EPI>(a, r, sum);
+            epilogue<EPI, HALO>(a, r, sum);
         }
     }
-    join_wait(a);
+    if constexpr (HALO) join_wait(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -268,13 +271,13 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
 // Arithmetic and summation order are those of k_csr_stream (bit-identical results).
 __device__ __forceinline__ bool stray(int k, int p0, int p1) { return k < p0 || k >= p1; }
 
-template <int EPI, int G, int CAPV>
+template <int EPI, int G, int CAPV, bool HALO>
 __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
     constexpr int LDSN = CAPV + 8;
     __shared__ __attribute__((aligned(16))) double lds[LDSN];
     __shared__ int seg[16];
     const int tid = threadIdx.x;
-    fork_signal(a);
+    if constexpr (HALO) fork_signal(a);
     const int b   = xcd_remap(blockIdx.x, a.nblk);
     const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
     const int p0 = a.row_ptr[r0], p1 = a.row_ptr[r1];
@@ -368,21 +371,21 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
         for (int k = s + l; k < e; k += G) sum += lds[k];
         sum = group_sum<G>(sum);
         if (l == 0) {
-            epilogue<EPI>(a, r, sum);
+            epilogue<EPI, HALO>(a, r, sum);
         }
     }
-    join_wait(a);
+    if constexpr (HALO) join_wait(a);
 }
 
 // ---------------------------------------------------------------------------
 // K1b: vector CSR (no LDS staging): G lanes own one row and stream it straight from
 // global memory, 256/G rows per workgroup.  Rows are contiguous in val/col, so a
 // wave still reads whole 128-B lines; there is no barrier and no LDS round trip.
-template <int EPI, int G>
+template <int EPI, int G, bool HALO>
 __global__ __launch_bounds__(BLOCK) void k_csr_vector(const SpmvArgs a, int nrows) {
     constexpr int RPB = BLOCK / G;
     const int nb = (nrows + RPB - 1) / RPB;
-    fork_signal(a);
+    if constexpr (HALO) fork_signal(a);
     const int b = xcd_remap(blockIdx.x, nb);
     const int tid = threadIdx.x;
     const int r = b * RPB + tid / G, l = tid % G;
@@ -400,9 +403,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_vector(const SpmvArgs a, int nrow
     }
     sum = group_sum<G>(sum);
     if (r < nrows && l == 0) {
-        epilogue<EPI>(a, r, sum);
+        epilogue<EPI, HALO>(a, r, sum);
     }
-    join_wait(a);
+    if constexpr (HALO) join_wait(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_boundary(const BoundaryArgs b) {
         }
     }
     sum = group_sum<G>(sum);
-    if (i < b.nrows && l == 0) epilogue<EPI>(b.s, r, sum);
+    if (i < b.nrows && l == 0) epilogue<EPI, false>(b.s, r, sum);
 }
 
 // ---------------------------------------------------------------------------

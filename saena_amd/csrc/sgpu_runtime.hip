@@ -222,59 +222,63 @@ namespace {
 using KernelFn = void (*)(const sk::SpmvArgs);
 using VecKernelFn = void (*)(const sk::SpmvArgs, int);
 
-// kernel family F: 0 k_csr_stream, 1 k_csr_cc16
-template <int F, int EPI, int CAPV, int G>
+// kernel family F: 0 k_csr_stream, 1 k_csr_cc16; H: interior half of a multi-rank apply (kernels.hip.h)
+template <int F, int EPI, int CAPV, int G, bool H>
 constexpr KernelFn kernel_of() {
-    if constexpr (F == 0) return sk::k_csr_stream<EPI, G, CAPV>;
-    else return sk::k_csr_cc16<EPI, G, CAPV>;
+    if constexpr (F == 0) return sk::k_csr_stream<EPI, G, CAPV, H>;
+    else return sk::k_csr_cc16<EPI, G, CAPV, H>;
 }
-template <int F, int EPI, int CAPV>
+template <int F, int EPI, int CAPV, bool H>
 KernelFn pick_g(int lanes) {
     switch (lanes) {
-        case 1:  return kernel_of<F, EPI, CAPV, 1>();
-        case 2:  return kernel_of<F, EPI, CAPV, 2>();
-        case 4:  return kernel_of<F, EPI, CAPV, 4>();
-        case 8:  return kernel_of<F, EPI, CAPV, 8>();
-        case 16: return kernel_of<F, EPI, CAPV, 16>();
-        case 32: return kernel_of<F, EPI, CAPV, 32>();
-        default: return kernel_of<F, EPI, CAPV, 64>();
+        case 1:  return kernel_of<F, EPI, CAPV, 1, H>();
+        case 2:  return kernel_of<F, EPI, CAPV, 2, H>();
+        case 4:  return kernel_of<F, EPI, CAPV, 4, H>();
+        case 8:  return kernel_of<F, EPI, CAPV, 8, H>();
+        case 16: return kernel_of<F, EPI, CAPV, 16, H>();
+        case 32: return kernel_of<F, EPI, CAPV, 32, H>();
+        default: return kernel_of<F, EPI, CAPV, 64, H>();
     }
 }
-template <int F, int EPI>
-KernelFn pick_cap(int lanes, bool big) { return big ? pick_g<F, EPI, sk::CAP_BIG>(lanes) : pick_g<F, EPI, sk::CAP>(lanes); }
-template <int F>
-KernelFn pick(int epi, int lanes, bool big) {
+template <int F, int EPI, bool H>
+KernelFn pick_cap(int lanes, bool big) { return big ? pick_g<F, EPI, sk::CAP_BIG, H>(lanes) : pick_g<F, EPI, sk::CAP, H>(lanes); }
+template <int F, bool H>
+KernelFn pick_h(int epi, int lanes, bool big) {
     switch (epi) {
-        case sk::EPI_SPMV:     return pick_cap<F, sk::EPI_SPMV>(lanes, big);
-        case sk::EPI_RESIDUAL: return pick_cap<F, sk::EPI_RESIDUAL>(lanes, big);
-        case sk::EPI_JACOBI:   return pick_cap<F, sk::EPI_JACOBI>(lanes, big);
-        case sk::EPI_CHEBY0:   return pick_cap<F, sk::EPI_CHEBY0>(lanes, big);
-        case sk::EPI_CHEBYK:   return pick_cap<F, sk::EPI_CHEBYK>(lanes, big);
-        default:               return pick_cap<F, sk::EPI_SUB>(lanes, big);
+        case sk::EPI_SPMV:     return pick_cap<F, sk::EPI_SPMV, H>(lanes, big);
+        case sk::EPI_RESIDUAL: return pick_cap<F, sk::EPI_RESIDUAL, H>(lanes, big);
+        case sk::EPI_JACOBI:   return pick_cap<F, sk::EPI_JACOBI, H>(lanes, big);
+        case sk::EPI_CHEBY0:   return pick_cap<F, sk::EPI_CHEBY0, H>(lanes, big);
+        case sk::EPI_CHEBYK:   return pick_cap<F, sk::EPI_CHEBYK, H>(lanes, big);
+        default:               return pick_cap<F, sk::EPI_SUB, H>(lanes, big);
     }
 }
-template <int EPI>
+template <int F>
+KernelFn pick(int epi, int lanes, bool big, bool halo) { return halo ? pick_h<F, true>(epi, lanes, big) : pick_h<F, false>(epi, lanes, big); }
+template <int EPI, bool H>
 VecKernelFn pick_vec_g(int lanes) {
     switch (lanes) {
-        case 1:  return sk::k_csr_vector<EPI, 1>;
-        case 2:  return sk::k_csr_vector<EPI, 2>;
-        case 4:  return sk::k_csr_vector<EPI, 4>;
-        case 8:  return sk::k_csr_vector<EPI, 8>;
-        case 16: return sk::k_csr_vector<EPI, 16>;
-        case 32: return sk::k_csr_vector<EPI, 32>;
-        default: return sk::k_csr_vector<EPI, 64>;
+        case 1:  return sk::k_csr_vector<EPI, 1, H>;
+        case 2:  return sk::k_csr_vector<EPI, 2, H>;
+        case 4:  return sk::k_csr_vector<EPI, 4, H>;
+        case 8:  return sk::k_csr_vector<EPI, 8, H>;
+        case 16: return sk::k_csr_vector<EPI, 16, H>;
+        case 32: return sk::k_csr_vector<EPI, 32, H>;
+        default: return sk::k_csr_vector<EPI, 64, H>;
     }
 }
-VecKernelFn pick_vec(int epi, int lanes) {
+template <bool H>
+VecKernelFn pick_vec_h(int epi, int lanes) {
     switch (epi) {
-        case sk::EPI_SPMV:     return pick_vec_g<sk::EPI_SPMV>(lanes);
-        case sk::EPI_RESIDUAL: return pick_vec_g<sk::EPI_RESIDUAL>(lanes);
-        case sk::EPI_JACOBI:   return pick_vec_g<sk::EPI_JACOBI>(lanes);
-        case sk::EPI_CHEBY0:   return pick_vec_g<sk::EPI_CHEBY0>(lanes);
-        case sk::EPI_CHEBYK:   return pick_vec_g<sk::EPI_CHEBYK>(lanes);
-        default:               return pick_vec_g<sk::EPI_SUB>(lanes);
+        case sk::EPI_SPMV:     return pick_vec_g<sk::EPI_SPMV, H>(lanes);
+        case sk::EPI_RESIDUAL: return pick_vec_g<sk::EPI_RESIDUAL, H>(lanes);
+        case sk::EPI_JACOBI:   return pick_vec_g<sk::EPI_JACOBI, H>(lanes);
+        case sk::EPI_CHEBY0:   return pick_vec_g<sk::EPI_CHEBY0, H>(lanes);
+        case sk::EPI_CHEBYK:   return pick_vec_g<sk::EPI_CHEBYK, H>(lanes);
+        default:               return pick_vec_g<sk::EPI_SUB, H>(lanes);
     }
 }
+VecKernelFn pick_vec(int epi, int lanes, bool halo) { return halo ? pick_vec_h<true>(epi, lanes) : pick_vec_h<false>(epi, lanes); }
 
 struct EpiArgs {
     const double *rhs = nullptr, *inv_diag = nullptr, *u = nullptr;
@@ -291,22 +295,23 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.ccol = nullptr;
+    const bool halo = skip != nullptr || seq != 0;
     if (P.variant == 3 || P.variant == 4) {                       // 16-bit compressed columns
         const int k = P.variant - 3;
         if (!P.cc_ok[k]) return fail(SGPU_ERR_STATE, "compressed columns of plan %d were not built", k);
         a.blk_row = k ? P.blk_row_big : P.blk_row;
         a.nblk = k ? P.nblk_big : P.nblk;
         a.segtab = P.segtab[k]; a.ccol = P.ccol[k];
-        hipLaunchKernelGGL(pick<1>(epi, P.lanes, k == 1), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+        hipLaunchKernelGGL(pick<1>(epi, P.lanes, k == 1, halo), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
     } else if (P.variant == 2) {                                  // vector CSR
         const int rpb = sk::BLOCK / P.lanes;
         a.blk_row = nullptr; a.nblk = 0;
-        hipLaunchKernelGGL(pick_vec(epi, P.lanes), dim3((P.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
+        hipLaunchKernelGGL(pick_vec(epi, P.lanes, halo), dim3((P.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
     } else {                                                      // 32-bit columns, 16 / 32 KiB tiles
         const bool big = P.variant == 1;
         a.blk_row = big ? P.blk_row_big : P.blk_row;
         a.nblk = big ? P.nblk_big : P.nblk;
-        hipLaunchKernelGGL(pick<0>(epi, P.lanes, big), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+        hipLaunchKernelGGL(pick<0>(epi, P.lanes, big, halo), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
     }
     HIPCHK(hipGetLastError());
     return SGPU_OK;
