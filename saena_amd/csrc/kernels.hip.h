@@ -517,6 +517,34 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_update(double alpha, const double
     }
 }
 
+// pCG with the scalars kept on the device (no host round trip between the dots and the update):
+// alpha = S[ia] / S[ib]; u -= alpha p; r -= alpha h; partial[block] = sum over the block's elements of the
+// NEW r*r, with k_dot_partial's element-to-thread assignment (launch it with the dot's grid).
+__device__ __forceinline__ double block_sum(double s, double *sh);
+__global__ __launch_bounds__(BLOCK) void k_pcg_update_dev(const double *__restrict__ S, int ia, int ib, const double *__restrict__ p,
+                                                          const double *__restrict__ h, double *__restrict__ u, double *__restrict__ r,
+                                                          size_t n, double *__restrict__ partial) {
+    __shared__ double sh[BLOCK / 64];
+    const double alpha = S[ia] / S[ib];
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        u[i] -= alpha * p[i];
+        const double ri = r[i] - alpha * h[i];
+        r[i] = ri;
+        s += ri * ri;
+    }
+    const double t = block_sum(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+// beta = S[ia] / S[ib]; p = z + beta p        (saena_object_solve.cpp:2655-2667; z = rho, or r for plain CG)
+__global__ __launch_bounds__(BLOCK) void k_pcg_direction_dev(const double *__restrict__ S, int ia, int ib, const double *__restrict__ z,
+                                                             double *__restrict__ p, size_t n) {
+    const double beta = S[ia] / S[ib];
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) p[i] = 1.0 * z[i] + beta * p[i];
+}
+
 // K9: dot product, stage 1: per-block partial (wave shuffle + LDS), stage 2 by k_reduce_partials
 __device__ __forceinline__ double block_sum(double s, double *sh) {
     s = group_sum<64>(s);

@@ -504,6 +504,31 @@ int dot_local_async(const double *x, const double *y, size_t n, double *dout) {
     return SGPU_OK;
 }
 
+// global dot whose result stays on the device (S[slot]); with a communicator the rank sums are combined in place
+int dot_dev(const double *x, const double *y, size_t n, int slot) {
+    CHK(dot_local_async(x, y, n, g.dscalar + slot));
+    if (g.comm) NCCLCHK(ncclAllReduce(g.dscalar + slot, g.dscalar + slot, 1, ncclDouble, ncclSum, g.comm, g.cs));
+    return SGPU_OK;
+}
+int dot_nblocks(size_t n) { return (int)std::min<size_t>(g.n_partials, std::max<size_t>(1, (n + sk::BLOCK - 1) / sk::BLOCK)); }
+// u -= (S[ia]/S[ib]) p; r -= (S[ia]/S[ib]) h; S[iout] = global r.r of the new r; *host_out = the same (ONE host sync)
+int pcg_update_dev(int ia, int ib, const double *p, const double *h, double *u, double *r, size_t n, int iout, double *host_out) {
+    const int nb = dot_nblocks(n);
+    hipLaunchKernelGGL(sk::k_pcg_update_dev, dim3(nb), dim3(sk::BLOCK), 0, g.cs, (const double *)g.dscalar, ia, ib, p, h, u, r, n, g.partials);
+    hipLaunchKernelGGL(sk::k_reduce_partials, dim3(1), dim3(sk::BLOCK), 0, g.cs, g.partials, nb, g.dscalar + iout);
+    HIPCHK(hipGetLastError());
+    if (g.comm) NCCLCHK(ncclAllReduce(g.dscalar + iout, g.dscalar + iout, 1, ncclDouble, ncclSum, g.comm, g.cs));
+    HIPCHK(hipMemcpyAsync(g.hscalar + iout, g.dscalar + iout, sizeof(double), hipMemcpyDeviceToHost, g.cs));
+    HIPCHK(hipStreamSynchronize(g.cs));
+    *host_out = g.hscalar[iout];
+    return SGPU_OK;
+}
+int pcg_direction_dev(int ia, int ib, const double *z, double *p, size_t n) {
+    hipLaunchKernelGGL(sk::k_pcg_direction_dev, dim3(grid_for(2 * n)), dim3(sk::BLOCK), 0, g.cs, (const double *)g.dscalar, ia, ib, z, p, n);
+    HIPCHK(hipGetLastError());
+    return SGPU_OK;
+}
+
 const double JACOBI_OMEGA_REF = (double)(float)(2.0 / 3);   // saena_matrix.h:182
 
 } // namespace
@@ -1348,24 +1373,26 @@ int sgpu_solve_pCG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, valu
     CHK(vcycle0(h, rho, r));                                          // :2536-2537
     CHK(sgpu_vec_copy(p, rho, sz));
     const double THRSHLD = init_dot * h->prm.solver_tol * h->prm.solver_tol;
-    double rho_res = 0, pdoth = 0, alpha = 0, beta = 0;
     current_dot = init_dot;
+    // The scalars stay on the device (slots 4..7 of the scratch; slot 0 belongs to sgpu_dot, which the coarsest CG
+    // of a V-cycle may call): S[a] = r.rho, S[5] = p.h, S[6] = r.r; alpha and beta are formed inside the
+    // update kernels, so an iteration has ONE host synchronisation (the convergence test) instead of four.  The
+    // reference's rho_res at the top of iteration i+1 (:2580) is the r.rho it computed for beta at the bottom of
+    // iteration i (:2655) -- same vectors, same value -- so that dot is computed once.
+    int a = 4, b = 7;
+    CHK(dot_dev(r, rho, sz, a));                                      // :2580 (first iteration)
     int i = 0;
     for (i = 0; i < h->prm.solver_max_iter; i++) {                    // :2565
         CHK(sgpu_spmv(A, p, hh));                                     // :2571
-        CHK(sgpu_dot(r, rho, sz, &rho_res));                          // :2580
-        CHK(sgpu_dot(p, hh, sz, &pdoth));                             // :2581
-        alpha = rho_res / pdoth;
-        hipLaunchKernelGGL(sk::k_pcg_update, dim3(grid_for(2 * sz)), dim3(sk::BLOCK), 0, g.cs, alpha, p, hh, u, r, sz);   // :2593-2596
-        HIPCHK(hipGetLastError());
-        CHK(sgpu_dot(r, r, sz, &current_dot));                        // :2603
+        CHK(dot_dev(p, hh, sz, 5));                                   // :2581
+        CHK(pcg_update_dev(a, 5, p, hh, u, r, sz, 6, &current_dot));  // alpha = rho_res / pdoth; :2593-2596; :2603
         if (hist && i + 1 < cap) hist[i + 1] = std::sqrt(current_dot);
         if (current_dot < THRSHLD) break;                             // :2620
         CHK(sgpu_vec_fill(rho, 0.0, sz));                             // :2640
         CHK(vcycle0(h, rho, r));                                      // :2641
-        CHK(sgpu_dot(r, rho, sz, &beta));                             // :2655
-        beta /= rho_res;
-        CHK(sgpu_vec_axpby(1.0, rho, beta, p, sz));                   // :2665-2667  p = rho + beta p
+        CHK(dot_dev(r, rho, sz, b));                                  // :2655
+        CHK(pcg_direction_dev(b, a, rho, p, sz));                     // beta = r.rho / rho_res; :2665-2667  p = rho + beta p
+        std::swap(a, b);
     }
     const bool conv = current_dot < THRSHLD;
     if (i == h->prm.solver_max_iter) i--;
@@ -1382,25 +1409,24 @@ int sgpu_solve_CG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value
     double *r = h->r, *hh = h->hh, *p = h->p;
     CHK(sgpu_vec_fill(u, 0.0, sz));
     CHK(sgpu_residual(A, u, rhs, r));
-    double init_dot = 0, current_dot = 0, rho_res = 0, pdoth = 0, beta = 0;
+    double init_dot = 0, current_dot = 0;
     CHK(sgpu_dot(r, r, sz, &init_dot));
     if (hist && cap > 0) hist[0] = std::sqrt(init_dot);
     CHK(sgpu_vec_copy(p, r, sz));
     const double THRSHLD = init_dot * h->prm.solver_tol * h->prm.solver_tol;
     current_dot = init_dot;
+    // device-resident scalars as in solve_pCG: S[a] = r.r before the update (= rho_res), S[b] = r.r after it
+    int a = 4, b = 7;
+    CHK(dot_dev(r, r, sz, a));
     int i = 0;
     for (i = 0; i < h->prm.solver_max_iter; i++) {
         CHK(sgpu_spmv(A, p, hh));
-        CHK(sgpu_dot(r, r, sz, &rho_res));
-        CHK(sgpu_dot(p, hh, sz, &pdoth));
-        const double alpha = rho_res / pdoth;
-        hipLaunchKernelGGL(sk::k_pcg_update, dim3(grid_for(2 * sz)), dim3(sk::BLOCK), 0, g.cs, alpha, p, hh, u, r, sz);
-        HIPCHK(hipGetLastError());
-        CHK(sgpu_dot(r, r, sz, &current_dot));
+        CHK(dot_dev(p, hh, sz, 5));
+        CHK(pcg_update_dev(a, 5, p, hh, u, r, sz, b, &current_dot));
         if (hist && i + 1 < cap) hist[i + 1] = std::sqrt(current_dot);
         if (current_dot < THRSHLD) break;
-        beta = current_dot / rho_res;
-        CHK(sgpu_vec_axpby(1.0, r, beta, p, sz));
+        CHK(pcg_direction_dev(b, a, r, p, sz));                       // beta = current_dot / rho_res; p = r + beta p
+        std::swap(a, b);
     }
     const bool conv = current_dot < THRSHLD;
     if (i == h->prm.solver_max_iter) i--;
