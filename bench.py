@@ -114,13 +114,15 @@ def vcycle_leg(capi, host, A, m, dist=None):
             "options": "data/options001.xml values: jacobi 3+3, tol 1e-8, conn_str 0.2", "host_setup_s": round(t_setup, 2)}
 
 
-def pmc_traffic(m, world):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (PMC counters cannot be read from inside the process); None for other configurations."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_spmv_128_cc16.json")
-    if m == 128 and world == 1 and os.path.exists(path):
+def pmc_traffic(m, world, kernel_name):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (PMC counters cannot be
+    read from inside the process).  Only for the kernel those passes profiled; None for anything else."""
+    table = {"k_csr_cc16<16KiB>": "r01_pmc_spmv_128_cc16.json", "k_csr_stream<16KiB>": "r01_pmc_spmv_128.json"}
+    name = table.get(kernel_name)
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    if m == 128 and world == 1 and path and os.path.exists(path):
         with open(path) as f:
-            return json.load(f)["traffic_bytes_per_launch"], "profiles/r01_pmc_spmv_128_cc16.json"
+            return json.load(f)["traffic_bytes_per_launch"], "profiles/" + name
     return None, None
 
 
@@ -232,7 +234,7 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "us_per_launch": round(ms_kernel * 1e3, 3), "algorithmic_bytes": B_local,
-                "traffic": pmc_traffic(m, world)[0], "traffic_source": pmc_traffic(m, world)[1],
+                "traffic": pmc_traffic(m, world, kernel_name)[0], "traffic_source": pmc_traffic(m, world, kernel_name)[1],
             },
         }
         if world == 1 and not multi and not args.no_vcycle:
