@@ -155,11 +155,20 @@ def main():
         uid = box[0]
     elif multi:
         uid = capi.get_unique_id()
-    capi.init(device=local_rank, rank=rank, nranks=world, unique_id=uid)
+    # SAENA_BENCH_DEVICE: rehearsal aid (several ranks on one card, if the RCCL build allows it)
+    device = int(os.environ.get("SAENA_BENCH_DEVICE", local_rank))
+    capi.init(device=device, rank=rank, nranks=world, unique_id=uid)
 
     # ---- operator through the host mirror of saena::matrix (product path, no oracle) ----
     m = args.m
-    comm = host.Comm("gpu", "rccl")
+    # Setup-time collectives (assemble, hierarchy distribution): over the RCCL communicator at one rank; with more
+    # ranks over the gloo group already open for the rendezvous -- that path is exercised at world_size 2-4 by the
+    # CPU test-suite, the RCCL one (RcclHostComm) only at one rank so far.  SAENA_BENCH_SETUP_COMM=rccl overrides.
+    # The data path (halo exchange, dots) rides RCCL either way.
+    if world > 1 and os.environ.get("SAENA_BENCH_SETUP_COMM", "gloo") != "rccl":
+        comm = host.Comm("gpu", "dist", dist)
+    else:
+        comm = host.Comm("gpu", "rccl")
     A = host.Matrix(comm)
     if world == 1:
         A.laplacian3D(m).assemble()                      # reference partitioner (trivial at one rank)

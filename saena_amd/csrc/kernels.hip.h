@@ -62,12 +62,10 @@ struct SpmvArgs {
     // (segment slot << 12) | (column & 4095)
     const int            *segtab;   // [nblk*16]
     const unsigned short *ccol;     // [nnz] (padded)
-    // in-kernel fork/join with the halo stream (multi-rank interior launch only, else nullptr):
-    // block 0 stores *flag_x = seq when it starts (stream order: everything earlier on the compute stream
-    // is complete, so the halo stream's pack may read x) and does not exit before *flag_h >= seq (the
-    // boundary-row kernel on the halo stream is done), so the launch's completion IS the join.
+    // in-kernel fork to the halo stream (multi-rank interior launch only, else nullptr): block 0 stores
+    // *flag_x = seq when it starts -- stream order: everything earlier on the compute stream is complete, so
+    // the halo stream's pack, which polls the flag, may read x.
     uint64_t *flag_x;
-    uint64_t *flag_h;
     uint64_t  seq;
 };
 
@@ -79,10 +77,6 @@ __device__ __forceinline__ void fork_signal(const SpmvArgs &a) {
     // stream order already completed (and released) everything earlier on this stream: a plain flag store suffices
     if (a.flag_x && blockIdx.x == 0 && threadIdx.x == 0)
         (void)__hip_atomic_exchange(a.flag_x, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an RMW is performed at memory, a plain store may linger in L2
-}
-__device__ __forceinline__ void join_wait(const SpmvArgs &a) {
-    if (a.flag_h && blockIdx.x == 0 && threadIdx.x == 0)
-        while (__hip_atomic_load(a.flag_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.seq) __builtin_amdgcn_s_sleep(32);
 }
 // every thread of the block waits until *flag >= seq.  NO acquire fence follows: on this part an agent-scope
 // acquire is an L2 invalidate per wave (measured: ~46 us for the 500 waves of a pack launch); the caller reads
@@ -181,7 +175,6 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
             for (int w = 1; w < BLOCK / 64; ++w) t += lds[w];
             epilogue<EPI, HALO>(a, r0, t);
         }
-        if constexpr (HALO) join_wait(a);
         return;
     }
 
@@ -259,7 +252,6 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
             epilogue<EPI, HALO>(a, r, sum);
         }
     }
-    if constexpr (HALO) join_wait(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -374,7 +366,6 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
             epilogue<EPI, HALO>(a, r, sum);
         }
     }
-    if constexpr (HALO) join_wait(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -405,7 +396,6 @@ __global__ __launch_bounds__(BLOCK) void k_csr_vector(const SpmvArgs a, int nrow
     if (r < nrows && l == 0) {
         epilogue<EPI, HALO>(a, r, sum);
     }
-    if constexpr (HALO) join_wait(a);
 }
 
 // ---------------------------------------------------------------------------

@@ -286,11 +286,11 @@ struct EpiArgs {
     double        c0 = 0.0, c1 = 0.0;
 };
 
-// seq != 0: the launch carries the fork (flag_x = seq at its start) and the join (does not finish before flag_h >= seq)
+// seq != 0: the launch carries the fork (block 0 stores flag_x = seq when it starts)
 int launch_part(const CsrPart &P, int epi, const double *x, double *y, const EpiArgs &e, const unsigned *skip = nullptr, uint64_t seq = 0) {
     if (P.nblk == 0) return SGPU_OK;
     sk::SpmvArgs a;
-    a.flag_x = seq ? g.kflag_x : nullptr; a.flag_h = seq ? g.kflag_h : nullptr; a.seq = seq;
+    a.flag_x = seq ? g.kflag_x : nullptr; a.seq = seq;
     a.row_ptr = P.row_ptr; a.col = P.col; a.val = P.val;
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
@@ -345,7 +345,7 @@ BndKernelFn pick_bnd(int epi, int lanes) {
 int launch_boundary(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e, bool halo_is_f32, hipStream_t stream) {
     if (op->rem.nrows == 0) return SGPU_OK;
     sk::BoundaryArgs b;
-    b.s.flag_x = nullptr; b.s.flag_h = nullptr; b.s.seq = 0;
+    b.s.flag_x = nullptr; b.s.seq = 0;
     b.s.row_ptr = op->loc.row_ptr; b.s.col = op->loc.col; b.s.val = op->loc.val; b.s.blk_row = nullptr; b.s.nblk = 0;
     b.s.x = x; b.s.y = y; b.s.rhs = e.rhs; b.s.inv_diag = e.inv_diag; b.s.u = e.u; b.s.d = e.d; b.s.c0 = e.c0; b.s.c1 = e.c1;
     b.s.skip = nullptr; b.s.segtab = nullptr; b.s.ccol = nullptr;
@@ -378,12 +378,14 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     const uint64_t n = ++g.seq;
     const unsigned *skip = op->has_remote ? op->skip : nullptr;
     // Three ways to express the two dependencies (fork: hs after cs's earlier work; join: cs after hs), fastest first:
-    //  K  folded into the kernels: the interior launch stores flag_x = n when it starts and does not finish before
-    //     flag_h >= n; pack waits for flag_x; the boundary kernel's last block stores flag_h.  No extra launches.
+    //  K  flags polled by kernels: block 0 of the interior launch stores flag_x = n when it starts, the pack launch
+    //     polls it; a one-wave k_flag_set behind the boundary kernel stores flag_h = n, a one-wave k_flag_wait on cs
+    //     polls it.  No runtime helper launches, no event hops.
     //  V  hipStreamWriteValue64 / hipStreamWaitValue64 (each is a ~4 us helper launch, ~5 us per hop)
     //  E  events (~11 us per hop)
-    // In every mode a wait is enqueued only AFTER its matching write, so no stream is left waiting for nothing;
-    // after the K-mode interior launch every error path still publishes flag_h.
+    // Invariant of all three: whatever polls or waits was enqueued AFTER the thing it waits for -- nothing on the GPU
+    // ever depends on a launch the host has yet to make.  (So a device-wide synchronisation inside an RCCL host call,
+    // e.g. while it connects a new peer, always completes; and an error return leaves no stream waiting.)
     const bool K = g.inkernel_sync && op->loc.nblk > 0;
     const bool V = g.value_ops;
     if (K) {
@@ -423,16 +425,15 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
         return SGPU_OK;
     };
     const int st = hs_chain();
+    CHK(st);
     // join: nothing later on cs may see y (or overwrite x and the send buffers) before hs is through
     if (K) {
-        // publish flag_h behind whatever reached hs -- also on an error path: the interior launch is waiting for it
-        const std::string keep = g_err;
         hipLaunchKernelGGL(sk::k_flag_set, dim3(1), dim3(64), 0, g.hs, g.kflag_h, n);
-        if (hipGetLastError() != hipSuccess && st == SGPU_OK) return fail(SGPU_ERR_HIP, "k_flag_set launch failed");
-        g_err = keep;
-        return st;
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(sk::k_flag_wait, dim3(1), dim3(64), 0, g.cs, (const uint64_t *)g.kflag_h, n);
+        HIPCHK(hipGetLastError());
+        return SGPU_OK;
     }
-    CHK(st);
     if (V) {
         HIPCHK(hipStreamWriteValue64(g.hs, g.flag_h, n, 0));
         HIPCHK(hipStreamWaitValue64(g.cs, g.flag_h, n, hipStreamWaitValueGte, ~0ull));
