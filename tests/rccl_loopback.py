@@ -80,6 +80,39 @@ def main():
         omega = float(np.float32(2.0 / 3))
         want_u = xl - (arr("inv_diag", R.M, np.float64) * omega) * (want - rhs)
         assert np.max(np.abs(du.download() - want_u)) <= 1e-12 * np.max(np.abs(want_u)), ("jacobi", fp32)
+        # residual and a 3-step Chebyshev smoother (every step a fresh exchange of the updated iterate), against the
+        # same operator applied on the host: A_loop v = local v + remote v[vIndex]
+        vi, invd = arr("vIndex", R.vIndexSize, np.int32), arr("inv_diag", R.M, np.float64)
+        lc, lv = arr("col_local", R.nnz_l_local, np.int32), arr("val_local", R.nnz_l_local, np.float64)
+        rr, rv = arr("row_remote", R.nnz_l_remote, np.int32), arr("val_remote", R.nnz_l_remote, np.float64)
+
+        def A_loop(v):
+            out = np.zeros(R.M)
+            np.add.at(out, rows, lv * v[lc])
+            h = v[vi].astype(np.float32).astype(np.float64) if fp32 else v[vi]
+            np.add.at(out, rr, rv * h[cols])
+            return out
+        dres = capi.DeviceVector(R.M)
+        op.residual(dxl, dr, dres)
+        want_res = A_loop(xl) - rhs
+        assert np.max(np.abs(dres.download() - want_res)) <= 1e-12 * np.max(np.abs(want_res)), ("residual", fp32)
+        eig = 2.0
+        alpha, beta = 0.13 * eig, eig
+        delta, theta = (beta - alpha) / 2, (beta + alpha) / 2
+        s1 = theta / delta
+        rhok = 1 / s1
+        u = xl.copy()
+        d = (1 / theta) * invd * (rhs - A_loop(u))
+        u = u + d
+        for _ in range(2):
+            rhokp1 = 1 / (2 * s1 - rhok)
+            d = rhokp1 * rhok * d + (2 * rhokp1 / delta) * invd * (rhs - A_loop(u))
+            u = u + d
+            rhok = rhokp1
+        du.upload(xl)
+        op.chebyshev(3, eig, du, dr)
+        tol = 1e-6 if fp32 else 1e-12       # the fp32 wire rounds the halo of every step
+        assert np.max(np.abs(du.download() - u)) <= tol * np.max(np.abs(u)), ("chebyshev", fp32, np.max(np.abs(du.download() - u)))
         ms = op.time_kernel(0, dxl, None, dy, 20)
         print(f"loopback halo ok (fp32={fp32}): {R.vIndexSize} doubles each way, {ms * 1e3:.1f} us per SpMV incl. exchange", flush=True)
     capi.finalize()
