@@ -43,12 +43,41 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_baseline_reference(m, seconds, cores):
+    """The reference's own saena_matrix::matvec, compiled from its sources (oracle/ref/Makefile -> oracle/_ref/ref_dump,
+    built where /root/reference exists and shipped as a prebuilt binary), one MPI rank per core.  None if unavailable."""
+    import shutil
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
+    if not (os.path.exists(exe) and os.path.exists(mpirun)):
+        return None
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_THREADING_LAYER="SEQUENTIAL")
+    try:
+        out = subprocess.run([mpirun, "-np", str(cores), exe, "/tmp", "time", str(m), str(seconds)], env=env,
+                             capture_output=True, text=True, timeout=60 + 6 * seconds)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("REF_TIME_MATVEC")][-1].split()
+        t, reps, ranks, nrm, Mbig, nnz = float(line[1]), int(line[2]), int(line[3]), float(line[4]), int(line[5]), int(line[6])
+    except Exception:                                       # noqa: BLE001 -- fall back to the port
+        return None
+    if m == 128 and abs(nrm - 4185009626440892.5) > 1e-9 * nrm:      # ||A v||^2 known answer (SURVEY.md 8c)
+        return None
+    B = 12 * nnz + 4 * (Mbig + 1) + 16 * Mbig
+    return {"value": round(B / t / 1e9, 3), "unit": "GB/s", "cores": ranks, "kind": "reference",
+            "sample": f"{reps} saena_matrix::matvec calls of the compiled reference (oracle/_ref/ref_dump, -Ofast) on the same "
+                      f"Poisson {m}^3 operator, mpirun -np {ranks} (one rank per core, nnz-balanced partition), {t * 1e3:.3f} ms each"}
+
+
 def cpu_baseline(m, seconds):
-    """Oracle (CPU restatement of saena_matrix::matvec) on this box's cores: P simulated MPI
-    ranks on P threads, the reference's default of one thread per rank."""
+    """CPU path timed beside the GPU one on this box's cores: the compiled reference when its prebuilt binary is here,
+    else the oracle (CPU restatement of saena_matrix::matvec): P simulated MPI ranks on P threads, the reference's
+    default of one thread per rank."""
     import numpy as np
-    from oracle import oracle as orc
     cores = max(1, min(os.cpu_count() or 1, 16))
+    ref = cpu_baseline_reference(m, seconds, cores)
+    if ref is not None:
+        return ref
+    from oracle import oracle as orc
     entries, Mbig = orc.laplacian3d(m)
     split = orc.split_nnz(entries, Mbig, cores)
     A = orc.OracleOp(entries, Mbig, Mbig, split)

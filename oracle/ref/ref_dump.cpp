@@ -12,6 +12,8 @@
 //        mpirun -np P ref_dump <outdir> band <M> <bw>
 //        mpirun -np P ref_dump <outdir> norms <m>          (norm pins only, large m)
 //        mpirun -np P ref_dump <outdir> file <matrix.mtx|.bin> <tag>   (one of the reference's data files)
+//        mpirun -np P ref_dump <outdir> time <m> <seconds>   (bench.py cpu_baseline: times saena_matrix::matvec,
+//                                                              prints "REF_TIME_MATVEC <s per matvec> <reps> <ranks>")
 //
 // Reference interfaces exercised (file:line in the reference checkout):
 //   saena_matrix::set/assemble            src/saena_matrix.cpp:459, src/saena_matrix_setup.cpp:4
@@ -125,10 +127,11 @@ int main(int argc, char **argv) {
     g_out = argv[1];
     const std::string kind = argv[2];
     const bool norms_only = (kind == "norms");
+    const bool timing = (kind == "time");
 
     saena_matrix A(comm);
     std::string tag;
-    if (kind == "poisson" || norms_only) {
+    if (kind == "poisson" || norms_only || timing) {
         const int m = atoi(argv[3]);
         fill_poisson(A, m, m, m);
         tag = "poisson" + std::to_string(m);
@@ -153,6 +156,28 @@ int main(int argc, char **argv) {
         rhs2[i] = cos(0.05 * g) - 0.3;
     }
     auto norm2 = [&](const std::vector<double> &x) { double s = 0; for (double t : x) s += t * t; return gsum(s); };
+
+    if (timing) {   // the reference's own matvec (src/saena_matrix_matvec.cpp:9-113) on this box's cores, one rank per core
+        const double budget = argc > 4 ? atof(argv[4]) : 10.0;
+        for (int i = 0; i < 3; ++i) A.matvec(v.data(), w.data());
+        MPI_Barrier(comm);
+        double t0 = MPI_Wtime();
+        for (int i = 0; i < 5; ++i) A.matvec(v.data(), w.data());
+        MPI_Barrier(comm);
+        double per = (MPI_Wtime() - t0) / 5;
+        MPI_Bcast(&per, 1, MPI_DOUBLE, 0, comm);
+        int reps = (int)(budget / (per > 1e-7 ? per : 1e-7));
+        if (reps < 5) reps = 5;
+        MPI_Barrier(comm);
+        t0 = MPI_Wtime();
+        for (int i = 0; i < reps; ++i) A.matvec(v.data(), w.data());
+        MPI_Barrier(comm);
+        per = (MPI_Wtime() - t0) / reps;
+        const double nrm = norm2(w);
+        if (!g_rank) printf("REF_TIME_MATVEC %.9e %d %d %.17g %ld %ld\n", per, reps, g_np, nrm, (long)A.Mbig, (long)A.nnz_g);
+        MPI_Finalize();
+        return 0;
+    }
 
     std::vector<double> pins;   // squared norms, SURVEY 8c style
     A.matvec(v.data(), w.data());
