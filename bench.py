@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--m", type=int, default=128, help="grid points per side (reference laplacian3D argument)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
-    ap.add_argument("--vcycle-timeout", type=float, default=300.0, help="watchdog of the multi-rank V-cycle leg, seconds")
+    ap.add_argument("--vcycle-timeout", type=float, default=150.0, help="watchdog of the multi-rank V-cycle leg, seconds")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -287,14 +287,22 @@ def main():
         # here, rank 0 still prints the SpMV line measured above.
         import threading
 
+        def line(err):
+            if rank != 0:
+                return ""
+            o = dict(out)
+            o["vcycle"] = {"error": err}
+            return json.dumps(o)
+
         def bail():
             if rank == 0:
-                out["vcycle"] = {"error": f"multi-rank V-cycle leg did not finish within {args.vcycle_timeout:.0f} s"}
-                print(json.dumps(out), flush=True)
+                print(line(f"multi-rank V-cycle leg did not finish within {args.vcycle_timeout:.0f} s"), flush=True)
             os._exit(0)
         dog = threading.Timer(args.vcycle_timeout, bail)
         dog.daemon = True
         dog.start()
+        # a native crash (GPU fault -> abort, or SIGTERM from the launcher when a sibling rank died) still prints the line
+        capi.check(capi.lib().sgpu_debug_on_fatal_print(line("multi-rank V-cycle leg ended with a fatal signal").encode()))
         try:
             A2 = host.Matrix(comm)
             A2.laplacian3D(m).assemble()
@@ -304,12 +312,12 @@ def main():
             if rank == 0:
                 out["vcycle"] = leg
         except Exception as e:                              # noqa: BLE001 -- reported, never fatal for the SpMV line
+            dog.cancel()
             if rank == 0:
-                out["vcycle"] = {"error": f"{type(e).__name__}: {e}"}
-                dog.cancel()
-                print(json.dumps(out), flush=True)
+                print(line(f"{type(e).__name__}: {e}"), flush=True)
             os._exit(0)
         dog.cancel()
+        capi.check(capi.lib().sgpu_debug_on_fatal_print(None))
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -211,6 +211,12 @@ int sgpu_solve_CG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value
 /* solve_coarsest_CG on the last level only (for tests) */
 int sgpu_coarsest_solve(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters);
 
+/* bench.py only: from now on a fatal signal in this process (SIGSEGV/SIGBUS/SIGABRT/SIGFPE/SIGILL/SIGTERM -- the HIP
+ * runtime aborts on a GPU fault, torchrun sends SIGTERM when a sibling rank dies) writes `line` (may be empty) to
+ * stdout and ends the process with status 0, so that an optional leg running after the measurement cannot lose the
+ * measured line.  NULL restores the default handlers.  `line` is copied. */
+int sgpu_debug_on_fatal_print(const char *line);
+
 /* ---- measurement -----------------------------------------------------------
  * Runs `reps` back-to-back launches of one kernel on the compute stream,
  * bracketed by hipEvents recorded on that same stream; *ms_per_launch is the

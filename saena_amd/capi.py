@@ -90,6 +90,7 @@ SYMBOLS = {
     "sgpu_amg_set_solve_params": (C.c_int, [_VP, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]),
     "sgpu_amg_profile_matvecs": (C.c_int, [_VP, C.c_int, _PD]),
     "sgpu_coarsest_solve": (C.c_int, [_VP, _VP, _VP, _PI]),
+    "sgpu_debug_on_fatal_print": (C.c_int, [C.c_char_p]),
     "sgpu_time_kernel": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.POINTER(C.c_float)]),
     "sgpu_algorithmic_bytes": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64)]),
 }

@@ -194,3 +194,16 @@ def test_gpu_path_fails_loudly_without_device():
             "try:\n    capi.init(0)\n    print('INIT_OK')\nexcept capi.SgpuError as e:\n    print('LOUD', e)\n") % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert "LOUD" in out.stdout or "INIT_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_fatal_signal_prints_the_measured_line():
+    """sgpu_debug_on_fatal_print (bench.py's safety net for its optional multi-rank leg): a fatal signal writes the
+    registered line to stdout and ends the process with status 0 (no GPU needed: no compute call is made)"""
+    import subprocess
+    code = ("import os, signal\n"
+            "from saena_amd import capi\n"
+            "capi.lib().sgpu_debug_on_fatal_print(b'{\"metric\": \"x\"}')\n"
+            "os.kill(os.getpid(), signal.SIGABRT)\n"
+            "print('not reached')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 0 and out.stdout == '{"metric": "x"}\n', (out.returncode, out.stdout, out.stderr[-500:])
