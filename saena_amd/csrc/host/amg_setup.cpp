@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <fstream>
 #include <cstdlib>
@@ -146,29 +147,84 @@ Csr spgemm(const Csr &A, const Csr &B) {
     std::vector<nnz_t> rowlen((size_t)A.nrows, 0);
     parallel_rows(A.nrows, &work, [&](int t, index_t lo, index_t hi) {
         tlo[t] = lo; thi[t] = hi;
-        std::vector<value_t> acc((size_t)B.ncols, 0.0);
-        std::vector<char> mark((size_t)B.ncols, 0);
+        // Two accumulators, same arithmetic (every output entry adds its products in generation order): an
+        // open-addressing table sized to the row, which stays in L1/L2 (a 415 K-column dense accumulator per thread
+        // cost ~22 ns per product in cache misses), and the dense array for rows that could fill a large part of it.
+        std::vector<value_t> acc;
+        std::vector<char> mark;
         std::vector<index_t> cols;
+        std::vector<index_t> hkey;
+        std::vector<value_t> hval;
+        std::vector<std::pair<index_t, value_t>> out;
+        std::vector<size_t> slots;
         auto &oc = tcol[t];
         auto &ov = tval[t];
         oc.reserve((size_t)((work[hi] - work[lo]) / 4 + 16));
         ov.reserve(oc.capacity());
         for (index_t i = lo; i < hi; ++i) {
-            cols.clear();
-            for (nnz_t ka = A.ptr[i]; ka < A.ptr[i + 1]; ++ka) {
-                const index_t k = A.col[ka];
-                const value_t a = A.val[ka];
-                for (nnz_t kb = B.ptr[k]; kb < B.ptr[k + 1]; ++kb) {
-                    const index_t j = B.col[kb];
-                    if (!mark[j]) { mark[j] = 1; cols.push_back(j); acc[j] = 0.0; }
-                    acc[j] += a * B.val[kb];
-                }
-            }
-            std::sort(cols.begin(), cols.end());
+            const nnz_t products = work[i + 1] - work[i] - 1;
             nnz_t cnt = 0;
-            for (index_t j : cols) {
-                if (std::fabs(acc[j]) > SAENA_ALMOST_ZERO || i == j) { oc.push_back(j); ov.push_back(acc[j]); ++cnt; }
-                mark[j] = 0;
+            if (products > (nnz_t)B.ncols / 8) {                         // dense accumulator
+                if (acc.empty()) { acc.assign((size_t)B.ncols, 0.0); mark.assign((size_t)B.ncols, 0); }
+                cols.clear();
+                for (nnz_t ka = A.ptr[i]; ka < A.ptr[i + 1]; ++ka) {
+                    const index_t k = A.col[ka];
+                    const value_t a = A.val[ka];
+                    for (nnz_t kb = B.ptr[k]; kb < B.ptr[k + 1]; ++kb) {
+                        const index_t j = B.col[kb];
+                        if (!mark[j]) { mark[j] = 1; cols.push_back(j); acc[j] = 0.0; }
+                        acc[j] += a * B.val[kb];
+                    }
+                }
+                std::sort(cols.begin(), cols.end());
+                for (index_t j : cols) {
+                    if (std::fabs(acc[j]) > SAENA_ALMOST_ZERO || i == j) { oc.push_back(j); ov.push_back(acc[j]); ++cnt; }
+                    mark[j] = 0;
+                }
+            } else {                                                      // hash accumulator, grown by rehashing at load 1/2
+                size_t cap = 256;
+                const size_t want = 2 * (size_t)std::min<nnz_t>(products, A.ptr[i + 1] - A.ptr[i] + 64);
+                while (cap < want) cap *= 2;
+                if (hkey.size() != cap) { hkey.assign(cap, -1); hval.assign(cap, 0.0); }
+                size_t mask = cap - 1;
+                out.clear();                                              // (column, unused) of every distinct output
+                auto slot_of = [&](index_t j) {
+                    size_t h = ((size_t)(unsigned)j * 2654435761u) & mask;
+                    while (hkey[h] != -1 && hkey[h] != j) h = (h + 1) & mask;
+                    return h;
+                };
+                for (nnz_t ka = A.ptr[i]; ka < A.ptr[i + 1]; ++ka) {
+                    const index_t k = A.col[ka];
+                    const value_t a = A.val[ka];
+                    for (nnz_t kb = B.ptr[k]; kb < B.ptr[k + 1]; ++kb) {
+                        const index_t j = B.col[kb];
+                        size_t h = slot_of(j);
+                        if (hkey[h] == -1) {
+                            if (2 * (out.size() + 1) > cap) {             // grow: values move, sums are untouched
+                                std::vector<index_t> okey(2 * cap, -1);
+                                std::vector<value_t> oval(2 * cap, 0.0);
+                                const size_t nmask = 2 * cap - 1;
+                                for (const auto &e : out) {
+                                    const size_t ho = slot_of(e.first);
+                                    size_t hn = ((size_t)(unsigned)e.first * 2654435761u) & nmask;
+                                    while (okey[hn] != -1) hn = (hn + 1) & nmask;
+                                    okey[hn] = e.first; oval[hn] = hval[ho];
+                                }
+                                hkey.swap(okey); hval.swap(oval);
+                                cap *= 2; mask = nmask;
+                                h = slot_of(j);
+                            }
+                            hkey[h] = j; hval[h] = 0.0; out.emplace_back(j, 0.0);
+                        }
+                        hval[h] += a * B.val[kb];
+                    }
+                }
+                slots.clear();
+                for (auto &e : out) { const size_t h = slot_of(e.first); e.second = hval[h]; slots.push_back(h); }
+                for (size_t h : slots) hkey[h] = -1;                      // cleared after ALL look-ups: probing needs the chains intact
+                std::sort(out.begin(), out.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+                for (const auto &e : out)
+                    if (std::fabs(e.second) > SAENA_ALMOST_ZERO || i == e.first) { oc.push_back(e.first); ov.push_back(e.second); ++cnt; }
             }
             rowlen[i] = cnt;
         }
@@ -254,33 +310,80 @@ index_t amg_hierarchy::aggregate(const saena_matrix &A, const std::vector<nnz_t>
     std::vector<char> decided((size_t)size, 0), dec_nei((size_t)size, 0), is_root((size_t)size, 0), is_root_nei((size_t)size, 0);
     std::vector<index_t> aggArray;
     for (index_t i = 0; i < size; ++i) agg[i] = i;
-    bool continueAgg = true;
-    while (continueAgg) {
-        for (index_t i = 0; i < size; ++i) {
-            if (decided[i]) continue;
-            aggregate2[i] = agg[i];
-            dec_nei[i] = 1;
-            is_root_nei[i] = 0;
-            for (nnz_t it = ptr[i]; it < ptr[i + 1]; ++it) {
-                const index_t c = col[it];
-                if (agg[c] < aggregate2[i] && (!decided[c] || is_root[c])) {
-                    aggregate2[i] = agg[c];
-                    dec_nei[i] = decided[c];
-                    is_root_nei[i] = is_root[c];
+    // The reference runs synchronous rounds over all undecided rows (setup1:760-960); 280 rounds for a 94^3 grid,
+    // ~140 visits per row, because the priority wave crosses the grid one node per round.  The same rounds are run
+    // here, but a row is re-evaluated only when a row it looks at changed state in the previous round -- otherwise
+    // its evaluation, which reads nothing but its neighbours' (agg, decided, is_root), would repeat the previous
+    // result and leave it undecided again.  Identical aggregates, ~3 visits per row.  Both sweeps of a round read
+    // only the previous round's state and write only row i's own entries, so the work list is dealt to threads.
+    const int T = n_threads();
+    std::vector<nnz_t> tptr((size_t)size + 1, 0);                 // who looks at row j: the transposed pattern
+    std::vector<index_t> tcol(col.size());
+    for (index_t c : col) tptr[(size_t)c + 1]++;
+    for (index_t i = 0; i < size; ++i) tptr[i + 1] += tptr[i];
+    {
+        std::vector<nnz_t> fill(tptr.begin(), tptr.end() - 1);
+        for (index_t i = 0; i < size; ++i)
+            for (nnz_t it = ptr[i]; it < ptr[i + 1]; ++it) tcol[fill[col[it]]++] = i;
+    }
+    std::vector<std::vector<index_t>> troots((size_t)T), tnext((size_t)T), tdone((size_t)T);
+    std::vector<char> queued((size_t)size, 0);
+    std::vector<index_t> work((size_t)size);
+    for (index_t i = 0; i < size; ++i) work[i] = i;
+    long rounds = 0, visited = 0, undecided = size;
+    while (!work.empty()) {
+        const index_t nw = (index_t)work.size();
+        ++rounds; visited += nw;
+        parallel_rows(nw, nullptr, [&](int, index_t lo, index_t hi) {
+            for (index_t q = lo; q < hi; ++q) {
+                const index_t i = work[q];
+                queued[i] = 0;
+                aggregate2[i] = agg[i];
+                dec_nei[i] = 1;
+                is_root_nei[i] = 0;
+                for (nnz_t it = ptr[i]; it < ptr[i + 1]; ++it) {
+                    const index_t c = col[it];
+                    if (agg[c] < aggregate2[i] && (!decided[c] || is_root[c])) {
+                        aggregate2[i] = agg[c];
+                        dec_nei[i] = decided[c];
+                        is_root_nei[i] = is_root[c];
+                    }
                 }
             }
-        }
-        for (index_t i = 0; i < size; ++i) {
-            if (!decided[i] && dec_nei[i]) {
-                decided[i] = 1;
-                if (agg[i] == aggregate2[i]) { is_root[i] = 1; aggArray.push_back(agg[i]); }
-                else if (is_root_nei[i]) agg[i] = aggregate2[i];
+        });
+        for (auto &v : tdone) v.clear();
+        parallel_rows(nw, nullptr, [&](int t, index_t lo, index_t hi) {
+            for (index_t q = lo; q < hi; ++q) {
+                const index_t i = work[q];
+                if (dec_nei[i]) {
+                    decided[i] = 1;
+                    if (agg[i] == aggregate2[i]) { is_root[i] = 1; troots[t].push_back(agg[i]); }
+                    else if (is_root_nei[i]) agg[i] = aggregate2[i];
+                    tdone[t].push_back(i);
+                }
             }
-        }
-        continueAgg = false;
-        for (index_t i = 0; i < size; ++i)
-            if (!decided[i]) { continueAgg = true; break; }
+        });
+        // next round: the undecided rows that look at a row decided in this one
+        for (auto &v : tnext) v.clear();
+        std::vector<index_t> done;
+        for (auto &v : tdone) done.insert(done.end(), v.begin(), v.end());
+        undecided -= (long)done.size();
+        parallel_rows((index_t)done.size(), nullptr, [&](int t, index_t lo, index_t hi) {
+            for (index_t q = lo; q < hi; ++q) {
+                const index_t j = done[q];
+                for (nnz_t it = tptr[j]; it < tptr[j + 1]; ++it) {
+                    const index_t c = tcol[it];
+                    if (!decided[c] && !__atomic_exchange_n(&queued[c], (char)1, __ATOMIC_RELAXED)) tnext[t].push_back(c);
+                }
+            }
+        });
+        work.clear();
+        for (auto &v : tnext) work.insert(work.end(), v.begin(), v.end());
+        std::sort(work.begin(), work.end());
     }
+    if (undecided != 0) throw std::runtime_error("aggregation did not terminate: " + std::to_string(undecided) + " undecided rows");
+    if (std::getenv("SAENA_SETUP_TIMING")) fprintf(stderr, "[aggregate] %ld rounds, %ld row visits for %d rows\n", rounds, visited, size);
+    for (auto &tr : troots) aggArray.insert(aggArray.end(), tr.begin(), tr.end());
     std::sort(aggArray.begin(), aggArray.end());
     for (index_t i = 0; i < size; ++i)
         agg[i] = (index_t)(std::lower_bound(aggArray.begin(), aggArray.end(), agg[i]) - aggArray.begin());
@@ -395,17 +498,35 @@ static void filter_csr(Csr &C, double THRE) {
 void amg_hierarchy::filter(std::vector<cooEntry> &, index_t, index_t) {}   // COO form unused (CSR form above)
 
 // coarsen (saena_object.cpp:409-452) = SA (setup1:8-254) + transposeP + compute_coarsen (setup2:8-358)
+namespace {
+struct PhaseTimer {       // SAENA_SETUP_TIMING=1: per-level phase times of the setup on stderr
+    bool on = std::getenv("SAENA_SETUP_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    int level;
+    explicit PhaseTimer(int l) : level(l) {}
+    void lap(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[setup L%d] %-22s %8.3f s\n", level, what, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
+} // namespace
+
 int amg_hierarchy::coarsen(int l) {
     amg_level &g = levels[l];
     saena_matrix &A = *g.A;
     Comm &c = *A.comm;
     if (c.nranks != 1) throw std::runtime_error("amg setup: multi-rank setup is not implemented in this round");
+    PhaseTimer pt(l);
 
     // ---- find_aggregation (setup1:255-432) ----
     std::vector<nnz_t> sptr;
     std::vector<index_t> scol, agg;
     strength_graph(A, opts.connStrength, sptr, scol);
+    pt.lap("strength graph");
     const index_t new_size = aggregate(A, sptr, scol, agg, &g.roots);
+    pt.lap("aggregation");
     sptr = {}; scol = {};
     int ret_val = 0;
     if (opts.dynamic_levels) {                                           // setup1:385-405
@@ -453,13 +574,17 @@ int amg_hierarchy::coarsen(int l) {
             std::copy(tval[t].begin(), tval[t].end(), Pc.val.begin() + Pc.ptr[tlo[t]]);
         }
     }
+    pt.lap("smoothed P");
     // ---- R = P^T (restrict_matrix::transposeP) ----
     Csr Rc = transpose(Pc);
+    pt.lap("R = P^T");
 
     // ---- Ac = (R A) P  (triple_mat_mult, setup2:361-849) ----
     Csr RA = spgemm(Rc, Ac_);
+    pt.lap("R*A");
     Csr AcN = spgemm(RA, Pc);
     RA = Csr();
+    pt.lap("(RA)*P");
 
     // ---- filter (setup2:117-121, :852-916) ----
     if (++filter_it >= opts.filter_start) {
@@ -468,6 +593,7 @@ int amg_hierarchy::coarsen(int l) {
         filter_thre_cur *= std::pow(10, opts.filter_rate);
     }
 
+    pt.lap("filter");
     // ---- hand the three operators over in the reference's layout ----
     transfer_matrix &P = g.P;
     P.comm = &c; P.Mbig = A.Mbig; P.Nbig = new_size; P.M = A.M;
@@ -482,6 +608,7 @@ int amg_hierarchy::coarsen(int l) {
 
     g.Ac_store.reset(new saena_matrix(&c));
     g.Ac_store->setup_from_csr(new_size, AcN.ptr, std::move(AcN.col), std::move(AcN.val));   // setup2:341 matrix_setup
+    pt.lap("layouts of P, R, Ac");
     return ret_val;
 }
 
