@@ -258,13 +258,13 @@ def test_cpp_surface_poisson_driver(capi, tmp_path):
     assert f"matmat: C = A*A has {M} rows, {(A @ A).nnz} nnz" in txt, txt
 
 
-def test_multirank_vcycle_emulated_on_one_gpu(capi, hier):
-    """A row-partitioned V-cycle (3 ranks, per-level partitions, the two coarsest levels shrunk onto rank 0)
+@pytest.mark.parametrize("P_", [3, 8])
+def test_multirank_vcycle_emulated_on_one_gpu(capi, hier, P_):
+    """A row-partitioned V-cycle (3 or 8 ranks, per-level partitions, the two coarsest levels shrunk onto rank 0)
     executed with every rank's kernels on this one GPU and the halos routed on the host: exercises the
     distributed A/P/R plans, the remote kernels and empty ranks through a whole V-cycle.  (The RCCL
     orchestration of sgpu_vcycle itself needs one GPU per rank.)"""
     As, Ps, Rs = hier
-    P_ = 3
     nl = len(As)
     splits = []
     for l, A in enumerate(As):
@@ -272,7 +272,11 @@ def test_multirank_vcycle_emulated_on_one_gpu(capi, hier):
         if l >= nl - 2:
             splits.append(np.array([0] + [n] * P_, np.int32))                # shrunk onto rank 0
         else:
-            splits.append(np.array([0, n // 4, (2 * n) // 3, n], np.int32))  # uneven blocks
+            if P_ == 3:
+                splits.append(np.array([0, n // 4, (2 * n) // 3, n], np.int32))          # uneven blocks
+            else:                                                                          # uneven blocks (no empty rank in the middle:
+                cut = [0] + [int(n * (q + 0.35 * (q % 3)) / P_) for q in range(1, P_)] + [n]   # the reference's owner search cannot
+                splits.append(np.array(cut, np.int32))                                      # represent one, its partitioner never makes one)
     OA = [orc.OracleOp(hierarchy.scipy_to_coo(A), A.shape[0], A.shape[0], splits[l]) for l, A in enumerate(As)]
     OP = [orc.OracleOp(hierarchy.scipy_to_coo(P), P.shape[0], P.shape[1], splits[l], splits[l + 1], square=False) for l, P in enumerate(Ps)]
     OR = [orc.OracleOp(hierarchy.scipy_to_coo(R), R.shape[0], R.shape[1], splits[l + 1], splits[l], square=False) for l, R in enumerate(Rs)]
