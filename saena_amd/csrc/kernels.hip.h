@@ -507,6 +507,24 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_update(double alpha, const double
     }
 }
 
+// First smoother sweep from a ZERO iterate (every coarse level of a V-cycle starts from u = 0, and so does the fine
+// level when the V-cycle preconditions CG): A*0 contributes nothing, so the sweep needs no pass over the matrix.
+// Same arithmetic as the epilogues with s = 0 and u = 0:  Jacobi  y = 0 - ((0 - rhs) * (inv_diag*omega)) = rhs*(inv_diag*omega);
+// Chebyshev step 0  d = (c*inv_diag)*(rhs - 0), y = 0 + d  -- bit-identical results (up to the sign of a zero).
+__global__ __launch_bounds__(BLOCK) void k_zero_sweep(int cheby, double c0, const double *__restrict__ rhs, const double *__restrict__ inv_diag,
+                                                      double *__restrict__ y, double *__restrict__ d, size_t n) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        if (cheby) {
+            const double dd = (c0 * inv_diag[i]) * rhs[i];
+            d[i] = dd;
+            y[i] = dd;
+        } else {
+            y[i] = rhs[i] * (inv_diag[i] * c0);
+        }
+    }
+}
+
 // pCG with the scalars kept on the device (no host round trip between the dots and the update):
 // alpha = S[ia] / S[ib]; u -= alpha p; r -= alpha h; partial[block] = sum over the block's elements of the
 // NEW r*r, with k_dot_partial's element-to-thread assignment (launch it with the dot's grid).

@@ -458,12 +458,25 @@ int ensure_d(sgpu_op *op) {
 int grid_for(size_t n) { return (int)std::min<size_t>(2048, std::max<size_t>(1, (n / 2 + sk::BLOCK - 1) / sk::BLOCK)); }
 
 // iter Jacobi sweeps ping-ponging u <-> alt; *out = buffer holding the result.
-int jacobi_pp(sgpu_op *op, int iter, double omega, double *u, double *alt, const double *rhs, double **out) {
+int zero_sweep(sgpu_op *op, int cheby, double c0, const double *rhs, double *y, double *d) {
+    if (op->M == 0) return SGPU_OK;
+    hipLaunchKernelGGL(sk::k_zero_sweep, dim3(grid_for(2 * (size_t)op->M)), dim3(sk::BLOCK), 0, g.cs, cheby, c0, rhs, (const double *)op->inv_diag,
+                       y, d, (size_t)op->M);
+    HIPCHK(hipGetLastError());
+    return SGPU_OK;
+}
+
+// zero_first: the iterate in `u` is known to be zero (its CONTENT is not read): the first sweep skips the matrix
+int jacobi_pp(sgpu_op *op, int iter, double omega, double *u, double *alt, const double *rhs, double **out, bool zero_first = false) {
     if (!op->inv_diag) return fail(SGPU_ERR_ARG, "jacobi: operator has no inv_diag");
     double *cur = u, *nxt = alt;
     for (int j = 0; j < iter; ++j) {
-        EpiArgs e; e.rhs = rhs; e.inv_diag = op->inv_diag; e.u = cur; e.c0 = omega;
-        CHK(apply(op, sk::EPI_JACOBI, cur, nxt, e));
+        if (j == 0 && zero_first) {
+            CHK(zero_sweep(op, 0, omega, rhs, nxt, nullptr));
+        } else {
+            EpiArgs e; e.rhs = rhs; e.inv_diag = op->inv_diag; e.u = cur; e.c0 = omega;
+            CHK(apply(op, sk::EPI_JACOBI, cur, nxt, e));
+        }
         std::swap(cur, nxt);
     }
     *out = cur;
@@ -471,7 +484,7 @@ int jacobi_pp(sgpu_op *op, int iter, double omega, double *u, double *alt, const
 }
 
 // saena_matrix::chebyshev scalars, src/saena_matrix.cpp:1084-1091,1113-1117
-int cheby_pp(sgpu_op *op, int iter, double eig_max, double *u, double *alt, const double *rhs, double **out) {
+int cheby_pp(sgpu_op *op, int iter, double eig_max, double *u, double *alt, const double *rhs, double **out, bool zero_first = false) {
     if (!op->inv_diag) return fail(SGPU_ERR_ARG, "chebyshev: operator has no inv_diag");
     CHK(ensure_d(op));
     const double alpha = 0.13 * eig_max, beta = eig_max;
@@ -480,7 +493,10 @@ int cheby_pp(sgpu_op *op, int iter, double eig_max, double *u, double *alt, cons
     double rhok = 1.0 / s1;
     double *cur = u, *nxt = alt;
     if (iter <= 0) { *out = cur; return SGPU_OK; }
-    {
+    if (zero_first) {
+        CHK(zero_sweep(op, 1, 1.0 / theta, rhs, nxt, op->dvec));
+        std::swap(cur, nxt);
+    } else {
         EpiArgs e; e.rhs = rhs; e.inv_diag = op->inv_diag; e.u = cur; e.d = op->dvec; e.c0 = 1.0 / theta;
         CHK(apply(op, sk::EPI_CHEBY0, cur, nxt, e));
         std::swap(cur, nxt);
@@ -1013,7 +1029,7 @@ struct sgpu_amg {
     double *r = nullptr, *rho = nullptr, *hh = nullptr, *p = nullptr;
     // captured V-cycles, one per (u, rhs) pointer pair (single rank): replaying a hipGraph removes
     // the ~70 launch gaps of a V-cycle, which weigh as much as a whole coarse level
-    struct Captured { double *u; const double *rhs; hipGraph_t graph; hipGraphExec_t exec; };
+    struct Captured { double *u; const double *rhs; bool u_zero; hipGraph_t graph; hipGraphExec_t exec; };
     double *Ainv = nullptr;   // dense inverse of the coarsest operator (coarse_solver == 1)
     bool coarse_local = true; // the coarsest operator has no halo on any rank
     ~sgpu_amg() {
@@ -1094,35 +1110,41 @@ int coarse_solve(sgpu_amg *h, double *u, const double *rhs, int *iters) {
     return coarse_cg_dist(h, A, u, rhs, iters);
 }
 
-int smooth_pp(sgpu_amg *h, int l, int iter, double *u, double *alt, const double *rhs, double **out) {
+int smooth_pp(sgpu_amg *h, int l, int iter, double *u, double *alt, const double *rhs, double **out, bool zero_first = false) {
     if (h->prm.smoother == 0) {
         const double om = h->prm.jacobi_omega != 0.0 ? h->prm.jacobi_omega : JACOBI_OMEGA_REF;
-        return jacobi_pp(h->A[l], iter, om, u, alt, rhs, out);
+        return jacobi_pp(h->A[l], iter, om, u, alt, rhs, out, zero_first);
     }
-    return cheby_pp(h->A[l], iter, h->eig[l], u, alt, rhs, out);
+    return cheby_pp(h->A[l], iter, h->eig[l], u, alt, rhs, out, zero_first);
 }
 
 // saena_object::vcycle (src/saena_object_solve.cpp:961-1431).  u/alt are the two
 // ping-pong buffers of this level; *out names the one holding the result.
-int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, double **out) {
+// u_zero: the iterate is zero by construction (every coarse level, :1249; the fine level when the V-cycle
+// preconditions CG, :2640) and the buffer's CONTENT is not read: the first pre-smoothing sweep then needs no
+// pass over the matrix (k_zero_sweep) and the zero fill itself is skipped.  Results are those of the plain sweep.
+int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, double **out, bool u_zero) {
+    const size_t n = (size_t)h->A[l]->M;
     if (l == h->nlevels - 1) {                             // :991-1057
+        if (u_zero && !h->Ainv) CHK(sgpu_vec_fill(u, 0.0, n));      // the CG solvers start from the iterate; the dense solve overwrites it
         CHK(coarse_solve(h, u, rhs, nullptr));
         *out = u;
         return SGPU_OK;
     }
     double *cur = u, *oth = alt, *t = nullptr;
     if (h->prm.preSmooth) {                                // :1105-1107
-        CHK(smooth_pp(h, l, h->prm.preSmooth, cur, oth, rhs, &t));
+        CHK(smooth_pp(h, l, h->prm.preSmooth, cur, oth, rhs, &t, u_zero));
         if (t != cur) std::swap(cur, oth);
+    } else if (u_zero) {
+        CHK(sgpu_vec_fill(cur, 0.0, n));
     }
     {                                                      // :1140 residual
         EpiArgs e; e.rhs = rhs;
         CHK(apply(h->A[l], sk::EPI_RESIDUAL, cur, h->res[l], e));
     }
     CHK(apply(h->R[l], sk::EPI_SPMV, h->res[l], h->rhs[l + 1], EpiArgs()));   // :1175
-    CHK(sgpu_vec_fill(h->u[l + 1], 0.0, (size_t)h->A[l + 1]->M));             // :1249
-    double *uc = nullptr;
-    CHK(vcycle_level(h, l + 1, h->u[l + 1], h->alt[l + 1], h->rhs[l + 1], &uc));   // :1254
+    double *uc = nullptr;                                                     // :1249 uCorrCoarse = 0, :1254
+    CHK(vcycle_level(h, l + 1, h->u[l + 1], h->alt[l + 1], h->rhs[l + 1], &uc, true));
     CHK(apply(h->P[l], sk::EPI_SUB, uc, cur, EpiArgs()));                     // :1325 + :1360-1361
     if (h->prm.postSmooth) {                               // :1397-1399
         CHK(smooth_pp(h, l, h->prm.postSmooth, cur, oth, rhs, &t));
@@ -1132,20 +1154,21 @@ int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, 
     return SGPU_OK;
 }
 
-int vcycle0_eager(sgpu_amg *h, double *u, const double *rhs) {
+int vcycle0_eager(sgpu_amg *h, double *u, const double *rhs, bool u_zero) {
     double *out = nullptr;
-    CHK(vcycle_level(h, 0, u, h->alt0, rhs, &out));
+    CHK(vcycle_level(h, 0, u, h->alt0, rhs, &out, u_zero));
     if (out != u) HIPCHK(hipMemcpyAsync(u, out, (size_t)h->A[0]->M * sizeof(double), hipMemcpyDeviceToDevice, g.cs));
     return SGPU_OK;
 }
 
-int vcycle0(sgpu_amg *h, double *u, const double *rhs) {
-    if (!h->prm.use_graph || g.comm) return vcycle0_eager(h, u, rhs);
+// u_zero: the caller guarantees a zero iterate WITHOUT having written it (see vcycle_level)
+int vcycle0(sgpu_amg *h, double *u, const double *rhs, bool u_zero = false) {
+    if (!h->prm.use_graph || g.comm) return vcycle0_eager(h, u, rhs, u_zero);
     for (auto &c : h->graphs)
-        if (c.u == u && c.rhs == rhs) { HIPCHK(hipGraphLaunch(c.exec, g.cs)); return SGPU_OK; }
-    sgpu_amg::Captured c{u, rhs, nullptr, nullptr};
+        if (c.u == u && c.rhs == rhs && c.u_zero == u_zero) { HIPCHK(hipGraphLaunch(c.exec, g.cs)); return SGPU_OK; }
+    sgpu_amg::Captured c{u, rhs, u_zero, nullptr, nullptr};
     HIPCHK(hipStreamBeginCapture(g.cs, hipStreamCaptureModeThreadLocal));
-    const int st = vcycle0_eager(h, u, rhs);
+    const int st = vcycle0_eager(h, u, rhs, u_zero);
     const hipError_t e = hipStreamEndCapture(g.cs, &c.graph);
     if (st != SGPU_OK) { if (c.graph) hipGraphDestroy(c.graph); return st; }
     if (e != hipSuccess) return fail(SGPU_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
@@ -1372,8 +1395,7 @@ int sgpu_solve_pCG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, valu
     double init_dot = 0, current_dot = 0;
     CHK(sgpu_dot(r, r, sz, &init_dot));
     if (hist && cap > 0) hist[0] = std::sqrt(init_dot);
-    CHK(sgpu_vec_fill(rho, 0.0, sz));
-    CHK(vcycle0(h, rho, r));                                          // :2536-2537
+    CHK(vcycle0(h, rho, r, true));                                    // :2536-2537 (rho = 0, V-cycle)
     CHK(sgpu_vec_copy(p, rho, sz));
     const double THRSHLD = init_dot * h->prm.solver_tol * h->prm.solver_tol;
     current_dot = init_dot;
@@ -1391,8 +1413,7 @@ int sgpu_solve_pCG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, valu
         CHK(pcg_update_dev(a, 5, p, hh, u, r, sz, 6, &current_dot));  // alpha = rho_res / pdoth; :2593-2596; :2603
         if (hist && i + 1 < cap) hist[i + 1] = std::sqrt(current_dot);
         if (current_dot < THRSHLD) break;                             // :2620
-        CHK(sgpu_vec_fill(rho, 0.0, sz));                             // :2640
-        CHK(vcycle0(h, rho, r));                                      // :2641
+        CHK(vcycle0(h, rho, r, true));                                // :2640-2641 (rho = 0, V-cycle)
         CHK(dot_dev(r, rho, sz, b));                                  // :2655
         CHK(pcg_direction_dev(b, a, rho, p, sz));                     // beta = r.rho / rho_res; :2665-2667  p = rho + beta p
         std::swap(a, b);
