@@ -68,6 +68,7 @@ public:
 
     int assemble(bool scale = false, bool use_dense = false);
     int assemble_band_matrix(bool use_dense = false);
+    int writeMatrixToFile(const std::string &name = "") const;   // "<name>-r<rank>.mtx", MatrixMarket coordinate real general
 
     saena_host::saena_matrix *get_internal_matrix();
     comm    get_comm();

@@ -43,6 +43,7 @@ int   saena_matrix_set(saena_matrix_h *A, index_t i, index_t j, value_t val);   
 int   saena_matrix_set_many(saena_matrix_h *A, const index_t *row, const index_t *col, const value_t *val, nnz_t n); /* :30 */
 int   saena_matrix_read_file(saena_matrix_h *A, const char *name, const char *input_type /* "" */);     /* saena.hpp:25-26 */
 int   saena_matrix_write_bin(saena_matrix_h *A, const char *name);
+int   saena_matrix_write_mtx(saena_matrix_h *A, const char *name);   /* saena.hpp:53 writeMatrixToFile: "<name>-r<rank>.mtx" */
 int   saena_matrix_set_remove_boundary(saena_matrix_h *A, int remove_bound);                        /* :44 */
 int   saena_matrix_add_duplicates(saena_matrix_h *A, int add);                                      /* :47 */
 int   saena_matrix_set_eig(saena_matrix_h *A, double eig);                                          /* :38 (value form) */

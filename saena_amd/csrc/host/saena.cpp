@@ -89,6 +89,7 @@ int matrix::assemble(bool scale, bool use_dense) {
     return m_pImpl->assemble();
 }
 int matrix::assemble_band_matrix(bool use_dense) { return assemble(false, use_dense); }
+int matrix::writeMatrixToFile(const std::string &name) const { return m_pImpl->writeMatrixToFile(name.empty() ? "mat" : name); }
 saena_host::saena_matrix *matrix::get_internal_matrix() { return m_pImpl; }
 comm matrix::get_comm() { return c_; }
 index_t matrix::get_num_rows() { return m_pImpl->remove_boundary ? m_pImpl->Mbig_with_bound : m_pImpl->Mbig; }   // saena.cpp:188: size before removing boundary

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <fstream>
 #include <numeric>
+#include <iomanip>
 #include <sstream>
 
 namespace saena_host {
@@ -140,6 +141,30 @@ int saena_matrix::write_bin(const std::string &filename) const {
             for (index_t j = 0; j < L.nnzPerRow_local[i]; ++j, ++k) e.emplace_back(i + split[comm->rank], L.col_local[k], L.val_local[k]);
         std::sort(e.begin(), e.end(), col_major);
         out.write(reinterpret_cast<const char *>(e.data()), (std::streamsize)(e.size() * sizeof(cooEntry)));
+    }
+    return 0;
+}
+
+int saena_matrix::writeMatrixToFile(const std::string &name) const {
+    if (!assembled) throw std::runtime_error("writeMatrixToFile: the matrix is not assembled");
+    const int rank = comm->rank;
+    const std::string fn = name + "-r" + std::to_string(rank) + ".mtx";
+    std::ofstream out(fn);
+    if (!out) throw std::runtime_error("could not open <" + fn + "> for writing");
+    if (rank == 0) {
+        out << "%%MatrixMarket matrix coordinate real general" << std::endl;
+        out << Mbig << "\t" << Mbig << "\t" << nnz_g << std::endl;
+    }
+    out << std::setprecision(12);
+    if (!entry.empty()) {
+        for (const auto &e : entry) out << e.row + 1 << "\t" << e.col + 1 << "\t" << e.val << "\n";
+    } else {                                   // one-rank CSR-only operators (coarse levels): column-major like `entry`
+        std::vector<cooEntry> e;
+        nnz_t k = 0;
+        for (index_t i = 0; i < L.M; ++i)
+            for (index_t j = 0; j < L.nnzPerRow_local[i]; ++j, ++k) e.emplace_back(i + split[rank], L.col_local[k], L.val_local[k]);
+        std::sort(e.begin(), e.end(), col_major);
+        for (const auto &x : e) out << x.row + 1 << "\t" << x.col + 1 << "\t" << x.val << "\n";
     }
     return 0;
 }

@@ -90,6 +90,9 @@ public:
     int read_file(const std::string &filename, const std::string &input_type = "");
     // write this rank's assembled entries as 16-byte triples (the reference's .bin format, :198-203)
     int write_bin(const std::string &filename) const;
+    // saena_matrix::writeMatrixToFile (saena_matrix.cpp:1205-1249): this rank's entries as "<name>-r<rank>.mtx",
+    // 1-based, 12 significant digits; rank 0's file carries the MatrixMarket header
+    int writeMatrixToFile(const std::string &name) const;
     // assemble (saena_matrix_setup.cpp:4): setup_initial_data + repartition_nnz_initial + matrix_setup
     int assemble();
     // skip the repartition and use the given row split (entries must already be global/deduplicated)

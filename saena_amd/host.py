@@ -34,6 +34,7 @@ HOST_SYMBOLS = {
     "saena_matrix_set_many": (C.c_int, [_VP, _PI, _PI, _PD, C.c_long]),
     "saena_matrix_read_file": (C.c_int, [_VP, C.c_char_p, C.c_char_p]),
     "saena_matrix_write_bin": (C.c_int, [_VP, C.c_char_p]),
+    "saena_matrix_write_mtx": (C.c_int, [_VP, C.c_char_p]),
     "saena_matrix_set_remove_boundary": (C.c_int, [_VP, C.c_int]),
     "saena_matrix_add_duplicates": (C.c_int, [_VP, C.c_int]),
     "saena_matrix_set_eig": (C.c_int, [_VP, C.c_double]),
@@ -235,6 +236,10 @@ class Matrix:
 
     def write_bin(self, name):
         _check(self.L, self.L.saena_matrix_write_bin(self.h, os.fsencode(name)))
+
+    def write_mtx(self, name):
+        """saena::matrix::writeMatrixToFile: this rank's entries as <name>-r<rank>.mtx"""
+        _check(self.L, self.L.saena_matrix_write_mtx(self.h, os.fsencode(name)))
 
     def set_remove_boundary(self, flag):
         self.L.saena_matrix_set_remove_boundary(self.h, 1 if flag else 0)

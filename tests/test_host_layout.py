@@ -207,3 +207,17 @@ def test_fatal_signal_prints_the_measured_line():
             "print('not reached')\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 0 and out.stdout == '{"metric": "x"}\n', (out.returncode, out.stdout, out.stderr[-500:])
+
+
+def test_write_matrix_to_file_roundtrip(tmp_path):
+    """saena::matrix::writeMatrixToFile: "<name>-r0.mtx" (header + 1-based triples) reads back to the same operator"""
+    comm = host.Comm("host", "self")
+    A = host.Matrix(comm).laplacian3D(9).assemble()           # stencil values are exact in 12 digits
+    A.write_mtx(str(tmp_path / "lap"))
+    fn = tmp_path / "lap-r0.mtx"
+    head = fn.read_text().splitlines()[:2]
+    assert head[0] == "%%MatrixMarket matrix coordinate real general" and head[1].split() == [str(A.num_rows), str(A.num_rows), str(A.nnz)]
+    B = host.Matrix(comm)
+    B.set_remove_boundary(False)
+    B.read_file(str(fn)).assemble()
+    assert_layout_equal(B.layout(), A.layout(), "roundtrip")
