@@ -130,7 +130,8 @@ Csr transpose(const Csr &A) {
 // C = A B (row-wise Gustavson, rows of C sorted by column, row chunks on threads).  Entries with
 // |v| <= ALMOST_ZERO are dropped unless row id == column id, the rule of the reference's SpGEMM
 // output (saena_object_setup_matmat.cpp:2423,2442).
-Csr spgemm(const Csr &A, const Csr &B) {
+// row_offset: global id of row 0 (distributed setup: the "row id == column id" exemption is about GLOBAL ids)
+Csr spgemm(const Csr &A, const Csr &B, index_t row_offset = 0) {
     Csr C;
     C.nrows = A.nrows; C.ncols = B.ncols;
     // work estimate per row for load balance
@@ -178,7 +179,7 @@ Csr spgemm(const Csr &A, const Csr &B) {
                 }
                 std::sort(cols.begin(), cols.end());
                 for (index_t j : cols) {
-                    if (std::fabs(acc[j]) > SAENA_ALMOST_ZERO || i == j) { oc.push_back(j); ov.push_back(acc[j]); ++cnt; }
+                    if (std::fabs(acc[j]) > SAENA_ALMOST_ZERO || i + row_offset == j) { oc.push_back(j); ov.push_back(acc[j]); ++cnt; }
                     mark[j] = 0;
                 }
             } else {                                                      // hash accumulator, grown by rehashing at load 1/2
@@ -224,7 +225,7 @@ Csr spgemm(const Csr &A, const Csr &B) {
                 for (size_t h : slots) hkey[h] = -1;                      // cleared after ALL look-ups: probing needs the chains intact
                 std::sort(out.begin(), out.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
                 for (const auto &e : out)
-                    if (std::fabs(e.second) > SAENA_ALMOST_ZERO || i == e.first) { oc.push_back(e.first); ov.push_back(e.second); ++cnt; }
+                    if (std::fabs(e.second) > SAENA_ALMOST_ZERO || i + row_offset == e.first) { oc.push_back(e.first); ov.push_back(e.second); ++cnt; }
             }
             rowlen[i] = cnt;
         }
@@ -461,7 +462,7 @@ double amg_hierarchy::find_eig(const saena_matrix &A) {
 }
 
 // filter (setup2:852-916): entries with |v| <= THRE are lumped into the diagonal (one-rank CSR form)
-static void filter_csr(Csr &C, double THRE) {
+static void filter_csr(Csr &C, double THRE, index_t row_offset = 0) {
     const index_t n = C.nrows;
     std::vector<nnz_t> nptr((size_t)n + 1, 0);
     std::vector<index_t> ncol;
@@ -472,10 +473,11 @@ static void filter_csr(Csr &C, double THRE) {
         bool has_diag = false;
         const size_t row_start = ncol.size();
         size_t diag_pos = 0;
+        const index_t gi = i + row_offset;
         for (nnz_t k = C.ptr[i]; k < C.ptr[i + 1]; ++k) {
             const index_t j = C.col[k];
-            if (std::fabs(C.val[k]) > THRE || j == i) {
-                if (j == i) { has_diag = true; diag_pos = ncol.size(); }
+            if (std::fabs(C.val[k]) > THRE || j == gi) {
+                if (j == gi) { has_diag = true; diag_pos = ncol.size(); }
                 ncol.push_back(j); nval.push_back(C.val[k]);
             } else {
                 add2diag += C.val[k];
@@ -486,8 +488,8 @@ static void filter_csr(Csr &C, double THRE) {
             if (std::fabs(nval[diag_pos]) < SAENA_ALMOST_ZERO) nval[diag_pos] = 1.0;
         } else {                                             // :896-903 missing diagonal -> 1.0, kept in column order
             size_t pos = row_start;
-            while (pos < ncol.size() && ncol[pos] < i) ++pos;
-            ncol.insert(ncol.begin() + pos, i);
+            while (pos < ncol.size() && ncol[pos] < gi) ++pos;
+            ncol.insert(ncol.begin() + pos, gi);
             nval.insert(nval.begin() + pos, 1.0);
         }
         nptr[i + 1] = (nnz_t)ncol.size();
@@ -683,10 +685,439 @@ void amg_hierarchy::distribute(Comm &c, const std::vector<index_t> &split0) {
     }
 }
 
+// ===========================================================================
+// Distributed setup: every rank builds only ITS rows of every level.  The algorithms are the one-rank ones
+// above, row block by row block; what a row block needs from other ranks (state of the aggregation, rows of
+// A and P on the far side of the partition boundary) is fetched through FetchPlan.  Orders of accumulation are
+// those of the one-rank code, so the hierarchy is the one-rank hierarchy bit for bit (tests/test_amg_setup.py).
+namespace {
+
+int owner_of_id(const std::vector<index_t> &split, index_t id) {
+    const int np = (int)split.size() - 1;
+    int p = (int)(std::upper_bound(split.begin(), split.end(), id) - split.begin()) - 1;
+    if (p < 0) p = 0;
+    if (p > np - 1) p = np - 1;
+    while (p < np - 1 && split[p + 1] <= id) ++p;      // empty blocks share a boundary value
+    while (p > 0 && split[p] > id) --p;
+    return p;
+}
+
+// a fixed list of global ids owned by other ranks, and the machinery to get per-id data from their owners
+struct FetchPlan {
+    std::vector<index_t> wanted;            // sorted, unique, none owned by this rank
+    std::vector<int> scount, rcount;        // ids I ask of each rank / ids each rank asks of me
+    std::vector<index_t> serve;             // local indices I serve, grouped by asking rank
+    index_t lo = 0;
+
+    void build(Comm &c, const std::vector<index_t> &split, std::vector<index_t> ids) {
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        wanted.swap(ids);
+        lo = split[c.rank];
+        scount.assign((size_t)c.nranks, 0);
+        for (index_t g : wanted) scount[owner_of_id(split, g)]++;
+        serve = c.alltoallv_records(wanted, scount, &rcount);
+        for (auto &x : serve) x -= lo;
+    }
+    index_t pos(index_t g) const { return (index_t)(std::lower_bound(wanted.begin(), wanted.end(), g) - wanted.begin()); }
+    // one T per wanted id, from the owner's local array
+    template <class T>
+    std::vector<T> values(Comm &c, const std::vector<T> &local) const {
+        std::vector<T> out((size_t)serve.size());
+        for (size_t i = 0; i < serve.size(); ++i) out[i] = local[(size_t)serve[i]];
+        return c.alltoallv_records(out, rcount);
+    }
+    // the rows `wanted` of a row-distributed CSR (global column ids), in the order of `wanted`
+    Csr rows(Comm &c, const Csr &local) const {
+        std::vector<nnz_t> len((size_t)local.nrows);
+        for (index_t i = 0; i < local.nrows; ++i) len[i] = local.ptr[i + 1] - local.ptr[i];
+        const std::vector<nnz_t> rlen = values(c, len);
+        std::vector<int> sc((size_t)c.nranks, 0);
+        std::vector<index_t> scol;
+        std::vector<value_t> sval;
+        size_t q = 0;
+        for (int p = 0; p < c.nranks; ++p)
+            for (int k = 0; k < rcount[p]; ++k, ++q) {
+                const index_t i = serve[q];
+                sc[p] += (int)len[i];
+                scol.insert(scol.end(), local.col.begin() + local.ptr[i], local.col.begin() + local.ptr[i + 1]);
+                sval.insert(sval.end(), local.val.begin() + local.ptr[i], local.val.begin() + local.ptr[i + 1]);
+            }
+        Csr R;
+        R.nrows = (index_t)wanted.size(); R.ncols = local.ncols;
+        R.col = c.alltoallv_records(scol, sc);
+        R.val = c.alltoallv_records(sval, sc);
+        R.ptr.assign((size_t)R.nrows + 1, 0);
+        for (index_t i = 0; i < R.nrows; ++i) R.ptr[i + 1] = R.ptr[i] + rlen[i];
+        if ((size_t)R.ptr[R.nrows] != R.col.size()) throw std::runtime_error("FetchPlan::rows: length mismatch");
+        return R;
+    }
+};
+
+// ids referenced by the columns of `M` that fall outside [lo, hi)
+std::vector<index_t> outside_cols(const Csr &M, index_t lo, index_t hi) {
+    std::vector<index_t> ids;
+    for (index_t cidx : M.col) if (cidx < lo || cidx >= hi) ids.push_back(cidx);
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    return ids;
+}
+
+// local rows + fetched rows stacked; columns of `M` relabelled to row positions in that stack (order untouched)
+Csr stack_rows(const Csr &local, const Csr &halo) {
+    Csr B;
+    B.nrows = local.nrows + halo.nrows; B.ncols = local.ncols;
+    B.ptr = local.ptr;
+    const nnz_t base = local.ptr[local.nrows];
+    for (index_t i = 0; i < halo.nrows; ++i) B.ptr.push_back(base + halo.ptr[i + 1]);
+    B.col = local.col; B.col.insert(B.col.end(), halo.col.begin(), halo.col.end());
+    B.val = local.val; B.val.insert(B.val.end(), halo.val.begin(), halo.val.end());
+    return B;
+}
+Csr relabel_cols(const Csr &M, index_t lo, index_t hi, const FetchPlan &plan, index_t ext_rows) {
+    Csr R = M;
+    R.ncols = ext_rows;
+    const index_t nloc = hi - lo;
+    for (auto &cidx : R.col) cidx = (cidx >= lo && cidx < hi) ? cidx - lo : nloc + plan.pos(cidx);
+    return R;
+}
+
+std::vector<cooEntry> csr_entries_colmajor(const Csr &M, index_t row_lo) {
+    std::vector<cooEntry> e;
+    e.reserve(M.col.size());
+    for (index_t i = 0; i < M.nrows; ++i)
+        for (nnz_t k = M.ptr[i]; k < M.ptr[i + 1]; ++k) e.emplace_back(i + row_lo, M.col[k], M.val[k]);
+    std::sort(e.begin(), e.end(), col_major);
+    return e;
+}
+
+struct AggState { index_t agg; char decided, is_root; char pad[2]; };
+
+} // namespace
+
+namespace {
+// find_eig above, row-distributed: same start vector (the LCG runs over the GLOBAL index), same recurrences; the dot
+// products are sums of per-rank partial sums, so the estimate agrees with the one-rank one to rounding (~1e-15)
+double dist_find_eig(Comm &c, const Csr &A, const std::vector<index_t> &split, const std::vector<value_t> &inv_diag, const FetchPlan &planA) {
+    const index_t lo = split[c.rank], hi = split[c.rank + 1], n = hi - lo, Mbig = split.back();
+    std::vector<double> isd((size_t)n);
+    for (index_t i = 0; i < n; ++i) isd[i] = std::sqrt(std::fabs(inv_diag[i]));
+    std::vector<double> isdE = isd;
+    { const std::vector<double> h = planA.values(c, isd); isdE.insert(isdE.end(), h.begin(), h.end()); }
+    const Csr Ar = relabel_cols(A, lo, hi, planA, n + (index_t)planA.wanted.size());
+    auto gsum = [&](double x) { c.allreduce_sum_f64(&x, 1); return x; };
+    auto matvec = [&](const std::vector<double> &x, std::vector<double> &y) {
+        std::vector<double> xE = x;
+        { const std::vector<double> h = planA.values(c, x); xE.insert(xE.end(), h.begin(), h.end()); }
+        for (index_t i = 0; i < n; ++i) {
+            double s_ = 0;
+            for (nnz_t k = Ar.ptr[i]; k < Ar.ptr[i + 1]; ++k) s_ += Ar.val[k] * isdE[(size_t)Ar.col[k]] * xE[(size_t)Ar.col[k]];
+            y[i] = s_ * isd[i];
+        }
+    };
+    const int m = (int)std::min<index_t>(20, Mbig);
+    std::vector<double> v((size_t)n), vprev((size_t)n, 0.0), w((size_t)n), alpha, beta;
+    unsigned long long lcg = 88172645463325252ULL;
+    double nrm = 0;
+    for (index_t gi = 0; gi < hi; ++gi) {
+        lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL;
+        if (gi >= lo) { v[(size_t)(gi - lo)] = ((lcg >> 11) * (1.0 / 9007199254740992.0)) * 2.0 - 1.0; nrm += v[(size_t)(gi - lo)] * v[(size_t)(gi - lo)]; }
+    }
+    nrm = std::sqrt(gsum(nrm));
+    for (auto &x : v) x /= nrm;
+    double b = 0;
+    for (int k = 0; k < m; ++k) {
+        matvec(v, w);
+        double a = 0;
+        for (index_t i = 0; i < n; ++i) a += w[i] * v[i];
+        a = gsum(a);
+        alpha.push_back(a);
+        for (index_t i = 0; i < n; ++i) w[i] -= a * v[i] + b * vprev[i];
+        b = 0;
+        for (index_t i = 0; i < n; ++i) b += w[i] * w[i];
+        b = std::sqrt(gsum(b));
+        if (k + 1 < m) beta.push_back(b);
+        if (b < 1e-300) break;
+        vprev = v;
+        for (index_t i = 0; i < n; ++i) v[i] = w[i] / b;
+    }
+    const int kdim = (int)alpha.size();
+    double l0 = alpha[0], h0 = alpha[0];
+    for (int i = 0; i < kdim; ++i) {
+        const double r = (i > 0 ? std::fabs(beta[i - 1]) : 0) + (i + 1 < kdim && i < (int)beta.size() ? std::fabs(beta[i]) : 0);
+        l0 = std::min(l0, alpha[i] - r); h0 = std::max(h0, alpha[i] + r);
+    }
+    auto count_below = [&](double x) {
+        int cnt = 0;
+        double d = 1;
+        for (int i = 0; i < kdim; ++i) {
+            const double b2 = i > 0 ? beta[i - 1] * beta[i - 1] : 0;
+            d = alpha[i] - x - (i > 0 ? b2 / d : 0);
+            if (d == 0) d = 1e-300;
+            if (d < 0) cnt++;
+        }
+        return cnt;
+    };
+    for (int it = 0; it < 200 && h0 - l0 > 1e-14 * std::max(std::fabs(l0), std::fabs(h0)); ++it) {
+        const double mid = 0.5 * (l0 + h0);
+        if (count_below(mid) >= kdim) h0 = mid; else l0 = mid;
+    }
+    return 1.0001 * 0.5 * (l0 + h0);
+}
+} // namespace
+
+int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o) {
+    Comm &c = *Ad->comm;
+    const int np = c.nranks, me = c.rank;
+    opts = o;
+    filter_thre_cur = opts.filter_thre;
+    filter_it = 0;
+    max_level = opts.max_level;
+    levels.clear();
+    levels.resize(1);
+    levels[0].A = Ad;
+    dist.clear();
+
+    // level 0: this rank's rows as CSR with global columns (entry is column-major)
+    std::vector<index_t> split = Ad->split;
+    Csr A;
+    {
+        std::vector<cooEntry> e = Ad->entry;
+        std::sort(e.begin(), e.end(), row_major);
+        const index_t lo = split[me], hi = split[me + 1];
+        A.nrows = hi - lo; A.ncols = Ad->Mbig;
+        A.ptr.assign((size_t)A.nrows + 1, 0);
+        for (const auto &x : e) A.ptr[(size_t)(x.row - lo) + 1]++;
+        for (index_t i = 0; i < A.nrows; ++i) A.ptr[i + 1] += A.ptr[i];
+        A.col.reserve(e.size()); A.val.reserve(e.size());
+        for (const auto &x : e) { A.col.push_back(x.col); A.val.push_back(x.val); }
+    }
+    std::vector<value_t> inv_diag = Ad->inv_diag;
+    index_t Mbig = Ad->Mbig;
+    const double om = Ad->jacobi_omega;
+
+    for (int l = 0;; ++l) {
+        PhaseTimer pt(l);
+        const index_t lo = split[me], hi = split[me + 1], nloc = hi - lo;
+        // ---- halo of A: the columns this rank's rows touch outside its block ----
+        FetchPlan planA;
+        planA.build(c, split, outside_cols(A, lo, hi));
+        dist.emplace_back();
+        {
+            dist_level &d = dist.back();
+            d.split = split; d.Mbig = Mbig; d.inv_diag = inv_diag; d.eig_max = l == 0 ? Ad->eig_max_of_invdiagXA : 0.0;
+            if (opts.smoother == "chebyshev" && std::fabs(d.eig_max) < SAENA_ALMOST_ZERO) {     // saena_object.cpp:201-204,:315
+                d.eig_max = dist_find_eig(c, A, split, inv_diag, planA);
+                if (l == 0) Ad->eig_max_of_invdiagXA = d.eig_max;
+            }
+            long nn = (long)A.col.size();
+            c.allreduce_sum_i64(&nn, 1);
+            d.nnzA = nn;
+            d.A.build(c, csr_entries_colmajor(A, lo), split, split);
+        }
+        if (l == max_level) break;
+
+        const index_t next = nloc + (index_t)planA.wanted.size();
+        auto ext = [&](index_t g) { return (g >= lo && g < hi) ? g - lo : nloc + planA.pos(g); };
+
+        // ---- strength graph (strength_graph above), columns as ext positions ----
+        std::vector<value_t> maxPerRow((size_t)nloc, -DBL_MAX);
+        for (index_t i = 0; i < nloc; ++i)
+            for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k)
+                if (A.col[k] != i + lo) maxPerRow[i] = std::max(maxPerRow[i], -A.val[k]);
+        std::vector<value_t> maxExt = maxPerRow;
+        { const std::vector<value_t> h = planA.values(c, maxPerRow); maxExt.insert(maxExt.end(), h.begin(), h.end()); }
+        std::vector<nnz_t> sptr((size_t)nloc + 1, 0);
+        std::vector<index_t> scol;                       // ext positions
+        for (index_t i = 0; i < nloc; ++i) {
+            for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+                const index_t j = A.col[k];
+                value_t s_, st;
+                if (i + lo == j) { s_ = 1; st = 1; }
+                else { s_ = -A.val[k] / maxPerRow[i]; st = -A.val[k] / maxExt[ext(j)]; }
+                if (s_ > opts.connStrength || st > opts.connStrength) scol.push_back(ext(j));
+            }
+            sptr[i + 1] = (nnz_t)scol.size();
+        }
+        pt.lap("strength graph");
+
+        // ---- aggregation: the synchronous rounds of aggregate() above; a round starts by refreshing the halo state ----
+        std::vector<AggState> st((size_t)next);
+        for (index_t i = 0; i < nloc; ++i) st[i] = AggState{i + lo, 0, 0, {0, 0}};
+        std::vector<index_t> aggregate2((size_t)nloc);
+        std::vector<char> dec_nei((size_t)nloc, 0), is_root_nei((size_t)nloc, 0);
+        std::vector<index_t> active((size_t)nloc);
+        for (index_t i = 0; i < nloc; ++i) active[i] = i;
+        long rounds = 0;
+        while (true) {
+            {
+                std::vector<AggState> loc(st.begin(), st.begin() + nloc);
+                const std::vector<AggState> h = planA.values(c, loc);
+                std::copy(h.begin(), h.end(), st.begin() + nloc);
+            }
+            for (index_t i : active) {
+                aggregate2[i] = st[i].agg; dec_nei[i] = 1; is_root_nei[i] = 0;
+                for (nnz_t it = sptr[i]; it < sptr[i + 1]; ++it) {
+                    const AggState &n = st[(size_t)scol[it]];
+                    if (n.agg < aggregate2[i] && (!n.decided || n.is_root)) { aggregate2[i] = n.agg; dec_nei[i] = n.decided; is_root_nei[i] = n.is_root; }
+                }
+            }
+            std::vector<index_t> left;
+            for (index_t i : active) {
+                if (dec_nei[i]) {
+                    st[i].decided = 1;
+                    if (st[i].agg == aggregate2[i]) st[i].is_root = 1;
+                    else if (is_root_nei[i]) st[i].agg = aggregate2[i];
+                } else {
+                    left.push_back(i);
+                }
+            }
+            active.swap(left);
+            ++rounds;
+            long undecided = (long)active.size();
+            c.allreduce_sum_i64(&undecided, 1);
+            if (undecided == 0) break;
+        }
+        // coarse numbering: roots in ascending fine order (aggregate_index_update); splitNew[r] = roots below rank r's block
+        std::vector<index_t> root_cid((size_t)nloc, -1);
+        index_t nroots = 0;
+        for (index_t i = 0; i < nloc; ++i) if (st[i].is_root) root_cid[i] = nroots++;
+        const std::vector<index_t> allroots = c.allgather_one(nroots);
+        std::vector<index_t> splitNew((size_t)np + 1, 0);
+        for (int p = 0; p < np; ++p) splitNew[p + 1] = splitNew[p] + allroots[p];
+        const index_t new_size = splitNew[np];
+        for (auto &x : root_cid) if (x >= 0) x += splitNew[me];
+        std::vector<index_t> aggc((size_t)nloc);            // coarse id of every local fine row
+        {
+            std::vector<index_t> far;
+            for (index_t i = 0; i < nloc; ++i) if (st[i].agg < lo || st[i].agg >= hi) far.push_back(st[i].agg);
+            FetchPlan pr;
+            pr.build(c, split, far);
+            const std::vector<index_t> h = pr.values(c, root_cid);
+            for (index_t i = 0; i < nloc; ++i) {
+                const index_t g = st[i].agg;
+                aggc[i] = (g >= lo && g < hi) ? root_cid[(size_t)(g - lo)] : h[(size_t)pr.pos(g)];
+                if (aggc[i] < 0) throw std::runtime_error("aggregation: a row joined a non-root");
+            }
+        }
+        if (std::getenv("SAENA_SETUP_TIMING") && me == 0) fprintf(stderr, "[aggregate] %ld rounds\n", rounds);
+        pt.lap("aggregation");
+        int ret_val = 0;
+        if (opts.dynamic_levels) {                                           // setup1:385-405
+            if ((unsigned)new_size <= least_row_threshold) ret_val = 1;
+            else if (static_cast<float>(new_size) / Mbig > row_reduction_up_thrshld) ret_val = 1;
+        }
+        // coarse partition: by the owner of the root; small levels live on rank 0 (saena_matrix_shrink.cpp:167-265)
+        std::vector<index_t> splitC = splitNew;
+        if (new_size <= shrink_rows) { splitC.assign((size_t)np + 1, new_size); splitC[0] = 0; }
+        const index_t clo = splitC[me], chi = splitC[me + 1];
+
+        // ---- P = (I - omega D^-1 A) P_tentative: local fine rows, global coarse columns ----
+        std::vector<index_t> aggcExt = aggc;
+        { const std::vector<index_t> h = planA.values(c, aggc); aggcExt.insert(aggcExt.end(), h.begin(), h.end()); }
+        Csr P;
+        P.nrows = nloc; P.ncols = new_size; P.ptr.assign((size_t)nloc + 1, 0);
+        {
+            std::vector<std::pair<index_t, value_t>> row;
+            for (index_t i = 0; i < nloc; ++i) {
+                row.clear();
+                for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+                    value_t vtmp = -om * inv_diag[i] * A.val[k];
+                    if (i + lo == A.col[k]) vtmp += 1;
+                    row.emplace_back(aggcExt[(size_t)ext(A.col[k])], vtmp);
+                }
+                std::stable_sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+                for (size_t q = 0; q < row.size(); ++q) {
+                    value_t v = row[q].second;
+                    while (q + 1 < row.size() && row[q + 1].first == row[q].first) v += row[++q].second;
+                    if (std::fabs(v) > SAENA_ALMOST_ZERO) { P.col.push_back(row[q].first); P.val.push_back(v); }
+                }
+                P.ptr[i + 1] = (nnz_t)P.col.size();
+            }
+        }
+        pt.lap("smoothed P");
+
+        // ---- R = P^T, rows to the owners of the coarse rows (under splitC), fine columns ascending ----
+        Csr R;
+        {
+            std::vector<cooEntry> send;
+            send.reserve(P.col.size());
+            for (index_t i = 0; i < nloc; ++i)
+                for (nnz_t k = P.ptr[i]; k < P.ptr[i + 1]; ++k) send.emplace_back(P.col[k], i + lo, P.val[k]);   // (coarse row, fine col)
+            std::sort(send.begin(), send.end(), row_major);
+            std::vector<int> sc((size_t)np, 0);
+            for (const auto &x : send) sc[owner_of_id(splitC, x.row)]++;
+            std::vector<cooEntry> got = c.alltoallv_records(send, sc);
+            std::sort(got.begin(), got.end(), row_major);
+            R.nrows = chi - clo; R.ncols = Mbig; R.ptr.assign((size_t)R.nrows + 1, 0);
+            for (const auto &x : got) R.ptr[(size_t)(x.row - clo) + 1]++;
+            for (index_t i = 0; i < R.nrows; ++i) R.ptr[i + 1] += R.ptr[i];
+            for (const auto &x : got) { R.col.push_back(x.col); R.val.push_back(x.val); }
+        }
+        pt.lap("R = P^T");
+
+        // ---- Ac = (R A) P (triple_mat_mult): rows of A, then rows of P, fetched for the columns outside this block ----
+        Csr RA;
+        {
+            FetchPlan pl;
+            pl.build(c, split, outside_cols(R, lo, hi));
+            const Csr Aext = stack_rows(A, pl.rows(c, A));
+            RA = spgemm(relabel_cols(R, lo, hi, pl, Aext.nrows), Aext, clo);
+        }
+        pt.lap("R*A");
+        Csr AcN;
+        {
+            FetchPlan pl;
+            pl.build(c, split, outside_cols(RA, lo, hi));
+            const Csr Pext = stack_rows(P, pl.rows(c, P));
+            AcN = spgemm(relabel_cols(RA, lo, hi, pl, Pext.nrows), Pext, clo);
+            RA = Csr();
+        }
+        pt.lap("(RA)*P");
+        if (++filter_it >= opts.filter_start) {
+            if (filter_thre_cur > opts.filter_max) filter_thre_cur = opts.filter_max;
+            filter_csr(AcN, filter_thre_cur, clo);
+            filter_thre_cur *= std::pow(10, opts.filter_rate);
+        }
+        pt.lap("filter");
+
+        // ---- this level's transfer operators in the reference's layout ----
+        {
+            dist_level &d = dist.back();
+            long nn = (long)P.col.size();
+            c.allreduce_sum_i64(&nn, 1);
+            d.nnzP = nn;
+            d.P.build(c, csr_entries_colmajor(P, lo), split, splitC);
+            d.R.build(c, csr_entries_colmajor(R, clo), splitC, split);
+        }
+        // ---- next level ----
+        std::vector<value_t> invd((size_t)(chi - clo), 1.0);
+        for (index_t i = 0; i < chi - clo; ++i)
+            for (nnz_t k = AcN.ptr[i]; k < AcN.ptr[i + 1]; ++k)
+                if (AcN.col[k] == i + clo) {
+                    if (std::fabs(AcN.val[k]) < SAENA_ALMOST_ZERO) throw std::runtime_error("there is a zero diagonal element at row index = " + std::to_string(i + clo));
+                    invd[i] = 1.0 / AcN.val[k];
+                }
+        A = std::move(AcN);
+        A.ncols = new_size;
+        inv_diag.swap(invd);
+        split = splitC;
+        Mbig = new_size;
+        pt.lap("layouts of P, R");
+        if (ret_val == 1) max_level = l + 1;                              // :287-289 this will be the last level
+    }
+    levels.resize(1);
+    return 0;
+}
+
 int amg_hierarchy::setup_distributed(saena_matrix *Ad, const amg_options &o) {
     Comm &c = *Ad->comm;
     if (!Ad->assembled) throw std::runtime_error("amg setup: the matrix is not assembled");
     if (c.nranks == 1) { setup(Ad, o); dist.clear(); return 0; }
+    // default: every rank builds only its rows (setup_rows_distributed).  The older gathered form (every rank builds
+    // the whole hierarchy, then keeps its rows; SAENA_SETUP=gathered) remains as a cross-check.
+    const char *mode = std::getenv("SAENA_SETUP");
+    if (!(mode && std::string(mode) == "gathered")) return setup_rows_distributed(Ad, o);
     // gather the fine operator on every rank (entries carry global ids)
     std::vector<int> counts = c.allgather_one((int)Ad->entry.size());
     std::vector<size_t> sc((size_t)c.nranks, Ad->entry.size() * sizeof(cooEntry)), sd((size_t)c.nranks, 0), rc((size_t)c.nranks), rd((size_t)c.nranks);

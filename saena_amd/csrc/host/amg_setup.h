@@ -75,7 +75,18 @@ public:
     std::unique_ptr<Comm> self_comm;
     index_t shrink_rows = 4096;
     int setup_distributed(saena_matrix *A_dist, const amg_options &o);
+    // the distributed setup proper: every rank builds its rows of every level (fills `dist` only)
+    int setup_rows_distributed(saena_matrix *A_dist, const amg_options &o);
     void distribute(Comm &c, const std::vector<index_t> &split0);
+
+    // per-level facts, whichever way the hierarchy was built
+    index_t level_rows(int l) const { return dist.empty() ? levels[(size_t)l].A->Mbig : dist[(size_t)l].Mbig; }
+    nnz_t   level_nnzA(int l) const { return dist.empty() ? levels[(size_t)l].A->nnz_g : dist[(size_t)l].nnzA; }
+    nnz_t   level_nnzP(int l) const { return l >= max_level ? 0 : dist.empty() ? levels[(size_t)l].P.nnz_g : dist[(size_t)l].nnzP; }
+    double  level_eig(int l) const {
+        const bool have = (size_t)l < levels.size() && levels[(size_t)l].A != nullptr;
+        return (dist.empty() || have) ? levels[(size_t)l].A->eig_max_of_invdiagXA : dist[(size_t)l].eig_max;
+    }
 
     // pieces, public for tests ------------------------------------------------
     // create_strength_matrix + strength_matrix::setup_matrix (setup1:520-719, strength_matrix.cpp:233-453):

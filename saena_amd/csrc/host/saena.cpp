@@ -223,20 +223,20 @@ int amg::set_matrix(saena::matrix *A, saena::options *opts) {
     const bool multi = !H_->dist.empty();
     std::vector<double> eig;
     for (int l = 0; l < n; ++l) {
-        const saena_host::amg_level &g = H_->levels[l];
+        const saena_host::amg_level *gp = multi ? nullptr : &H_->levels[l];
         sgpu_op_desc d; sgpu_op *op = nullptr;
         const int f32 = l >= o.float_level ? 1 : 0;          // float_level semantics (saena_object.cpp:241-244,277-285)
         if (l == 0) op = A->device_op();
         else {
-            if (multi) fill_desc(H_->dist[l].A, &H_->dist[l].inv_diag, &d); else fill_desc(g.A->L, &g.A->inv_diag, &d);
+            if (multi) fill_desc(H_->dist[l].A, &H_->dist[l].inv_diag, &d); else fill_desc(gp->A->L, &gp->A->inv_diag, &d);
             d.halo_fp32 = f32;
             gchk(sgpu_op_create(&d, &op), "sgpu_op_create(A)");
         }
         dA_.push_back(op);
-        eig.push_back(g.A->eig_max_of_invdiagXA);
+        eig.push_back(H_->level_eig(l));
         if (l < n - 1) {
-            fill_desc(multi ? H_->dist[l].P : g.P.L, nullptr, &d); d.halo_fp32 = f32; gchk(sgpu_op_create(&d, &op), "sgpu_op_create(P)"); dP_.push_back(op);
-            fill_desc(multi ? H_->dist[l].R : g.R.L, nullptr, &d); d.halo_fp32 = f32; gchk(sgpu_op_create(&d, &op), "sgpu_op_create(R)"); dR_.push_back(op);
+            fill_desc(multi ? H_->dist[l].P : gp->P.L, nullptr, &d); d.halo_fp32 = f32; gchk(sgpu_op_create(&d, &op), "sgpu_op_create(P)"); dP_.push_back(op);
+            fill_desc(multi ? H_->dist[l].R : gp->R.L, nullptr, &d); d.halo_fp32 = f32; gchk(sgpu_op_create(&d, &op), "sgpu_op_create(R)"); dR_.push_back(op);
         }
     }
     if (!std::getenv("SAENA_NO_AUTOTUNE"))
@@ -249,7 +249,7 @@ int amg::set_matrix(saena::matrix *A, saena::options *opts) {
     gchk(sgpu_amg_create(n, dA_.data(), dP_.data(), dR_.data(), eig.data(), &p, &damg_), "sgpu_amg_create");
     if (verbose && A->get_comm().rank() == 0) {
         printf("_____________________________\n\nnumber of levels = << %d >> (the finest level is 0)\n", n - 1);
-        for (int l = 0; l < n; ++l) printf("level %d: rows %d, nnz %ld\n", l, H_->levels[l].A->Mbig, (long)H_->levels[l].A->nnz_g);
+        for (int l = 0; l < n; ++l) printf("level %d: rows %d, nnz %ld\n", l, H_->level_rows(l), (long)H_->level_nnzA(l));
     }
     return 0;
 }

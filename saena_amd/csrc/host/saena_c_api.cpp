@@ -219,7 +219,7 @@ int saena_amg_num_levels(saena_amg_h *S) { return S->set ? S->H.max_level + 1 : 
 int saena_amg_level_split(saena_amg_h *S, int l, index_t *split_out) {
     return guard([&] {
         if (!S->set || l < 0 || l > S->H.max_level) throw std::runtime_error("bad level");
-        if (S->H.dist.empty()) { split_out[0] = 0; split_out[1] = S->H.levels[l].A->Mbig; }
+        if (S->H.dist.empty()) { split_out[0] = 0; split_out[1] = S->H.level_rows(l); }
         else std::copy(S->H.dist[l].split.begin(), S->H.dist[l].split.end(), split_out);
     });
 }
@@ -227,11 +227,10 @@ int saena_amg_level_split(saena_amg_h *S, int l, index_t *split_out) {
 int saena_amg_level_info(saena_amg_h *S, int l, index_t *rows, nnz_t *nnzA, nnz_t *nnzP, double *eig) {
     return guard([&] {
         if (!S->set || l < 0 || l > S->H.max_level) throw std::runtime_error("bad level");
-        const amg_level &g = S->H.levels[l];
-        if (rows) *rows = g.A->Mbig;
-        if (nnzA) *nnzA = g.A->nnz_g;
-        if (nnzP) *nnzP = l < S->H.max_level ? g.P.nnz_g : 0;
-        if (eig) *eig = g.A->eig_max_of_invdiagXA;
+        if (rows) *rows = S->H.level_rows(l);
+        if (nnzA) *nnzA = S->H.level_nnzA(l);
+        if (nnzP) *nnzP = S->H.level_nnzP(l);
+        if (eig) *eig = S->H.level_eig(l);
     });
 }
 
@@ -281,7 +280,7 @@ int saena_amg_to_device(saena_amg_h *S) {
         d.halo_fp32 = l >= fl ? 1 : 0;
         if (gchk(sgpu_op_create(&d, &o))) return -2;
         S->dA.push_back(o);
-        eig.push_back(S->H.levels[l].A->eig_max_of_invdiagXA);
+        eig.push_back(S->H.level_eig(l));
         if (l < n - 1) {
             if (saena_amg_level_desc(S, l, 1, &d)) return -1;
             d.halo_fp32 = l >= fl ? 1 : 0; if (gchk(sgpu_op_create(&d, &o))) return -2; S->dP.push_back(o);

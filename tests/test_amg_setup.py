@@ -89,7 +89,7 @@ def test_chebyshev_eig_estimate():
 
 
 # ---- multi-rank: redundant setup + per-level row partition (over gloo, no GPU) ----
-def _dist_worker(rank, world, port, m, ret):
+def _dist_worker(rank, world, port, m, ret, smoother="jacobi"):
     import os
     import sys
     import torch.distributed as dist
@@ -100,12 +100,18 @@ def _dist_worker(rank, world, port, m, ret):
         from tests.test_host_layout import assert_layout_equal, oracle_layout
         L = host.load("host")
         comm = host.Comm("host", "dist", dist)
+        kw = dict(host.OPTIONS001, smoother=smoother)
         A = host.Matrix(comm).laplacian3D(m).assemble()
-        S = host.AmgSolver(A, host.options(L, **host.OPTIONS001))
+        S = host.AmgSolver(A, host.options(L, **kw))
         # the same hierarchy at one rank, in this process
         A1 = host.Matrix(host.Comm("host", "self")).laplacian3D(m).assemble()
-        S1 = host.AmgSolver(A1, host.options(L, **host.OPTIONS001))
+        S1 = host.AmgSolver(A1, host.options(L, **kw))
         assert S.num_levels == S1.num_levels
+        for l in range(S.num_levels):
+            a, b = S.level_info(l), S1.level_info(l)
+            assert (a["rows"], a["nnzA"], a["nnzP"]) == (b["rows"], b["nnzA"], b["nnzP"]), (l, a, b)
+            if smoother == "chebyshev":      # per-rank partial sums in the Lanczos dots: equal to rounding
+                assert abs(a["eig_max"] - b["eig_max"]) <= 1e-12 * b["eig_max"], (l, a["eig_max"], b["eig_max"])
         splits = [S.level_split(l) for l in range(S.num_levels)]
         np.testing.assert_array_equal(splits[0], A.split)
         assert any(np.all(s[1:] == s[-1]) for s in splits[1:]), "small levels must shrink onto rank 0"
@@ -130,14 +136,20 @@ def _dist_worker(rank, world, port, m, ret):
         dist.destroy_process_group()
 
 
-def test_distributed_hierarchy_gloo():
+@pytest.mark.parametrize("mode,smoother,world", [("rows", "jacobi", 3), ("rows", "chebyshev", 4), ("gathered", "jacobi", 2)])
+def test_distributed_hierarchy_gloo(mode, smoother, world, monkeypatch):
+    """The hierarchy built over several ranks -- every rank building only its rows of every level (the default), or the
+    older gather-then-slice form -- is the one-rank hierarchy bit for bit: every level's A, P and R layout equals the
+    oracle's layout of the one-rank operator under that level's partition."""
     import torch.multiprocessing as mp
     from tests.test_host_layout import _free_port
-    world, port = 3, _free_port()
+    monkeypatch.setenv("SAENA_SETUP", mode)
+    monkeypatch.setenv("SAENA_SETUP_THREADS", "2")
+    port = _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 24, ret)) for r in range(world)]
+        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 24, ret, smoother)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
