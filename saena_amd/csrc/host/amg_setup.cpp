@@ -1,6 +1,6 @@
 // amg_setup.cpp -- smoothed-aggregation setup on the host (restatement; citations are
-// file:line in paralab/Saena).  Single-rank SpGEMM in this round: the hierarchy of a
-// multi-rank run must be built at one rank (amg_hierarchy::setup throws otherwise).
+// file:line in paralab/Saena).  amg_hierarchy::setup builds a hierarchy at one rank;
+// setup_rows_distributed builds the same hierarchy over several ranks, every rank its own rows.
 #include "amg_setup.h"
 
 #include <algorithm>

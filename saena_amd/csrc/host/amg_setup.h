@@ -65,11 +65,12 @@ public:
     // saena_object::setup (saena_object.cpp:175-406)
     int setup(saena_matrix *A, const amg_options &o);
 
-    // Multi-rank use (this round): the SpGEMM of the setup is single-rank, so every rank gathers the fine
-    // operator, builds the SAME hierarchy redundantly and keeps its row blocks.  Partition per level: the
-    // fine split is A's; a coarse level inherits it through the aggregates (splitNew[r] = number of roots
-    // below split[r], aggregate_index_update setup1:2115-2122); levels with <= shrink_rows rows live
+    // Multi-rank use: setup_distributed -> setup_rows_distributed, every rank builds its rows of every level (`dist`).
+    // Partition per level: the fine split is A's; a coarse level inherits it through the aggregates (splitNew[r] =
+    // number of roots below split[r], aggregate_index_update setup1:2115-2122); levels with <= shrink_rows rows live
     // entirely on rank 0 (the reference shrinks coarse levels onto fewer ranks, saena_matrix_shrink.cpp:167-265).
+    // SAENA_SETUP=gathered selects the older form: gather the fine operator, build the whole hierarchy on every
+    // rank (`levels`, `A_global`), keep the own rows (`distribute`).
     std::vector<dist_level> dist;
     std::unique_ptr<saena_matrix> A_global;      // the gathered fine operator (one-rank replica)
     std::unique_ptr<Comm> self_comm;
