@@ -722,11 +722,13 @@ struct FetchPlan {
     index_t pos(index_t g) const { return (index_t)(std::lower_bound(wanted.begin(), wanted.end(), g) - wanted.begin()); }
     // one T per wanted id, from the owner's local array
     template <class T>
-    std::vector<T> values(Comm &c, const std::vector<T> &local) const {
+    std::vector<T> values(Comm &c, const T *local) const {
         std::vector<T> out((size_t)serve.size());
         for (size_t i = 0; i < serve.size(); ++i) out[i] = local[(size_t)serve[i]];
         return c.alltoallv_records(out, rcount);
     }
+    template <class T>
+    std::vector<T> values(Comm &c, const std::vector<T> &local) const { return values(c, local.data()); }
     // the rows `wanted` of a row-distributed CSR (global column ids), in the order of `wanted`
     Csr rows(Comm &c, const Csr &local) const {
         std::vector<nnz_t> len((size_t)local.nrows);
@@ -782,12 +784,14 @@ Csr relabel_cols(const Csr &M, index_t lo, index_t hi, const FetchPlan &plan, in
     return R;
 }
 
+// the local rows of M as global-id entries in column-major order (counting sort by column: rows stay ascending)
 std::vector<cooEntry> csr_entries_colmajor(const Csr &M, index_t row_lo) {
-    std::vector<cooEntry> e;
-    e.reserve(M.col.size());
+    std::vector<nnz_t> cnt((size_t)M.ncols + 1, 0);
+    for (index_t cidx : M.col) cnt[(size_t)cidx + 1]++;
+    for (index_t j = 0; j < M.ncols; ++j) cnt[j + 1] += cnt[j];
+    std::vector<cooEntry> e(M.col.size());
     for (index_t i = 0; i < M.nrows; ++i)
-        for (nnz_t k = M.ptr[i]; k < M.ptr[i + 1]; ++k) e.emplace_back(i + row_lo, M.col[k], M.val[k]);
-    std::sort(e.begin(), e.end(), col_major);
+        for (nnz_t k = M.ptr[i]; k < M.ptr[i + 1]; ++k) e[(size_t)cnt[M.col[k]]++] = cooEntry(i + row_lo, M.col[k], M.val[k]);
     return e;
 }
 
@@ -915,10 +919,17 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             d.nnzA = nn;
             d.A.build(c, csr_entries_colmajor(A, lo), split, split);
         }
+        pt.lap("layout of A");
         if (l == max_level) break;
 
         const index_t next = nloc + (index_t)planA.wanted.size();
-        auto ext = [&](index_t g) { return (g >= lo && g < hi) ? g - lo : nloc + planA.pos(g); };
+        std::vector<index_t> aext(A.col.size());                    // ext position (local row, or nloc + halo position) of every column of A
+        parallel_rows(nloc, &A.ptr, [&](int, index_t a0, index_t a1) {
+            for (nnz_t k = A.ptr[a0]; k < A.ptr[a1]; ++k) {
+                const index_t g = A.col[k];
+                aext[(size_t)k] = (g >= lo && g < hi) ? g - lo : nloc + planA.pos(g);
+            }
+        });
 
         // ---- strength graph (strength_graph above), columns as ext positions ----
         std::vector<value_t> maxPerRow((size_t)nloc, -DBL_MAX);
@@ -934,49 +945,91 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                 const index_t j = A.col[k];
                 value_t s_, st;
                 if (i + lo == j) { s_ = 1; st = 1; }
-                else { s_ = -A.val[k] / maxPerRow[i]; st = -A.val[k] / maxExt[ext(j)]; }
-                if (s_ > opts.connStrength || st > opts.connStrength) scol.push_back(ext(j));
+                else { s_ = -A.val[k] / maxPerRow[i]; st = -A.val[k] / maxExt[(size_t)aext[(size_t)k]]; }
+                if (s_ > opts.connStrength || st > opts.connStrength) scol.push_back(aext[(size_t)k]);
             }
             sptr[i + 1] = (nnz_t)scol.size();
         }
         pt.lap("strength graph");
 
-        // ---- aggregation: the synchronous rounds of aggregate() above; a round starts by refreshing the halo state ----
+        // ---- aggregation: the synchronous rounds of aggregate() above.  A round starts by refreshing the state of the
+        //      halo rows; as there, a row is re-evaluated only when a row it looks at -- local or halo -- changed state ----
         std::vector<AggState> st((size_t)next);
         for (index_t i = 0; i < nloc; ++i) st[i] = AggState{i + lo, 0, 0, {0, 0}};
+        for (index_t j = nloc; j < next; ++j) st[j] = AggState{planA.wanted[(size_t)(j - nloc)], 0, 0, {0, 0}};
+        std::vector<nnz_t> tptr((size_t)next + 1, 0);               // who looks at ext position e: the transposed pattern
+        std::vector<index_t> tcol(scol.size());
+        for (index_t e : scol) tptr[(size_t)e + 1]++;
+        for (index_t e = 0; e < next; ++e) tptr[e + 1] += tptr[e];
+        {
+            std::vector<nnz_t> fill(tptr.begin(), tptr.end() - 1);
+            for (index_t i = 0; i < nloc; ++i)
+                for (nnz_t it = sptr[i]; it < sptr[i + 1]; ++it) tcol[fill[scol[it]]++] = i;
+        }
         std::vector<index_t> aggregate2((size_t)nloc);
-        std::vector<char> dec_nei((size_t)nloc, 0), is_root_nei((size_t)nloc, 0);
-        std::vector<index_t> active((size_t)nloc);
-        for (index_t i = 0; i < nloc; ++i) active[i] = i;
-        long rounds = 0;
+        std::vector<char> dec_nei((size_t)nloc, 0), is_root_nei((size_t)nloc, 0), queued((size_t)nloc, 1);
+        std::vector<index_t> work((size_t)nloc);
+        for (index_t i = 0; i < nloc; ++i) work[i] = i;
+        const int T = n_threads();
+        std::vector<std::vector<index_t>> tnext((size_t)T), tdone((size_t)T);
+        long rounds = 0, my_undecided = nloc;
         while (true) {
-            {
-                std::vector<AggState> loc(st.begin(), st.begin() + nloc);
-                const std::vector<AggState> h = planA.values(c, loc);
-                std::copy(h.begin(), h.end(), st.begin() + nloc);
-            }
-            for (index_t i : active) {
-                aggregate2[i] = st[i].agg; dec_nei[i] = 1; is_root_nei[i] = 0;
-                for (nnz_t it = sptr[i]; it < sptr[i + 1]; ++it) {
-                    const AggState &n = st[(size_t)scol[it]];
-                    if (n.agg < aggregate2[i] && (!n.decided || n.is_root)) { aggregate2[i] = n.agg; dec_nei[i] = n.decided; is_root_nei[i] = n.is_root; }
+            {   // halo refresh; the rows that look at a halo row whose state changed join this round's work list
+                const std::vector<AggState> h = planA.values(c, st.data());
+                for (size_t j = 0; j < h.size(); ++j) {
+                    AggState &old = st[(size_t)nloc + j];
+                    if (old.agg != h[j].agg || old.decided != h[j].decided || old.is_root != h[j].is_root) {
+                        old = h[j];
+                        for (nnz_t it = tptr[(size_t)nloc + j]; it < tptr[(size_t)nloc + j + 1]; ++it) {
+                            const index_t r = tcol[it];
+                            if (!st[r].decided && !queued[r]) { queued[r] = 1; work.push_back(r); }
+                        }
+                    }
                 }
+                std::sort(work.begin(), work.end());
             }
-            std::vector<index_t> left;
-            for (index_t i : active) {
-                if (dec_nei[i]) {
-                    st[i].decided = 1;
-                    if (st[i].agg == aggregate2[i]) st[i].is_root = 1;
-                    else if (is_root_nei[i]) st[i].agg = aggregate2[i];
-                } else {
-                    left.push_back(i);
+            const index_t nw = (index_t)work.size();
+            parallel_rows(nw, nullptr, [&](int, index_t a0, index_t a1) {
+                for (index_t q = a0; q < a1; ++q) {
+                    const index_t i = work[q];
+                    queued[i] = 0;
+                    aggregate2[i] = st[i].agg; dec_nei[i] = 1; is_root_nei[i] = 0;
+                    for (nnz_t it = sptr[i]; it < sptr[i + 1]; ++it) {
+                        const AggState &n = st[(size_t)scol[it]];
+                        if (n.agg < aggregate2[i] && (!n.decided || n.is_root)) { aggregate2[i] = n.agg; dec_nei[i] = n.decided; is_root_nei[i] = n.is_root; }
+                    }
                 }
-            }
-            active.swap(left);
+            });
+            for (auto &v : tdone) v.clear();
+            parallel_rows(nw, nullptr, [&](int t, index_t a0, index_t a1) {
+                for (index_t q = a0; q < a1; ++q) {
+                    const index_t i = work[q];
+                    if (dec_nei[i]) {
+                        st[i].decided = 1;
+                        if (st[i].agg == aggregate2[i]) st[i].is_root = 1;
+                        else if (is_root_nei[i]) st[i].agg = aggregate2[i];
+                        tdone[t].push_back(i);
+                    }
+                }
+            });
+            for (auto &v : tnext) v.clear();
+            std::vector<index_t> done;
+            for (auto &v : tdone) done.insert(done.end(), v.begin(), v.end());
+            my_undecided -= (long)done.size();
+            parallel_rows((index_t)done.size(), nullptr, [&](int t, index_t a0, index_t a1) {
+                for (index_t q = a0; q < a1; ++q)
+                    for (nnz_t it = tptr[done[q]]; it < tptr[done[q] + 1]; ++it) {
+                        const index_t r = tcol[it];
+                        if (!st[r].decided && !__atomic_exchange_n(&queued[r], (char)1, __ATOMIC_RELAXED)) tnext[t].push_back(r);
+                    }
+            });
+            work.clear();
+            for (auto &v : tnext) work.insert(work.end(), v.begin(), v.end());
             ++rounds;
-            long undecided = (long)active.size();
+            long undecided = my_undecided;
             c.allreduce_sum_i64(&undecided, 1);
             if (undecided == 0) break;
+            if (rounds > 4L * Mbig + 16) throw std::runtime_error("aggregation did not terminate");
         }
         // coarse numbering: roots in ascending fine order (aggregate_index_update); splitNew[r] = roots below rank r's block
         std::vector<index_t> root_cid((size_t)nloc, -1);
@@ -1024,7 +1077,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                 for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
                     value_t vtmp = -om * inv_diag[i] * A.val[k];
                     if (i + lo == A.col[k]) vtmp += 1;
-                    row.emplace_back(aggcExt[(size_t)ext(A.col[k])], vtmp);
+                    row.emplace_back(aggcExt[(size_t)aext[(size_t)k]], vtmp);
                 }
                 std::stable_sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
                 for (size_t q = 0; q < row.size(); ++q) {

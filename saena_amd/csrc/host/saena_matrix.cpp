@@ -378,6 +378,7 @@ void DistLayout::build(Comm &c, const std::vector<cooEntry> &entry, const std::v
     recvCount.assign((size_t)nprocs, 0);
     nnzPerProcScan.assign((size_t)nprocs + 1, 0);
     std::vector<cooEntry> ent_loc_row;
+    ent_loc_row.reserve((size_t)nnz_l);
     nnz_t i = 0;
     while (i < nnz_l) {                                                  // :828-859
         const long procNum = owner_of(split_col, entry[i].col);
@@ -408,10 +409,16 @@ void DistLayout::build(Comm &c, const std::vector<cooEntry> &entry, const std::v
     nnz_l_remote = (nnz_t)row_remote.size();
     col_remote_size = (index_t)vElement_remote.size();
     recvCount[rank] = 0;
-    std::sort(ent_loc_row.begin(), ent_loc_row.end(), row_major);        // :905
+    // :905 row-major order.  The local entries arrive column-major (rows ascending inside a column), so a counting
+    // sort by row -- the row lengths are known -- yields (row, column) order in one pass instead of an O(n log n) sort.
     row_local.resize((size_t)nnz_l_local); col_local.resize((size_t)nnz_l_local); val_local.resize((size_t)nnz_l_local);
-    for (nnz_t k = 0; k < nnz_l_local; ++k) {
-        row_local[k] = ent_loc_row[k].row; col_local[k] = ent_loc_row[k].col; val_local[k] = ent_loc_row[k].val;
+    {
+        std::vector<nnz_t> at((size_t)M + 1, 0);
+        for (index_t r = 0; r < M; ++r) at[r + 1] = at[r] + nnzPerRow_local[r];
+        for (const auto &e : ent_loc_row) {
+            const nnz_t k = at[e.row]++;
+            row_local[k] = e.row; col_local[k] = e.col; val_local[k] = e.val;
+        }
     }
     for (int p = 1; p < nprocs + 1; ++p) nnzPerProcScan[p] += nnzPerProcScan[p - 1];   // :948-950
 
