@@ -637,7 +637,7 @@ int amg_hierarchy::setup(saena_matrix *A, const amg_options &o) {
 }
 
 // ---------------------------------------------------------------------------
-// multi-rank: redundant one-rank setup, then row-partition every level
+// multi-rank, gathered form (SAENA_SETUP=gathered): one-rank setup on every rank, then row-partition every level
 
 namespace {
 // rows [lo,hi) of a one-rank layout as global-id entries, column-major sorted

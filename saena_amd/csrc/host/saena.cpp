@@ -218,7 +218,7 @@ int amg::set_matrix(saena::matrix *A, saena::options *opts) {
     o.filter_thre = opts->get_filter_thre(); o.filter_max = opts->get_filter_max(); o.filter_start = opts->get_filter_start();
     o.filter_rate = opts->get_filter_rate();
     H_ = new saena_host::amg_hierarchy();
-    H_->setup_distributed(A->get_internal_matrix(), o);      // one rank: plain setup; more: redundant setup + row partition
+    H_->setup_distributed(A->get_internal_matrix(), o);      // one rank: plain setup; more: every rank builds its rows of every level
     const int n = H_->max_level + 1;
     const bool multi = !H_->dist.empty();
     std::vector<double> eig;
