@@ -725,7 +725,7 @@ struct FetchPlan {
     std::vector<T> values(Comm &c, const T *local) const {
         std::vector<T> out((size_t)serve.size());
         for (size_t i = 0; i < serve.size(); ++i) out[i] = local[(size_t)serve[i]];
-        return c.alltoallv_records(out, rcount);
+        return c.alltoallv_known(out, rcount, scount);        // I serve rcount[p] ids to rank p and receive my scount[p] back
     }
     template <class T>
     std::vector<T> values(Comm &c, const std::vector<T> &local) const { return values(c, local.data()); }

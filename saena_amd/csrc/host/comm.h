@@ -57,6 +57,19 @@ struct Comm {
         if (rcount_out) *rcount_out = rcount;
         return recv;
     }
+    // the same with the receive counts already known (repeated exchanges over a fixed plan: no count round trip)
+    template <class T>
+    std::vector<T> alltoallv_known(const std::vector<T> &send, const std::vector<int> &scount, const std::vector<int> &rcount) {
+        std::vector<size_t> sc((size_t)nranks), sd((size_t)nranks), rc((size_t)nranks), rd((size_t)nranks);
+        size_t so = 0, ro = 0;
+        for (int i = 0; i < nranks; ++i) {
+            sc[i] = (size_t)scount[i] * sizeof(T); sd[i] = so; so += sc[i];
+            rc[i] = (size_t)rcount[i] * sizeof(T); rd[i] = ro; ro += rc[i];
+        }
+        std::vector<T> recv(ro / sizeof(T));
+        alltoallv(send.data(), sc.data(), sd.data(), recv.data(), rc.data(), rd.data());
+        return recv;
+    }
     long sum(long x) { allreduce_sum_i64(&x, 1); return x; }
     long max_(long x) {      // max through a gather (setup only)
         std::vector<long> all = allgather_one(x);
