@@ -468,7 +468,7 @@ int zero_sweep(sgpu_op *op, int cheby, double c0, const double *rhs, double *y, 
 
 // zero_first: the iterate in `u` is known to be zero (its CONTENT is not read): the first sweep skips the matrix
 int jacobi_pp(sgpu_op *op, int iter, double omega, double *u, double *alt, const double *rhs, double **out, bool zero_first = false) {
-    if (!op->inv_diag) return fail(SGPU_ERR_ARG, "jacobi: operator has no inv_diag");
+    if (!op->inv_diag && op->M > 0) return fail(SGPU_ERR_ARG, "jacobi: operator has no inv_diag");   // (a rank may own no rows of a level)
     double *cur = u, *nxt = alt;
     for (int j = 0; j < iter; ++j) {
         if (j == 0 && zero_first) {
@@ -485,7 +485,7 @@ int jacobi_pp(sgpu_op *op, int iter, double omega, double *u, double *alt, const
 
 // saena_matrix::chebyshev scalars, src/saena_matrix.cpp:1084-1091,1113-1117
 int cheby_pp(sgpu_op *op, int iter, double eig_max, double *u, double *alt, const double *rhs, double **out, bool zero_first = false) {
-    if (!op->inv_diag) return fail(SGPU_ERR_ARG, "chebyshev: operator has no inv_diag");
+    if (!op->inv_diag && op->M > 0) return fail(SGPU_ERR_ARG, "chebyshev: operator has no inv_diag");
     CHK(ensure_d(op));
     const double alpha = 0.13 * eig_max, beta = eig_max;
     const double delta = (beta - alpha) / 2.0, theta = (beta + alpha) / 2.0;
@@ -1212,7 +1212,7 @@ int sgpu_amg_create(int nlevels, sgpu_op *const *A, sgpu_op *const *P, sgpu_op *
             if (P[l]->M != A[l]->M || P[l]->N_local != A[l + 1]->M) return fail(SGPU_ERR_ARG, "P[%d] shape mismatch", l);
             if (R[l]->M != A[l + 1]->M || R[l]->N_local != A[l]->M) return fail(SGPU_ERR_ARG, "R[%d] shape mismatch", l);
             h->P.push_back(P[l]); h->R.push_back(R[l]);
-            if (!A[l]->inv_diag) return fail(SGPU_ERR_ARG, "A[%d] has no inv_diag", l);
+            if (!A[l]->inv_diag && A[l]->M > 0) return fail(SGPU_ERR_ARG, "A[%d] has no inv_diag", l);   // (no rows of this level on this rank: fine)
             if (h->prm.smoother == 1 && !(h->eig[l] > 0.0)) return fail(SGPU_ERR_ARG, "chebyshev needs eig_max[%d] > 0", l);
         }
     }

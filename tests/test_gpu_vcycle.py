@@ -317,6 +317,14 @@ def test_multirank_vcycle_emulated_on_one_gpu(capi, hier, P_):
             for r in range(P_):
                 WA[l].g[r].jacobi(1, us[r], rhss[r])
 
+    # every rank's own sgpu_amg over its share -- ranks > 0 own NO rows of the two shrunk levels, one of which is not
+    # the coarsest: creation and a V-cycle call must cope (values are meaningless here: no halo is routed inside the call)
+    for r in range(P_):
+        G_r = capi.Amg([w.g[r] for w in WA], [w.g[r] for w in WP], [w.g[r] for w in WR], pre=2, post=2, smoother="jacobi")
+        m_r = int(splits[0][r + 1] - splits[0][r])
+        G_r.vcycle(capi.DeviceVector(m_r, np.zeros(m_r)), capi.DeviceVector(m_r, np.ones(m_r)))
+        G_r.solve_pCG(capi.DeviceVector(m_r), capi.DeviceVector(m_r, np.ones(m_r)))
+
     n0 = As[0].shape[0]
     rhs, u0 = inputs.rhs2(n0), inputs.v2(n0) * 0.01
     us, rs = WA[0].slices(u0, splits[0]), WA[0].slices(rhs, splits[0])

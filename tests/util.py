@@ -9,7 +9,7 @@ def gpu_operator(op: "orc.OracleOp", r=0, halo_fp32=False):
     """Build an sgpu_op for simulated rank r from the oracle's storage layout
     (the same arrays a Saena maintainer would pass from saena_matrix members)."""
     R = op.rank(r)
-    has_diag = bool(R.inv_diag)
+    has_diag = bool(R.inv_diag) and R.M > 0      # like the product's fill_desc: no rows -> no inv_diag pointer
     return capi.Operator(
         M=R.M, N_local=int(op.split_col[r + 1] - op.split_col[r]), col_offset=int(op.split_col[r]),
         nnzPerRow_local=op.rank_array(r, "nnzPerRow_local", R.M, np.int32),
