@@ -187,7 +187,12 @@ def main():
         uid = capi.get_unique_id()
     # SAENA_BENCH_DEVICE: rehearsal aid (several ranks on one card, if the RCCL build allows it)
     device = int(os.environ.get("SAENA_BENCH_DEVICE", local_rank))
-    capi.init(device=device, rank=rank, nranks=world, unique_id=uid)
+    if world > 1 and os.environ.get("SAENA_BENCH_NO_RCCL"):
+        # rehearsal of the N > 1 control flow on ONE card (RCCL refuses several ranks per device): every rank gets a
+        # 1-rank GPU context without a communicator, so halos are simply not exchanged -- the numbers mean nothing
+        capi.init(device=device, rank=0, nranks=1, unique_id=None)
+    else:
+        capi.init(device=device, rank=rank, nranks=world, unique_id=uid)
 
     # ---- operator through the host mirror of saena::matrix (product path, no oracle) ----
     m = args.m
