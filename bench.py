@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--m", type=int, default=128, help="grid points per side (reference laplacian3D argument)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
-    ap.add_argument("--vcycle-timeout", type=float, default=240.0, help="watchdog of the multi-rank V-cycle legs, seconds")
+    ap.add_argument("--vcycle-timeout", type=float, default=360.0, help="watchdog of the multi-rank V-cycle legs, seconds")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
     return ap.parse_args()
 
