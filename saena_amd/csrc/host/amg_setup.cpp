@@ -1093,19 +1093,29 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         // ---- R = P^T, rows to the owners of the coarse rows (under splitC), fine columns ascending ----
         Csr R;
         {
-            std::vector<cooEntry> send;
-            send.reserve(P.col.size());
-            for (index_t i = 0; i < nloc; ++i)
-                for (nnz_t k = P.ptr[i]; k < P.ptr[i + 1]; ++k) send.emplace_back(P.col[k], i + lo, P.val[k]);   // (coarse row, fine col)
-            std::sort(send.begin(), send.end(), row_major);
+            // entries (coarse row, fine col) in (row, col) order by a counting sort over the coarse ids this rank touches;
+            // owners are contiguous ranges of coarse ids, so that order is also grouped by destination rank
+            index_t cmin = new_size, cmax = -1;
+            for (index_t cidx : P.col) { cmin = std::min(cmin, cidx); cmax = std::max(cmax, cidx); }
+            std::vector<cooEntry> send(P.col.size());
             std::vector<int> sc((size_t)np, 0);
-            for (const auto &x : send) sc[owner_of_id(splitC, x.row)]++;
-            std::vector<cooEntry> got = c.alltoallv_records(send, sc);
-            std::sort(got.begin(), got.end(), row_major);
+            if (cmax >= cmin) {
+                std::vector<nnz_t> at((size_t)(cmax - cmin) + 2, 0);
+                for (index_t cidx : P.col) at[(size_t)(cidx - cmin) + 1]++;
+                for (size_t j = 0; j + 1 < at.size(); ++j) at[j + 1] += at[j];
+                for (index_t i = 0; i < nloc; ++i)
+                    for (nnz_t k = P.ptr[i]; k < P.ptr[i + 1]; ++k) send[(size_t)at[(size_t)(P.col[k] - cmin)]++] = cooEntry(P.col[k], i + lo, P.val[k]);
+                for (const auto &x : send) sc[owner_of_id(splitC, x.row)]++;
+            }
+            // received blocks come from ranks in ascending order = ascending fine ids, each block in (row, col) order:
+            // a stable counting sort by row restores (row, col) order over the whole
+            const std::vector<cooEntry> got = c.alltoallv_records(send, sc);
             R.nrows = chi - clo; R.ncols = Mbig; R.ptr.assign((size_t)R.nrows + 1, 0);
             for (const auto &x : got) R.ptr[(size_t)(x.row - clo) + 1]++;
             for (index_t i = 0; i < R.nrows; ++i) R.ptr[i + 1] += R.ptr[i];
-            for (const auto &x : got) { R.col.push_back(x.col); R.val.push_back(x.val); }
+            R.col.resize(got.size()); R.val.resize(got.size());
+            std::vector<nnz_t> at(R.ptr.begin(), R.ptr.end() - 1);
+            for (const auto &x : got) { const nnz_t q = at[(size_t)(x.row - clo)]++; R.col[(size_t)q] = x.col; R.val[(size_t)q] = x.val; }
         }
         pt.lap("R = P^T");
 
