@@ -201,6 +201,9 @@ public:
     void matmat(saena::matrix *A, saena::matrix *B, saena::matrix *C, bool assemble = true, bool print_timing = false);
     void profile_matvecs();                                   // average matvec time of every level's A
 
+    int  switch_to_dense(bool val);                 // dense row-major storage for the coarse levels past the density threshold
+    int  set_dense_threshold(float thre);
+    double get_dense_threshold();
     int  set_verbose(bool verb);
     bool verbose = false;
     int  set_multigrid_max_level(int max);
@@ -219,6 +222,8 @@ private:
     std::vector<value_t> hist_;
     int iters_ = 0;
     bool dynamic_levels_ = true;
+    bool switch_to_dense_ = false;
+    float dense_thre_override_ = 0;
     int max_level_override_ = -1;
     void drop_device();
     int run(value_t *&u, saena::options *opts, int which, bool print_info);   // which: 0 solve, 1 solve_pCG, 2 solve_CG, 3 solve_smoother

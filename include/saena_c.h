@@ -92,6 +92,9 @@ typedef struct {
     int    float_level;
     double filter_thre, filter_max;
     int    filter_start, filter_rate;
+    int    switch_to_dense;      /* saena.hpp:146-148: store levels denser than dense_thre (and smaller than dense_sz_thre rows) */
+    float  dense_thre;           /* as dense row-major arrays -- saena_matrix_dense; off in every options file of the reference */
+    int    dense_sz_thre;
 } saena_options_c;
 int saena_options_default(saena_options_c *o);
 int saena_options_from_file(const char *xml_name, saena_options_c *o);   /* saena::options(const string&), saena.cpp:444-546 */

@@ -118,7 +118,9 @@ int sgpu_op_info(const sgpu_op *op, index_t *M, index_t *N_local, nnz_t *nnz_loc
 int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
 /* kernel variant of the local part: 0 k_csr_stream with 16 KiB tiles, 1 with 32 KiB tiles, 2 k_csr_vector
  * (no LDS staging), 3 / 4 k_csr_cc16 (16-bit compressed column ids, 10 B/nnz) on the 16 / 32 KiB plan;
- * 3 and 4 are refused when a block touches more than 16 column segments or holds a row longer than the tile */
+ * 3 and 4 are refused when a block touches more than 16 column segments or holds a row longer than the tile;
+ * 5 k_dense_rows: dense row-major storage (saena_matrix_dense, the reference's `switch_to_dense`), for operators
+ * without a halo, at most 8192 x 8192 and at least 10 % full */
 int sgpu_op_set_variant(sgpu_op *op, int variant);
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name);
 /* time a few (variant, lanes) candidates on this operator and keep the fastest (plan-time autotune) */

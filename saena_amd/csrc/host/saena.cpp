@@ -217,6 +217,8 @@ int amg::set_matrix(saena::matrix *A, saena::options *opts) {
     o.max_level = max_level_override_ >= 0 ? max_level_override_ : opts->get_max_lev(); o.float_level = opts->get_float_lev();
     o.filter_thre = opts->get_filter_thre(); o.filter_max = opts->get_filter_max(); o.filter_start = opts->get_filter_start();
     o.filter_rate = opts->get_filter_rate();
+    o.switch_to_dense = opts->get_switch_dense() || switch_to_dense_; o.dense_thre = opts->get_dense_thre(); o.dense_sz_thre = opts->get_dense_sz_thre();
+    if (dense_thre_override_ > 0) o.dense_thre = dense_thre_override_;
     H_ = new saena_host::amg_hierarchy();
     H_->setup_distributed(A->get_internal_matrix(), o);      // one rank: plain setup; more: every rank builds its rows of every level
     const int n = H_->max_level + 1;
@@ -242,6 +244,11 @@ int amg::set_matrix(saena::matrix *A, saena::options *opts) {
     if (!std::getenv("SAENA_NO_AUTOTUNE"))
         for (auto *v : {&dA_, &dP_, &dR_})
             for (sgpu_op *op : *v) gchk(sgpu_op_autotune(op), "sgpu_op_autotune");
+    if (o.switch_to_dense)                    // saena_object_setup2.cpp:328
+        for (int l = 1; l < n; ++l) {
+            const double rows = (double)H_->level_rows(l), dens = (double)H_->level_nnzA(l) / (rows * rows);
+            if (dens > o.dense_thre && rows <= o.dense_sz_thre) sgpu_op_set_variant(dA_[(size_t)l], 5);     // refused (halo, size): stays sparse
+        }
     sgpu_amg_params p;
     sgpu_amg_default_params(&p);
     p.preSmooth = o.preSmooth; p.postSmooth = o.postSmooth; p.smoother = o.smoother == "jacobi" ? 0 : 1;
@@ -298,6 +305,9 @@ int amg::run(value_t *&u, saena::options *opts, int which, bool print_info) {
 int amg::solve(value_t *&u, saena::options *opts) { return run(u, opts, 0, true); }
 int amg::solve_pCG(value_t *&u, saena::options *opts, bool print_info) { return run(u, opts, 1, print_info); }
 int amg::solve_CG(value_t *&u, saena::options *opts) { return run(u, opts, 2, true); }
+int amg::switch_to_dense(bool val) { switch_to_dense_ = val; return 0; }                 // saena.cpp:729-743
+int amg::set_dense_threshold(float thre) { dense_thre_override_ = thre; return 0; }
+double amg::get_dense_threshold() { return dense_thre_override_ > 0 ? dense_thre_override_ : 0.1; }
 int amg::solve_smoother(value_t *&u, saena::options *opts) { return run(u, opts, 3, true); }
 
 // saena_object::matmat + matmat_assemble (saena_object_setup_matmat.cpp:1164-1487,1640-1708)

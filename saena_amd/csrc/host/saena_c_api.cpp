@@ -184,6 +184,7 @@ int saena_options_default(saena_options_c *o) {
     o->preSmooth = d.preSmooth; o->postSmooth = d.postSmooth; o->connStrength = d.connStrength;
     o->dynamic_levels = d.dynamic_levels; o->max_level = d.max_level; o->float_level = d.float_level;
     o->filter_thre = d.filter_thre; o->filter_max = d.filter_max; o->filter_start = d.filter_start; o->filter_rate = d.filter_rate;
+    o->switch_to_dense = d.switch_to_dense; o->dense_thre = d.dense_thre; o->dense_sz_thre = d.dense_sz_thre;
     return 0;
 }
 
@@ -195,6 +196,7 @@ int saena_options_from_file(const char *name, saena_options_c *o) {
         o->preSmooth = d.preSmooth; o->postSmooth = d.postSmooth; o->connStrength = d.connStrength;
         o->dynamic_levels = d.dynamic_levels; o->max_level = d.max_level; o->float_level = d.float_level;
         o->filter_thre = d.filter_thre; o->filter_max = d.filter_max; o->filter_start = d.filter_start; o->filter_rate = d.filter_rate;
+        o->switch_to_dense = d.switch_to_dense; o->dense_thre = d.dense_thre; o->dense_sz_thre = d.dense_sz_thre;
     });
 }
 
@@ -208,6 +210,7 @@ int saena_amg_set_matrix(saena_amg_h *S, saena_matrix_h *A, const saena_options_
             d.preSmooth = o->preSmooth; d.postSmooth = o->postSmooth; d.connStrength = o->connStrength;
             d.dynamic_levels = o->dynamic_levels != 0; d.max_level = o->max_level; d.float_level = o->float_level;
             d.filter_thre = o->filter_thre; d.filter_max = o->filter_max; d.filter_start = o->filter_start; d.filter_rate = o->filter_rate;
+            d.switch_to_dense = o->switch_to_dense != 0; d.dense_thre = o->dense_thre; d.dense_sz_thre = o->dense_sz_thre;
         }
         S->H.setup_distributed(&A->A, d);
         S->set = true;
@@ -292,6 +295,11 @@ int saena_amg_to_device(saena_amg_h *S) {
         for (auto *v : {&S->dA, &S->dP, &S->dR})
             for (sgpu_op *o : *v)
                 if (gchk(sgpu_op_autotune(o))) return -2;
+    if (S->H.opts.switch_to_dense)            // saena_object_setup2.cpp:328: switch_to_dense && density > dense_thre && Mbig <= dense_sz_thre
+        for (int l = 1; l < n; ++l) {
+            const double rows = (double)S->H.level_rows(l), dens = (double)S->H.level_nnzA(l) / (rows * rows);
+            if (dens > S->H.opts.dense_thre && rows <= S->H.opts.dense_sz_thre) sgpu_op_set_variant(S->dA[(size_t)l], 5);   // refused (halo, size): stays sparse
+        }
     sgpu_amg_params p;
     sgpu_amg_default_params(&p);
     const amg_options &o = S->H.opts;

@@ -399,6 +399,22 @@ __global__ __launch_bounds__(BLOCK) void k_csr_vector(const SpmvArgs a, int nrow
 }
 
 // ---------------------------------------------------------------------------
+// K1c: dense row-major operator (saena_matrix_dense::matvec_dense, src/saena_matrix_dense.cpp:181-260,
+// the reference's optional `switch_to_dense` storage for coarse levels that are mostly full).  One wave per row streams
+// the row with coalesced 8-byte loads (no column ids: 8 B per entry instead of 12), the fused epilogues are the sparse ones.
+template <int EPI>
+__global__ __launch_bounds__(BLOCK) void k_dense_rows(const SpmvArgs a, const double *__restrict__ dense, int nrows, int ncols) {
+    const int r = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    double sum = 0.0;
+    if (r < nrows) {
+        const double *row = dense + (size_t)r * ncols;
+        for (int j = l; j < ncols; j += 64) sum += row[j] * a.x[j];
+    }
+    sum = group_sum<64>(sum);
+    if (r < nrows && l == 0) epilogue<EPI, false>(a, r, sum);
+}
+
+// ---------------------------------------------------------------------------
 // K2: boundary rows.  Rows that own remote entries are left out of the interior launch (SpmvArgs::skip)
 // and computed whole by this kernel on the halo stream, after the exchange: G lanes own one row, add its
 // local products (x) and then its remote products (halo buffer, ascending receive position = the order of

@@ -103,14 +103,18 @@ struct CsrPart {
     double *val = nullptr;
     int     nblk = 0, nblk_big = 0;
     int     lanes = 1;            // G
-    int     variant = 0;          // 0 stream 16 KiB, 1 stream 32 KiB, 2 vector CSR, 3 cc16 16 KiB, 4 cc16 32 KiB
+    int     variant = 0;          // 0 stream 16 KiB, 1 stream 32 KiB, 2 vector CSR, 3 cc16 16 KiB, 4 cc16 32 KiB, 5 dense rows
+    double *dense = nullptr;      // variant 5: row-major nrows x ncols (built on demand for small, mostly full operators)
+    int     ncols = 0;
+    std::vector<double> h_val;    // host copy of the values, kept only while a dense form is still possible
     // 16-bit compressed columns (variants 3/4): per plan ([0] 16 KiB, [1] 32 KiB) a segment table and packed column ids
     int            *segtab[2] = {nullptr, nullptr};
     unsigned short *ccol[2] = {nullptr, nullptr};
     bool            cc_ok[2] = {false, false};
     std::vector<int> h_rp, h_col, h_blk, h_blk_big;   // host copies kept for build_cc16 / the coarsest factorisation
     void free_all() {
-        hipFree(row_ptr); hipFree(col); hipFree(blk_row); hipFree(blk_row_big); hipFree(rows); hipFree(val);
+        hipFree(row_ptr); hipFree(col); hipFree(blk_row); hipFree(blk_row_big); hipFree(rows); hipFree(val); hipFree(dense);
+        dense = nullptr;
         for (int k = 0; k < 2; ++k) { hipFree(segtab[k]); hipFree(ccol[k]); segtab[k] = nullptr; ccol[k] = nullptr; }
         row_ptr = col = blk_row = blk_row_big = rows = nullptr; val = nullptr;
     }
@@ -157,6 +161,21 @@ int build_part(CsrPart &P, const std::vector<int> &rp, const std::vector<int> &c
     CHK(dev_upload(&P.val, val.data(), val.size(), 8));
     CHK(dev_upload(&P.blk_row, blk.data(), blk.size()));
     if (rows) CHK(dev_upload(&P.rows, rows->data(), rows->size()));
+    return SGPU_OK;
+}
+
+// dense form of a small, mostly full operator (saena_matrix_dense: rows <= dense_sz_thre 5000 by default)
+constexpr int DENSE_MAX_ROWS = 8192;
+bool dense_candidate(int nrows, int ncols, int64_t nnz) {
+    return nrows > 0 && ncols > 0 && nrows <= DENSE_MAX_ROWS && ncols <= DENSE_MAX_ROWS && (double)nnz >= 0.1 * (double)nrows * (double)ncols;
+}
+int build_dense(CsrPart &P) {
+    if (P.dense) return SGPU_OK;
+    if (P.h_val.empty() || P.h_rp.empty()) return fail(SGPU_ERR_ARG, "this operator is too large or too sparse for the dense form");
+    std::vector<double> d((size_t)P.nrows * P.ncols, 0.0);
+    for (int i = 0; i < P.nrows; ++i)
+        for (int k = P.h_rp[i]; k < P.h_rp[i + 1]; ++k) d[(size_t)i * P.ncols + P.h_col[k]] = P.h_val[k];
+    CHK(dev_upload(&P.dense, d.data(), d.size()));
     return SGPU_OK;
 }
 
@@ -298,7 +317,16 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.ccol = nullptr;
     const bool halo = skip != nullptr || seq != 0;
-    if (P.variant == 3 || P.variant == 4) {                       // 16-bit compressed columns
+    if (P.variant == 5) {                                         // dense rows, one wave per row
+        if (!P.dense) return fail(SGPU_ERR_STATE, "the dense form was not built");
+        if (halo) return fail(SGPU_ERR_STATE, "the dense form serves operators without a halo");
+        a.blk_row = nullptr; a.nblk = 0;
+        void (*kd)(const sk::SpmvArgs, const double *, int, int) =
+            epi == sk::EPI_SPMV ? sk::k_dense_rows<sk::EPI_SPMV> : epi == sk::EPI_RESIDUAL ? sk::k_dense_rows<sk::EPI_RESIDUAL>
+            : epi == sk::EPI_JACOBI ? sk::k_dense_rows<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows<sk::EPI_CHEBY0>
+            : epi == sk::EPI_CHEBYK ? sk::k_dense_rows<sk::EPI_CHEBYK> : sk::k_dense_rows<sk::EPI_SUB>;
+        hipLaunchKernelGGL(kd, dim3((P.nrows + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, (const double *)P.dense, P.nrows, P.ncols);
+    } else if (P.variant == 3 || P.variant == 4) {                       // 16-bit compressed columns
         const int k = P.variant - 3;
         if (!P.cc_ok[k]) return fail(SGPU_ERR_STATE, "compressed columns of plan %d were not built", k);
         a.blk_row = k ? P.blk_row_big : P.blk_row;
@@ -727,6 +755,8 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         }
         std::vector<double> val(d->val_local, d->val_local + d->nnz_l_local);
         CHK(build_part(op->loc, rp, col, val, nullptr));
+        op->loc.ncols = d->N_local;
+        if (dense_candidate(d->M, d->N_local, d->nnz_l_local)) op->loc.h_val = val;
         if (d->M <= sk::CG_MAXN) op->h_val = val;
     }
     // remote part: CSC over the receive buffer -> CSR over the halo buffer on the rows that own remote entries
@@ -841,7 +871,7 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>"};
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows"};
     if (variant) *variant = op->loc.variant;
     if (kernel_name) *kernel_name = names[op->loc.variant];
     return SGPU_OK;
@@ -849,8 +879,11 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 4) return fail(SGPU_ERR_ARG, "variant must be 0..4");
-    if (variant >= 3) {
+    if (variant < 0 || variant > 5) return fail(SGPU_ERR_ARG, "variant must be 0..5");
+    if (variant == 5) {
+        if (op->has_remote) return fail(SGPU_ERR_ARG, "the dense form serves operators without a halo");
+        CHK(build_dense(op->loc));
+    } else if (variant >= 3) {
         CHK(build_cc16(op->loc, variant - 3));
         if (!op->loc.cc_ok[variant - 3]) return fail(SGPU_ERR_ARG, "this operator's blocks touch more than 16 column segments (or hold a long row)");
     }
@@ -876,6 +909,8 @@ int sgpu_op_autotune(sgpu_op *op) {
     int bv = 0, bg = g0;
     std::vector<int> variants = {0, 1, 2};
     for (int k = 0; k < 2; ++k) { CHK(build_cc16(op->loc, k)); if (op->loc.cc_ok[k]) variants.push_back(3 + k); }
+    if (!op->has_remote && !op->loc.h_val.empty() && (double)op->loc.nnz >= 0.5 * (double)op->loc.nrows * op->loc.ncols && build_dense(op->loc) == SGPU_OK)
+        variants.push_back(5);                         // at least half full: the dense form moves fewer bytes
     // Only the LOCAL part is timed, without the halo exchange: ranks may end up with different candidate
     // lists (a rank's blocks may be too scattered for 16-bit columns), so no collective may run in here.
     EpiArgs e; e.rhs = r.p; e.inv_diag = op->inv_diag; e.u = x.p; e.c0 = JACOBI_OMEGA_REF;
@@ -898,6 +933,7 @@ int sgpu_op_autotune(sgpu_op *op) {
             }
     hipEventDestroy(e0); hipEventDestroy(e1);
     op->loc.variant = bv; op->loc.lanes = bg;
+    if (bv != 5 && op->loc.dense) { hipFree(op->loc.dense); op->loc.dense = nullptr; }
     for (int k = 0; k < 2; ++k)                       // free the compressed arrays of the plans that lost
         if (op->loc.cc_ok[k] && bv != 3 + k) {
             hipFree(op->loc.segtab[k]); hipFree(op->loc.ccol[k]);

@@ -65,7 +65,8 @@ class OptionsC(C.Structure):
     _fields_ = [("solver_max_iter", C.c_int), ("relative_tol", C.c_double), ("smoother", C.c_int),
                 ("preSmooth", C.c_int), ("postSmooth", C.c_int), ("connStrength", C.c_float),
                 ("dynamic_levels", C.c_int), ("max_level", C.c_int), ("float_level", C.c_int),
-                ("filter_thre", C.c_double), ("filter_max", C.c_double), ("filter_start", C.c_int), ("filter_rate", C.c_int)]
+                ("filter_thre", C.c_double), ("filter_max", C.c_double), ("filter_start", C.c_int), ("filter_rate", C.c_int),
+                ("switch_to_dense", C.c_int), ("dense_thre", C.c_float), ("dense_sz_thre", C.c_int)]
 
 
 HOST_SYMBOLS.update({

@@ -340,3 +340,34 @@ def test_error_codes_not_exit(capi):
     dx, dy = capi.DeviceVector(3, [1.0, 2.0, 3.0]), capi.DeviceVector(3, [9.0, 9.0, 9.0])
     Z.spmv(dx, dy)
     np.testing.assert_array_equal(dy.download(), [0.0, -4.5, 0.0])
+
+
+@pytest.mark.parametrize("name", ["band64_63", "band3000_1400", "band300_7", "poisson12"])
+def test_dense_variant(capi, name):
+    """variant 5, k_dense_rows (the reference's switch_to_dense storage, saena_matrix_dense): every fused epilogue
+    against the oracle on full / half-full operators; refused -- not mis-computed -- below 10 % fill"""
+    entries, M = get_problem(name)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    if len(entries) < 0.1 * M * M:
+        with pytest.raises(capi.SgpuError):
+            G.set_variant(5)
+        return
+    G.set_variant(5)
+    assert G.variant() == (5, "k_dense_rows")
+    x, rhs = inputs.v2(M), inputs.rhs2(M)
+    dx, dy, dr, dres = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs), capi.DeviceVector(M)
+    G.spmv(dx, dy)
+    assert np.all(np.abs(dy.download() - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
+    G.residual(dx, dr, dres)
+    assert rel(dres.download(), A.residual(x, rhs)) <= 1e-13
+    du = capi.DeviceVector(M, x)
+    G.jacobi(3, du, dr)
+    assert rel(du.download(), A.jacobi(3, x, rhs)) <= TOL_SMOOTH
+    A.set_eig(1.9371)
+    du.upload(x)
+    G.chebyshev(3, 1.9371, du, dr)
+    assert rel(du.download(), A.chebyshev(3, x, rhs)) <= TOL_SMOOTH
+    G.set_variant(0)                                   # and back
+    G.spmv(dx, dy)
+    assert np.all(np.abs(dy.download() - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)

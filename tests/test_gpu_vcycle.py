@@ -337,6 +337,27 @@ def test_multirank_vcycle_emulated_on_one_gpu(capi, hier, P_):
     assert rel(got, O1.vcycle(u0, rhs)) <= 1e-10
 
 
+def test_switch_to_dense_pipeline(capi):
+    """options.switch_to_dense (saena_object_setup2.cpp:328): levels denser than dense_thre are stored dense on the
+    device; same iteration count and residual history as the sparse hierarchy to the history tolerance"""
+    from saena_amd import host
+    L = host.load("gpu")
+    A = host.Matrix(host.Comm("gpu", "self")).laplacian3D(20).assemble()
+    rhs = A.laplacian3D_rhs()
+    S0 = host.AmgSolver(A, host.options(L, **host.OPTIONS001)).to_device()
+    S1 = host.AmgSolver(A, host.options(L, **dict(host.OPTIONS001, switch_to_dense=1, dense_thre=0.1, dense_sz_thre=5000))).to_device()
+    names = [S1.device_op(l).variant()[1] for l in range(S1.num_levels)]
+    dens = [S1.level_info(l)["nnzA"] / S1.level_info(l)["rows"] ** 2 for l in range(S1.num_levels)]
+    assert names[0] != "k_dense_rows" and any(n == "k_dense_rows" for n in names[1:]), (names, dens)
+    for l in range(1, S1.num_levels):
+        assert (names[l] == "k_dense_rows") == (dens[l] > 0.1), (l, names, dens)
+    u0, it0, h0, ok0 = S0.solve_pCG(rhs)
+    u1, it1, h1, ok1 = S1.solve_pCG(rhs)
+    assert ok0 and ok1 and it0 == it1
+    assert np.all(np.abs(h0 - h1) <= TOL_HIST * h0[0])
+    assert rel(u1, u0) <= 1e-9
+
+
 def _dist_gpu_worker(rank, world, port, ret):
     import os
     import sys
@@ -368,9 +389,15 @@ def test_distributed_hierarchy_reaches_the_device():
     (sgpu_op_create with 3-rank halo plans, levels this rank owns no rows of, sgpu_amg_create), solve_pCG -- in a
     1-rank GPU context per process.  Without a communicator only the local parts are applied, so the numbers mean
     nothing; the point is that every call on real distributed layouts succeeds (RCCL refuses 3 ranks on one card)."""
-    import torch.multiprocessing as mp
-    from tests.test_host_layout import _free_port
-    world, port = 3, _free_port()
+    # the standard library's multiprocessing, NOT torch's: importing torch here would load its bundled HIP runtime
+    # next to the system one this process already initialised (two runtimes in one process abort at exit); the
+    # children import torch first, like `bench.py --gpus N`
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    world = 3
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
