@@ -89,7 +89,7 @@ def test_chebyshev_eig_estimate():
 
 
 # ---- multi-rank: redundant setup + per-level row partition (over gloo, no GPU) ----
-def _dist_worker(rank, world, port, m, ret, smoother="jacobi"):
+def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False):
     import os
     import sys
     import torch.distributed as dist
@@ -101,11 +101,16 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi"):
         L = host.load("host")
         comm = host.Comm("host", "dist", dist)
         kw = dict(host.OPTIONS001, smoother=smoother)
-        A = host.Matrix(comm).laplacian3D(m).assemble()
+        if slab:      # bench.py's weak-scaled operator: even z-slabs of an m x m x (nz world + 2) grid (anisotropic: aggregates span ranks)
+            nz, n2 = 8, (m - 2) ** 2
+            A = host.Matrix(comm).laplacian3D(m, m, nz * world + 2)
+            A.assemble(np.array([r * n2 * nz for r in range(world + 1)], np.int32))
+            A1 = host.Matrix(host.Comm("host", "self")).laplacian3D(m, m, nz * world + 2).assemble()
+        else:
+            A = host.Matrix(comm).laplacian3D(m).assemble()
+            A1 = host.Matrix(host.Comm("host", "self")).laplacian3D(m).assemble()
         S = host.AmgSolver(A, host.options(L, **kw))
-        # the same hierarchy at one rank, in this process
-        A1 = host.Matrix(host.Comm("host", "self")).laplacian3D(m).assemble()
-        S1 = host.AmgSolver(A1, host.options(L, **kw))
+        S1 = host.AmgSolver(A1, host.options(L, **kw))     # the same hierarchy at one rank, in this process
         assert S.num_levels == S1.num_levels
         for l in range(S.num_levels):
             a, b = S.level_info(l), S1.level_info(l)
@@ -136,8 +141,9 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,smoother,world", [("rows", "jacobi", 3), ("rows", "chebyshev", 4), ("gathered", "jacobi", 2)])
-def test_distributed_hierarchy_gloo(mode, smoother, world, monkeypatch):
+@pytest.mark.parametrize("mode,smoother,world,slab", [("rows", "jacobi", 3, False), ("rows", "chebyshev", 4, False), ("rows", "jacobi", 4, True),
+                                                      ("gathered", "jacobi", 2, False)])
+def test_distributed_hierarchy_gloo(mode, smoother, world, slab, monkeypatch):
     """The hierarchy built over several ranks -- every rank building only its rows of every level (the default), or the
     older gather-then-slice form -- is the one-rank hierarchy bit for bit: every level's A, P and R layout equals the
     oracle's layout of the one-rank operator under that level's partition."""
@@ -149,7 +155,7 @@ def test_distributed_hierarchy_gloo(mode, smoother, world, monkeypatch):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 24, ret, smoother)) for r in range(world)]
+        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 30 if slab else 24, ret, smoother, slab)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
