@@ -117,7 +117,7 @@ def vcycle_leg(capi, host, A, m, dist=None):
     lib = capi.lib()
     PD = C.POINTER(C.c_double)
     best = None
-    for _ in range(3):                                   # first pass warms up; keep the best of the rest
+    for _ in range(3 if dist is None else 2):            # first pass warms up; keep the best of the rest
         barrier()
         t0 = time.perf_counter()
         st = lib.sgpu_solve_pCG(h, du.ptr, dr.ptr, C.byref(it), hist.ctypes.data_as(PD), 64)
@@ -130,7 +130,7 @@ def vcycle_leg(capi, host, A, m, dist=None):
     for _ in range(3):
         capi.check(lib.sgpu_vcycle(h, du.ptr, dr.ptr))
     barrier()
-    n = 20
+    n = 20 if dist is None else 10
     t0 = time.perf_counter()
     for _ in range(n):
         capi.check(lib.sgpu_vcycle(h, du.ptr, dr.ptr))
