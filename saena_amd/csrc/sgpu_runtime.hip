@@ -1376,7 +1376,7 @@ int sgpu_solve(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t 
     const double THRSHLD = init_dot * h->prm.solver_tol * h->prm.solver_tol;
     int i = 0;
     for (; i < h->prm.solver_max_iter; ++i) {                         // :1957-1970
-        CHK(vcycle0(h, u, rhs));
+        CHK(vcycle0(h, u, rhs, i == 0));                              // the first V-cycle starts from the zero iterate set above
         CHK(sgpu_residual(A, u, rhs, h->r));
         CHK(sgpu_dot(h->r, h->r, sz, &current_dot));
         if (hist && i + 1 < cap) hist[i + 1] = std::sqrt(current_dot);
