@@ -32,6 +32,8 @@ int main(int argc, char **argv) {
 
     saena::amg solver;
     solver.set_verbose(true);
+    solver.set_scale(false);                              // the reference driver's knobs are accepted (experiments/Poisson.cpp)
+    solver.set_num_threads(1);
     auto t0 = std::chrono::steady_clock::now();
     solver.set_matrix(&A, &opts);
     solver.set_rhs(rhs);

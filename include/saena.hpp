@@ -69,6 +69,13 @@ public:
     int assemble(bool scale = false, bool use_dense = false);
     int assemble_band_matrix(bool use_dense = false);
     int writeMatrixToFile(const std::string &name = "") const;   // "<name>-r<rank>.mtx", MatrixMarket coordinate real general
+    // Knobs of the reference's CPU implementation that have no counterpart on this path; accepted so that drivers
+    // written against the reference compile and run unchanged (reference saena.cpp:115-140,205-214):
+    void set_p_order(int) {}                        // p-multigrid order of the Nektar++ coupling (out of scope)
+    void set_prodim(int) {}
+    void set_num_threads(const int &) {}            // OpenMP threads of the CPU kernels
+    int  set_shrink(bool) { return 0; }             // coarse levels are placed by amg_hierarchy::shrink_rows here
+    int  print(int ran, std::string name = "");     // this rank's entries (ran < 0: every rank), like print_entry
 
     saena_host::saena_matrix *get_internal_matrix();
     comm    get_comm();
@@ -204,6 +211,15 @@ public:
     int  switch_to_dense(bool val);                 // dense row-major storage for the coarse levels past the density threshold
     int  set_dense_threshold(float thre);
     double get_dense_threshold();
+    // accepted for source compatibility, no effect on this path (reference saena.cpp:696-727,901-911)
+    void set_num_threads(const int &) {}
+    int  set_shrink_levels(std::vector<bool>) { return 0; }
+    int  set_shrink_values(std::vector<int>) { return 0; }
+    int  switch_repart(bool) { return 0; }
+    int  set_repart_thre(float) { return 0; }
+    int  set_scale(bool sc);                        // symmetric diagonal scaling is not implemented: true is refused
+    int  set_sample_sz_percent(double) { return 0; }
+    int  matrix_diff(saena::matrix &A, saena::matrix &B);   // prints entry-wise differences of two assembled matrices
     int  set_verbose(bool verb);
     bool verbose = false;
     int  set_multigrid_max_level(int max);

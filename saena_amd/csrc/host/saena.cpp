@@ -89,6 +89,12 @@ int matrix::assemble(bool scale, bool use_dense) {
     return m_pImpl->assemble();
 }
 int matrix::assemble_band_matrix(bool use_dense) { return assemble(false, use_dense); }
+int matrix::print(int ran, std::string name) {          // saena_matrix::print_entry
+    if (ran >= 0 && ran != c_.rank()) return 0;
+    printf("\nmatrix %s on rank %d: %ld entries\n", name.c_str(), c_.rank(), (long)m_pImpl->entry.size());
+    for (const auto &e : m_pImpl->entry) printf("%d\t%d\t%.12g\n", e.row, e.col, e.val);
+    return 0;
+}
 int matrix::writeMatrixToFile(const std::string &name) const { return m_pImpl->writeMatrixToFile(name.empty() ? "mat" : name); }
 saena_host::saena_matrix *matrix::get_internal_matrix() { return m_pImpl; }
 comm matrix::get_comm() { return c_; }
@@ -305,6 +311,20 @@ int amg::run(value_t *&u, saena::options *opts, int which, bool print_info) {
 int amg::solve(value_t *&u, saena::options *opts) { return run(u, opts, 0, true); }
 int amg::solve_pCG(value_t *&u, saena::options *opts, bool print_info) { return run(u, opts, 1, print_info); }
 int amg::solve_CG(value_t *&u, saena::options *opts) { return run(u, opts, 2, true); }
+int amg::set_scale(bool sc) {
+    if (sc) throw std::runtime_error("saena::amg::set_scale(true): symmetric scaling is not on the GPU path (false in the reference's drivers)");
+    return 0;
+}
+// saena::amg::matrix_diff (saena.cpp:913-948)
+int amg::matrix_diff(saena::matrix &A1, saena::matrix &B1) {
+    const auto &ea = A1.get_internal_matrix()->entry, &eb = B1.get_internal_matrix()->entry;
+    if (A1.get_nnz() != B1.get_nnz() && A1.get_comm().rank() == 0) printf("error: matrix_diff(): A.nnz_g != B.nnz_g\n");
+    printf("\nmatrix_diff: \n");
+    for (size_t i = 0; i < std::min(ea.size(), eb.size()); ++i)
+        printf("%d\t%d\t%.12g\t%d\t%d\t%.12g\t%.12g\n", ea[i].row, ea[i].col, ea[i].val, eb[i].row, eb[i].col, eb[i].val, ea[i].val - eb[i].val);
+    printf("A->entry.size() = %lu, B->entry.size() = %lu \n", (unsigned long)ea.size(), (unsigned long)eb.size());
+    return 0;
+}
 int amg::switch_to_dense(bool val) { switch_to_dense_ = val; return 0; }                 // saena.cpp:729-743
 int amg::set_dense_threshold(float thre) { dense_thre_override_ = thre; return 0; }
 double amg::get_dense_threshold() { return dense_thre_override_ > 0 ? dense_thre_override_ : 0.1; }
