@@ -156,6 +156,15 @@ def pmc_traffic(m, world, kernel_name):
     return None, None
 
 
+def _init_context(capi, world, rank, device, uid):
+    if world > 1 and os.environ.get("SAENA_BENCH_NO_RCCL"):
+        # rehearsal of the N > 1 control flow on ONE card (RCCL refuses several ranks per device): every rank gets a
+        # 1-rank GPU context without a communicator, so halos are simply not exchanged -- the numbers mean nothing
+        capi.init(device=device, rank=0, nranks=1, unique_id=None)
+    else:
+        capi.init(device=device, rank=rank, nranks=world, unique_id=uid)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -187,12 +196,18 @@ def main():
         uid = capi.get_unique_id()
     # SAENA_BENCH_DEVICE: rehearsal aid (several ranks on one card, if the RCCL build allows it)
     device = int(os.environ.get("SAENA_BENCH_DEVICE", local_rank))
-    if world > 1 and os.environ.get("SAENA_BENCH_NO_RCCL"):
-        # rehearsal of the N > 1 control flow on ONE card (RCCL refuses several ranks per device): every rank gets a
-        # 1-rank GPU context without a communicator, so halos are simply not exchanged -- the numbers mean nothing
-        capi.init(device=device, rank=0, nranks=1, unique_id=None)
-    else:
-        capi.init(device=device, rank=rank, nranks=world, unique_id=uid)
+    # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the ONE JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        _init_context(capi, world, rank, device, uid)
+    finally:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)                   # the banner sits in C stdio's buffer when stdout is a pipe or a file
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     # ---- operator through the host mirror of saena::matrix (product path, no oracle) ----
     m = args.m
