@@ -156,6 +156,25 @@ def pmc_traffic(m, world, kernel_name):
     return None, None
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """Libraries (gloo, RCCL) print banners on stdout while they connect: stdout is reserved for the ONE JSON line."""
+    import ctypes
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        ctypes.CDLL(None).fflush(None)                   # C stdio buffers when stdout is a pipe or a file
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def _init_context(capi, world, rank, device, uid):
     if world > 1 and os.environ.get("SAENA_BENCH_NO_RCCL"):
         # rehearsal of the N > 1 control flow on ONE card (RCCL refuses several ranks per device): every rank gets a
@@ -180,7 +199,8 @@ def main():
         if world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo", rank=rank, world_size=world)   # CPU rendezvous only; data rides RCCL
+            with stdout_to_stderr():
+                dist.init_process_group("gloo", rank=rank, world_size=world)   # CPU rendezvous only; data rides RCCL
 
     import numpy as np
     from saena_amd import capi, host
@@ -196,18 +216,8 @@ def main():
         uid = capi.get_unique_id()
     # SAENA_BENCH_DEVICE: rehearsal aid (several ranks on one card, if the RCCL build allows it)
     device = int(os.environ.get("SAENA_BENCH_DEVICE", local_rank))
-    # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the ONE JSON line
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
-    try:
+    with stdout_to_stderr():
         _init_context(capi, world, rank, device, uid)
-    finally:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)                   # the banner sits in C stdio's buffer when stdout is a pipe or a file
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
 
     # ---- operator through the host mirror of saena::matrix (product path, no oracle) ----
     m = args.m
@@ -355,9 +365,10 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
 
-    capi.finalize()
-    if dist is not None:
-        dist.destroy_process_group()
+    with stdout_to_stderr():
+        capi.finalize()
+        if dist is not None:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
