@@ -213,6 +213,17 @@ int sgpu_solve_CG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value
 /* solve_coarsest_CG on the last level only (for tests) */
 int sgpu_coarsest_solve(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters);
 
+/* Host-routed transport (validation without one GPU per rank -- RCCL refuses several ranks on one device): the
+ * context of rank `rank` of `nranks` is created WITHOUT an RCCL communicator; every halo exchange is staged through
+ * host memory and handed to `exchange`, every scalar reduction to `allreduce_sum`.  All library code above the
+ * transport (plans, interior/boundary kernels, V-cycle, solve*, coarsest level on one rank ...) is the multi-rank
+ * code.  exchange: send/recv are packed host buffers of `elem_bytes`-sized elements, peers in ascending rank order. */
+typedef int (*sgpu_host_exchange_fn)(void *user, const void *send, const int *send_rank, const int *send_count, int nsend,
+                                     void *recv, const int *recv_rank, const int *recv_count, int nrecv, int elem_bytes);
+typedef int (*sgpu_host_allreduce_fn)(void *user, double *v, int n);
+int sgpu_debug_init_host_transport(int device_id, int rank, int nranks, sgpu_host_exchange_fn exchange,
+                                   sgpu_host_allreduce_fn allreduce_sum, void *user);
+
 /* bench.py only: from now on a fatal signal in this process (SIGSEGV/SIGBUS/SIGABRT/SIGFPE/SIGILL/SIGTERM -- the HIP
  * runtime aborts on a GPU fault, torchrun sends SIGTERM when a sibling rank dies) writes `line` (may be empty) to
  * stdout and ends the process with status 0, so that an optional leg running after the measurement cannot lose the

@@ -91,6 +91,7 @@ SYMBOLS = {
     "sgpu_amg_profile_matvecs": (C.c_int, [_VP, C.c_int, _PD]),
     "sgpu_coarsest_solve": (C.c_int, [_VP, _VP, _VP, _PI]),
     "sgpu_debug_on_fatal_print": (C.c_int, [C.c_char_p]),
+    "sgpu_debug_init_host_transport": (C.c_int, [C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
     "sgpu_time_kernel": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.POINTER(C.c_float)]),
     "sgpu_algorithmic_bytes": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64)]),
 }
@@ -120,6 +121,65 @@ def check(status):
 
 
 _initialised = False
+
+
+_transport_keep = None
+
+
+def init_host_transport(device, dist):
+    """sgpu_debug_init_host_transport over a torch.distributed group that moves CPU tensors (gloo): this process is
+    rank dist.get_rank() of dist.get_world_size(); halos and scalar reductions are routed through the host.  For
+    validating the multi-rank code with several processes on ONE card (RCCL needs one device per rank)."""
+    global _initialised, _transport_keep
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    XF = C.CFUNCTYPE(C.c_int, _VP, _VP, _PI, _PI, C.c_int, _VP, _PI, _PI, C.c_int, C.c_int)
+    AF = C.CFUNCTYPE(C.c_int, _VP, _PD, C.c_int)
+
+    def view(ptr, nbytes):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,)) if nbytes else np.zeros(0, np.uint8)
+
+    def exchange(user, send, srank, scount, nsend, recv, rrank, rcount, nrecv, eb):
+        try:
+            reqs, outs, keep = [], [], []
+            so = 0
+            for i in range(nsend):
+                n = scount[i] * eb
+                t = torch.from_numpy(view(send + so if send else None, n).copy())
+                keep.append(t)
+                reqs.append(dist.isend(t, srank[i]))
+                so += n
+            ro = 0
+            for i in range(nrecv):
+                n = rcount[i] * eb
+                t = torch.empty(n, dtype=torch.uint8)
+                outs.append((ro, n, t))
+                reqs.append(dist.irecv(t, rrank[i]))
+                ro += n
+            for rq in reqs:
+                rq.wait()
+            for ro, n, t in outs:
+                if n:
+                    view(recv + ro, n)[:] = t.numpy()
+            return 0
+        except Exception as e:      # pragma: no cover
+            print("host transport exchange failed:", e)
+            return 1
+
+    def allreduce(user, v, n):
+        try:
+            a = np.ctypeslib.as_array(v, shape=(n,))
+            t = torch.from_numpy(a.copy())
+            dist.all_reduce(t)
+            a[:] = t.numpy()
+            return 0
+        except Exception as e:      # pragma: no cover
+            print("host transport allreduce failed:", e)
+            return 1
+    xf, af = XF(exchange), AF(allreduce)
+    _transport_keep = (xf, af)
+    check(lib().sgpu_debug_init_host_transport(int(device), rank, world, C.cast(xf, _VP), C.cast(af, _VP), None))
+    _initialised = True
 
 
 def init(device=0, rank=0, nranks=1, unique_id=None):

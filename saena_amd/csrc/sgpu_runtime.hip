@@ -72,10 +72,21 @@ struct Ctx {
     bool        value_ops = false;
     bool        inkernel_sync = false;   // fork/join folded into the interior / pack / boundary kernels (no extra launches)
     uint64_t   *kflag_x = nullptr, *kflag_h = nullptr;   // their flags: device memory, one cache line each
+    // host-routed transport (sgpu_debug_init_host_transport): no RCCL communicator, halos and reductions via callbacks
+    sgpu_host_exchange_fn  xchg = nullptr;
+    sgpu_host_allreduce_fn ared = nullptr;
+    void                  *xuser = nullptr;
+    bool multi() const { return comm != nullptr || xchg != nullptr; }
 };
 Ctx g;
 
 int need_ctx() { return g.live ? SGPU_OK : fail(SGPU_ERR_STATE, "sgpu_init has not been called"); }
+
+// scalar sum over the ranks of a host-routed context
+int host_allreduce(double *v, int n) {
+    if (g.ared(g.xuser, v, n) != 0) return fail(SGPU_ERR_RCCL, "host transport: allreduce callback failed");
+    return SGPU_OK;
+}
 
 struct DevBuf {
     double *p = nullptr;
@@ -388,6 +399,29 @@ int launch_boundary(sgpu_op *op, int epi, const double *x, double *y, const EpiA
     return SGPU_OK;
 }
 
+// Host-routed exchange: pack -> host -> callback -> device, then the same interior / boundary kernels, all on cs.
+int apply_host_transport(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
+    const bool f32 = op->halo_fp32 != 0;
+    const size_t eb = f32 ? sizeof(float) : sizeof(double);
+    std::vector<char> hs((size_t)op->vIndexSize * eb), hr((size_t)op->recvSize * eb);
+    if (op->vIndexSize) {
+        const dim3 grid(std::min(sk::PACK_MAX_BLOCKS, (op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK));
+        if (f32) hipLaunchKernelGGL(sk::k_pack_f32, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_f, op->vIndexSize, (const uint64_t *)nullptr, (uint64_t)0);
+        else hipLaunchKernelGGL(sk::k_pack, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_buf, op->vIndexSize, 0, (const uint64_t *)nullptr, (uint64_t)0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hs.data(), f32 ? (const void *)op->send_f : (const void *)op->send_buf, hs.size(), hipMemcpyDeviceToHost, g.cs));
+    }
+    HIPCHK(hipStreamSynchronize(g.cs));
+    if (g.xchg(g.xuser, hs.data(), op->sendRank.data(), op->sendCount.data(), (int)op->sendRank.size(),
+               hr.data(), op->recvRank.data(), op->recvCount.data(), (int)op->recvRank.size(), (int)eb) != 0)
+        return fail(SGPU_ERR_RCCL, "host transport: exchange callback failed");
+    if (op->recvSize) HIPCHK(hipMemcpyAsync(f32 ? (void *)op->recv_f : (void *)op->recv_buf, hr.data(), hr.size(), hipMemcpyHostToDevice, g.cs));
+    CHK(launch_part(op->loc, epi, x, y, e, op->has_remote ? op->skip : nullptr));
+    if (op->has_remote) CHK(launch_boundary(op, epi, x, y, e, f32, g.cs));
+    HIPCHK(hipStreamSynchronize(g.cs));                  // the staging vectors die with this frame
+    return SGPU_OK;
+}
+
 // y = epi(A x).  With a communicator the two streams split the ROWS, not the phases:
 //   cs (compute): interior rows -- every row without remote entries -- straight away;
 //   hs (halo):    wait for the inputs (ev_x) -> pack -> ncclSend/ncclRecv group -> boundary rows whole;
@@ -396,6 +430,7 @@ int launch_boundary(sgpu_op *op, int epi, const double *x, double *y, const EpiA
 // profiles/r01_halo_loopback_trace.md) and the interior launch never waits for it: this is where the
 // reference overlaps MPI_Isend/Irecv with its local loop (src/saena_matrix_matvec.cpp:32-80).
 int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
+    if (g.xchg && !op->injected && (op->vIndexSize || op->recvSize)) return apply_host_transport(op, epi, x, y, e);
     const bool exchanged = g.comm && !op->injected && (op->vIndexSize || op->recvSize);
     if (!exchanged) {
         if (op->has_remote && op->injected) {           // halo supplied by the caller (tests): same kernels, one stream
@@ -555,6 +590,14 @@ int dot_local_async(const double *x, const double *y, size_t n, double *dout) {
 int dot_dev(const double *x, const double *y, size_t n, int slot) {
     CHK(dot_local_async(x, y, n, g.dscalar + slot));
     if (g.comm) NCCLCHK(ncclAllReduce(g.dscalar + slot, g.dscalar + slot, 1, ncclDouble, ncclSum, g.comm, g.cs));
+    if (g.xchg) {                                        // host-routed: down, sum over ranks, back up (later kernels read S[slot])
+        double v = 0;
+        HIPCHK(hipMemcpyAsync(&v, g.dscalar + slot, sizeof v, hipMemcpyDeviceToHost, g.cs));
+        HIPCHK(hipStreamSynchronize(g.cs));
+        CHK(host_allreduce(&v, 1));
+        HIPCHK(hipMemcpyAsync(g.dscalar + slot, &v, sizeof v, hipMemcpyHostToDevice, g.cs));
+        HIPCHK(hipStreamSynchronize(g.cs));
+    }
     return SGPU_OK;
 }
 int dot_nblocks(size_t n) { return (int)std::min<size_t>(g.n_partials, std::max<size_t>(1, (n + sk::BLOCK - 1) / sk::BLOCK)); }
@@ -567,6 +610,11 @@ int pcg_update_dev(int ia, int ib, const double *p, const double *h, double *u, 
     if (g.comm) NCCLCHK(ncclAllReduce(g.dscalar + iout, g.dscalar + iout, 1, ncclDouble, ncclSum, g.comm, g.cs));
     HIPCHK(hipMemcpyAsync(g.hscalar + iout, g.dscalar + iout, sizeof(double), hipMemcpyDeviceToHost, g.cs));
     HIPCHK(hipStreamSynchronize(g.cs));
+    if (g.xchg) {
+        CHK(host_allreduce(g.hscalar + iout, 1));
+        HIPCHK(hipMemcpyAsync(g.dscalar + iout, g.hscalar + iout, sizeof(double), hipMemcpyHostToDevice, g.cs));
+        HIPCHK(hipStreamSynchronize(g.cs));
+    }
     *host_out = g.hscalar[iout];
     return SGPU_OK;
 }
@@ -644,6 +692,16 @@ int sgpu_init(int device_id, int rank, int nranks, const void *uid) {
     return SGPU_OK;
 }
 
+int sgpu_debug_init_host_transport(int device_id, int rank, int nranks, sgpu_host_exchange_fn exchange,
+                                   sgpu_host_allreduce_fn allreduce_sum, void *user) {
+    if (!exchange || !allreduce_sum) return fail(SGPU_ERR_ARG, "null transport callback");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SGPU_ERR_ARG, "bad rank %d of %d", rank, nranks);
+    CHK(sgpu_init(device_id, 0, 1, nullptr));
+    g.rank = rank; g.nranks = nranks;
+    g.xchg = exchange; g.ared = allreduce_sum; g.xuser = user;
+    return SGPU_OK;
+}
+
 int sgpu_finalize(void) {
     if (!g.live) return SGPU_OK;
     hipDeviceSynchronize();
@@ -669,6 +727,7 @@ int sgpu_device_sync(void) {
 
 int sgpu_barrier(void) {
     CHK(sgpu_device_sync());
+    if (g.xchg) { double z = 0; CHK(host_allreduce(&z, 1)); }
     if (g.comm) {
         HIPCHK(hipMemsetAsync(g.dint, 0, sizeof(int), g.cs));
         NCCLCHK(ncclAllReduce(g.dint, g.dint, 1, ncclInt, ncclSum, g.comm, g.cs));
@@ -724,6 +783,7 @@ int sgpu_dot(const value_t *x, const value_t *y, size_t n, value_t *out) {
     if (g.comm) NCCLCHK(ncclAllReduce(g.dscalar, g.dscalar, 1, ncclDouble, ncclSum, g.comm, g.cs));
     HIPCHK(hipMemcpyAsync(g.hscalar, g.dscalar, sizeof(double), hipMemcpyDeviceToHost, g.cs));
     HIPCHK(hipStreamSynchronize(g.cs));
+    if (g.xchg) CHK(host_allreduce(g.hscalar, 1));
     *out = g.hscalar[0];
     return SGPU_OK;
 }
@@ -816,7 +876,7 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
     if (d->vIndexSize && !d->vIndex) return fail(SGPU_ERR_ARG, "vIndex is null");
     if (sd != d->vIndexSize) return fail(SGPU_ERR_ARG, "sum(sendProcCount)=%d != vIndexSize=%d", sd, d->vIndexSize);
     if (rd != d->col_remote_size) return fail(SGPU_ERR_ARG, "sum(recvProcCount)=%d != col_remote_size=%d", rd, d->col_remote_size);
-    if (g.comm) {   // (a context without a communicator may hold plans of a larger world for the single-GPU halo tests)
+    if (g.multi()) {   // (a context without a communicator may hold plans of a larger world for the single-GPU halo tests)
         const bool loopback = g.nranks == 1;        // one rank with a communicator: self send/recv, for RCCL path tests
         for (int r : op->sendRank) if (r < 0 || r >= g.nranks || (r == g.rank && !loopback)) return fail(SGPU_ERR_ARG, "bad send rank %d", r);
         for (int r : op->recvRank) if (r < 0 || r >= g.nranks || (r == g.rank && !loopback)) return fail(SGPU_ERR_ARG, "bad recv rank %d", r);
@@ -831,7 +891,7 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->recv_buf), (size_t)op->recvSize * sizeof(double)));
         HIPCHK(hipMemsetAsync(op->recv_buf, 0, (size_t)op->recvSize * sizeof(double), g.cs));
     }
-    if (op->halo_fp32 && g.comm) {
+    if (op->halo_fp32 && g.multi()) {
         if (op->vIndexSize) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->send_f), (size_t)op->vIndexSize * sizeof(float)));
         if (op->recvSize) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->recv_f), (size_t)op->recvSize * sizeof(float)));
     }
@@ -1199,7 +1259,7 @@ int vcycle0_eager(sgpu_amg *h, double *u, const double *rhs, bool u_zero) {
 
 // u_zero: the caller guarantees a zero iterate WITHOUT having written it (see vcycle_level)
 int vcycle0(sgpu_amg *h, double *u, const double *rhs, bool u_zero = false) {
-    if (!h->prm.use_graph || g.comm) return vcycle0_eager(h, u, rhs, u_zero);
+    if (!h->prm.use_graph || g.multi()) return vcycle0_eager(h, u, rhs, u_zero);
     for (auto &c : h->graphs)
         if (c.u == u && c.rhs == rhs && c.u_zero == u_zero) { HIPCHK(hipGraphLaunch(c.exec, g.cs)); return SGPU_OK; }
     sgpu_amg::Captured c{u, rhs, u_zero, nullptr, nullptr};
@@ -1261,7 +1321,13 @@ int sgpu_amg_create(int nlevels, sgpu_op *const *A, sgpu_op *const *P, sgpu_op *
     }
     // direct coarsest solve: one rank, or a coarsest level that lives whole on one rank (no halo on any rank:
     // the setup shrinks small levels onto rank 0, ranks holding zero rows have nothing to solve)
-    bool coarse_local = !g.comm;
+    bool coarse_local = !g.multi();
+    if (g.xchg) {
+        sgpu_op *Ac = A[nlevels - 1];
+        double has_halo = (Ac->vIndexSize || Ac->recvSize) ? 1.0 : 0.0;
+        CHK(host_allreduce(&has_halo, 1));
+        coarse_local = has_halo == 0.0;
+    }
     if (g.comm) {
         sgpu_op *Ac = A[nlevels - 1];
         int has_halo = (Ac->vIndexSize || Ac->recvSize) ? 1 : 0;
