@@ -175,11 +175,12 @@ def stdout_to_stderr():
         os.close(saved)
 
 
-def _init_context(capi, world, rank, device, uid):
+def _init_context(capi, world, rank, device, uid, dist):
     if world > 1 and os.environ.get("SAENA_BENCH_NO_RCCL"):
-        # rehearsal of the N > 1 control flow on ONE card (RCCL refuses several ranks per device): every rank gets a
-        # 1-rank GPU context without a communicator, so halos are simply not exchanged -- the numbers mean nothing
-        capi.init(device=device, rank=0, nranks=1, unique_id=None)
+        # rehearsal of the N > 1 run on ONE card (RCCL refuses several ranks per device): the multi-rank code runs
+        # with halos and reductions routed through the host and gloo (sgpu_debug_init_host_transport) -- residuals
+        # are the real ones, timings mean nothing
+        capi.init_host_transport(device, dist)
     else:
         capi.init(device=device, rank=rank, nranks=world, unique_id=uid)
 
@@ -217,7 +218,7 @@ def main():
     # SAENA_BENCH_DEVICE: rehearsal aid (several ranks on one card, if the RCCL build allows it)
     device = int(os.environ.get("SAENA_BENCH_DEVICE", local_rank))
     with stdout_to_stderr():
-        _init_context(capi, world, rank, device, uid)
+        _init_context(capi, world, rank, device, uid, dist)
 
     # ---- operator through the host mirror of saena::matrix (product path, no oracle) ----
     m = args.m
