@@ -77,6 +77,7 @@ struct Ctx {
     sgpu_host_allreduce_fn ared = nullptr;
     void                  *xuser = nullptr;
     bool multi() const { return comm != nullptr || xchg != nullptr; }
+    std::vector<char> peer_seen;   // RCCL connects a peer lazily at the first send/recv with it: see apply()
 };
 Ctx g;
 
@@ -451,8 +452,14 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     // Invariant of all three: whatever polls or waits was enqueued AFTER the thing it waits for -- nothing on the GPU
     // ever depends on a launch the host has yet to make.  (So a device-wide synchronisation inside an RCCL host call,
     // e.g. while it connects a new peer, always completes; and an error return leaves no stream waiting.)
-    const bool K = g.inkernel_sync && op->loc.nblk > 0;
-    const bool V = g.value_ops;
+    // The first exchange with a peer makes RCCL set up the connection inside ncclGroupEnd (allocations, IPC handles,
+    // possibly device-wide synchronisation): that one runs in the plainest mode, events, with no polling kernel around.
+    bool fresh_peer = false;
+    if (g.peer_seen.size() != (size_t)g.nranks) g.peer_seen.assign((size_t)g.nranks, 0);
+    for (int r : op->sendRank) if (!g.peer_seen[(size_t)r]) { fresh_peer = true; g.peer_seen[(size_t)r] = 1; }
+    for (int r : op->recvRank) if (!g.peer_seen[(size_t)r]) { fresh_peer = true; g.peer_seen[(size_t)r] = 1; }
+    const bool K = g.inkernel_sync && op->loc.nblk > 0 && !fresh_peer;
+    const bool V = g.value_ops && !fresh_peer;
     if (K) {
         CHK(launch_part(op->loc, epi, x, y, e, skip, n));
     } else {
