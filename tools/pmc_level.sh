@@ -11,12 +11,12 @@ for C in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_s
     i=$((i+1))
     timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $D/pass$i -- python3 -m tests.perf_one 128 $LV 0 $KIND 40 $V $G > $D/pass$i.log 2>&1
 done
-tail -1 $D/pass1.log
+grep "which=" $D/pass1.log | tail -1
 python3 - "$D" "$OUT" <<'PY'
 import csv, glob, json, sys
 from collections import defaultdict
 d, out = sys.argv[1], sys.argv[2]
-line = open(d + "/pass1.log").read().strip().splitlines()[-1]
+line = [ln for ln in open(d + "/pass1.log").read().splitlines() if "which=" in ln][-1]
 vals, names = defaultdict(list), defaultdict(int)
 rows = []
 for f in sorted(glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True)):
