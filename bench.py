@@ -193,6 +193,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if world > 1:      # the ranks share this host's cores: split them for the threaded host setup
+        os.environ.setdefault("SAENA_SETUP_THREADS", str(max(2, min(16, (os.cpu_count() or 16) // world))))
     dist = None
     if world > 1 or os.environ.get("SAENA_BENCH_IMPORT_TORCH"):
         # torch first: its bundled HIP/RCCL runtime must be the one both sides use
