@@ -1,0 +1,29 @@
+"""The bench line's contract (driver + judge read these keys), checked on the committed line of this round."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    line = open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "GB/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["us_per_launch"] * 1e-6) / 1e9) < 1.0
+    assert r["traffic"] is None or 0.5 * r["algorithmic_bytes"] < r["traffic"] < 2 * r["algorithmic_bytes"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+    assert abs(d["value"] - r["algorithmic_bytes"] / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
+    v = d["vcycle"]
+    assert v["pcg_iterations"] == 9 and f"{v['final_residual']:.6e}" == "5.355578e-05" and f"{v['initial_residual']:.6e}" == "5.992963e+04"
