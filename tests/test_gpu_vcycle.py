@@ -414,7 +414,7 @@ def test_distributed_hierarchy_reaches_the_device():
         assert res.get(r) == "ok", f"rank {r}: {res.get(r)}"
 
 
-def _transport_worker(rank, world, port, smoother, ret):
+def _transport_worker(rank, world, port, smoother, ret, float_level=3):
     import os
     import sys
     import torch.distributed as dist                      # torch first (its HIP runtime), like bench.py --gpus N
@@ -427,7 +427,7 @@ def _transport_worker(rank, world, port, smoother, ret):
         L = host.load("gpu")
         comm = host.Comm("gpu", "dist", dist)
         A = host.Matrix(comm).laplacian3D(32).assemble()   # the reference's nnz-balanced partition
-        S = host.AmgSolver(A, host.options(L, **dict(host.OPTIONS001, smoother=smoother))).to_device()
+        S = host.AmgSolver(A, host.options(L, **dict(host.OPTIONS001, smoother=smoother, float_level=float_level))).to_device()
         u, it, hist, ok = S.solve_pCG(A.laplacian3D_rhs())
         u2, it2, hist2, ok2 = S.solve(A.laplacian3D_rhs())
         ret[rank] = ("ok", it, [float(h) for h in hist], bool(ok), it2, float(hist2[-1]), bool(ok2),
@@ -439,8 +439,9 @@ def _transport_worker(rank, world, port, smoother, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,smoother", [(3, "jacobi"), (4, "chebyshev")])
-def test_multirank_solve_through_the_library(capi, world, smoother):
+@pytest.mark.parametrize("world,smoother,float_level", [(3, "jacobi", 3), (4, "chebyshev", 3), (3, "jacobi", 0)],
+                         ids=["3-jacobi", "4-chebyshev", "3-jacobi-fp32-halos"])
+def test_multirank_solve_through_the_library(capi, world, smoother, float_level):
     """The LIBRARY's multi-rank solve (sgpu_solve_pCG / sgpu_solve over the row-distributed hierarchy: interior and
     boundary kernels, shrunk coarse levels, dense coarsest solve on rank 0, global dots) with several processes on
     this one card, halos and reductions routed through gloo (sgpu_debug_init_host_transport) because RCCL needs one
@@ -456,7 +457,7 @@ def test_multirank_solve_through_the_library(capi, world, smoother):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=_transport_worker, args=(r, world, port, smoother, ret)) for r in range(world)]
+        procs = [ctx.Process(target=_transport_worker, args=(r, world, port, smoother, ret, float_level)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -472,6 +473,11 @@ def test_multirank_solve_through_the_library(capi, world, smoother):
     assert rows == [27000, 13500, 1420, 253, 69]
     assert ok and it == 7
     assert f"{hist[0]:.6e}" == "7.227341e+03"
+    if float_level == 0:
+        # every level's halo crosses the wire in fp32 (matvec_sparse_float): the iteration still converges, a little
+        # differently -- the halo values carry 2^-24 relative rounding
+        assert ok2 and abs(hist[-1] - 2.246251e-05) <= 0.5 * 2.246251e-05, hist
+        return
     if smoother == "jacobi":
         assert abs(hist[-1] - 2.246251e-05) <= 2e-6 * 2.246251e-05, hist[-1]           # the printed 7 digits
     from saena_amd import host
