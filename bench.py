@@ -144,6 +144,31 @@ def vcycle_leg(capi, host, A, m, dist=None):
             "options": "data/options001.xml values: jacobi 3+3, tol 1e-8, conn_str 0.2", "host_setup_s": round(t_setup, 2)}
 
 
+def verify_spmv(np, host, A, op, x, y, g0):
+    """One more SpMV, checked against the same product formed on the host from this rank's layout arrays with the
+    closed-form input x(g) = sin(0.001 g) -- halo values included, so with more than one rank this checks what the
+    RCCL exchange delivered.  -> (max |y_gpu - y_host| / max sum_j |a_ij x_j|, rows checked)"""
+    op.spmv(x, y)
+    got = y.download()
+    d = host.desc_arrays(A.desc())
+    M = d["M"]
+    f = lambda g: np.sin(0.001 * g)                                          # noqa: E731
+    rows = np.repeat(np.arange(M), d["nnzPerRow_local"])
+    want = np.zeros(M)
+    bound = np.zeros(M)
+    t = d["val_local"] * f(d["col_local"].astype(np.float64))              # col_local holds GLOBAL ids
+    np.add.at(want, rows, t)
+    np.add.at(bound, rows, np.abs(t))
+    hc = A.halo_columns()
+    if len(hc):
+        slot = np.repeat(np.arange(len(hc)), d["nnzPerCol_remote"])
+        t = d["val_remote"] * f(hc[slot].astype(np.float64))
+        np.add.at(want, d["row_remote"], t)
+        np.add.at(bound, d["row_remote"], np.abs(t))
+    err = float(np.max(np.abs(got - want)) / max(float(np.max(bound)), 1e-300)) if M else 0.0
+    return err, int(M)
+
+
 def pmc_traffic(m, world, kernel_name):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (PMC counters cannot be
     read from inside the process).  Only for the kernel those passes profiled; None for anything else."""
@@ -268,9 +293,13 @@ def main():
     sync_all()
     wall = time.perf_counter() - t0
 
+    err, _ = verify_spmv(np, host, A, op, x, y, g0)        # outside the timed region
     B_total = B_local
     if dist is not None:
         import torch
+        e = torch.tensor([err], dtype=torch.float64)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        err = float(e[0])
         t = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
@@ -301,6 +330,9 @@ def main():
                 "partition": "1 rank" if world == 1 else f"{world} even z-slabs, RCCL halo of {n * n} doubles per side",
                 "pct_of_hbm_peak": round(B_total / sec_per_step / 1e9 / (HBM_PEAK_GBS * world) * 100, 2),
             },
+            "check": {"what": "y = A x of one more SpMV against the host-formed product from the layout arrays, halo values included; "
+                              "max over all ranks of max_i |y_gpu - y_host| / max_i sum_j |a_ij x_j|",
+                      "max_rel_err": err, "ok": bool(err <= 1e-13)},
             "roofline": {
                 "bound": "hbm", "kernel": f"{kernel_name}, {info['lanes_per_row']} lane(s)/row",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -58,6 +58,8 @@ int   saena_matrix_get_split(saena_matrix_h *A, index_t *split_out /* nranks+1 *
 int   saena_matrix_get_desc(saena_matrix_h *A, sgpu_op_desc *out);
 /* remaining layout arrays not part of sgpu_op_desc, for layout tests: col_remote[nnz_l_remote], nnzPerProcScan[nranks+1] */
 int   saena_matrix_get_layout_extra(saena_matrix_h *A, const index_t **col_remote, const nnz_t **nnzPerProcScan);
+/* global column id of every slot of the receive (halo) buffer, [col_remote_size] -- vElement_remote (saena_matrix.h:57) */
+int   saena_matrix_get_halo_columns(saena_matrix_h *A, const index_t **vElement_remote);
 
 /* generators (reference src/aux_functions2.cpp:254-373, :629-700, :1296-1381) */
 int   saena_laplacian3D(saena_matrix_h *A, index_t mx, index_t my, index_t mz);

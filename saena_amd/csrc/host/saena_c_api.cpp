@@ -114,6 +114,10 @@ int saena_matrix_get_desc(saena_matrix_h *A, sgpu_op_desc *out) {
         fill_desc(A->A.L, &A->A.inv_diag, out);
     });
 }
+int saena_matrix_get_halo_columns(saena_matrix_h *A, const index_t **v) {
+    if (v) *v = A->A.L.vElement_remote.data();
+    return 0;
+}
 int saena_matrix_get_layout_extra(saena_matrix_h *A, const index_t **col_remote, const nnz_t **scan) {
     if (col_remote) *col_remote = A->A.L.col_remote.data();
     if (scan) *scan = A->A.L.nnzPerProcScan.data();

@@ -47,6 +47,7 @@ HOST_SYMBOLS = {
     "saena_matrix_get_split": (C.c_int, [_VP, _PI]),
     "saena_matrix_get_desc": (C.c_int, [_VP, C.POINTER(OpDesc)]),
     "saena_matrix_get_layout_extra": (C.c_int, [_VP, C.POINTER(_PI), C.POINTER(C.POINTER(C.c_long))]),
+    "saena_matrix_get_halo_columns": (C.c_int, [_VP, C.POINTER(_PI)]),
     "saena_laplacian3D": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
     "saena_laplacian3D_set_rhs": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _PD]),
     "saena_band_matrix": (C.c_int, [_VP, C.c_int, C.c_uint]),
@@ -311,6 +312,13 @@ class Matrix:
         out["col_remote"] = np.ctypeslib.as_array(cr, shape=(d.nnz_l_remote,)).copy() if d.nnz_l_remote else np.zeros(0, np.int32)
         out["nnzPerProcScan"] = np.ctypeslib.as_array(sc, shape=(self.comm.nranks + 1,)).copy()
         return out
+
+    def halo_columns(self):
+        """global column id of every slot of this rank's receive (halo) buffer"""
+        d = self.desc()
+        p = _PI()
+        self.L.saena_matrix_get_halo_columns(self.h, C.byref(p))
+        return np.ctypeslib.as_array(p, shape=(d.col_remote_size,)).copy() if d.col_remote_size else np.zeros(0, np.int32)
 
     def free(self):
         if self.h:
