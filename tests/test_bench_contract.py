@@ -25,5 +25,6 @@ def test_committed_bench_line_has_the_contract_keys():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
     assert abs(d["value"] - r["algorithmic_bytes"] / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
+    assert d["check"]["ok"] is True and d["check"]["max_rel_err"] <= 1e-13
     v = d["vcycle"]
     assert v["pcg_iterations"] == 9 and f"{v['final_residual']:.6e}" == "5.355578e-05" and f"{v['initial_residual']:.6e}" == "5.992963e+04"
