@@ -371,3 +371,88 @@ def test_dense_variant(capi, name):
     G.set_variant(0)                                   # and back
     G.spmv(dx, dy)
     assert np.all(np.abs(dy.download() - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
+
+
+def _golden_worker(rank, world, port, fn, ret):
+    import sys
+    import tempfile
+    import torch.distributed as dist                      # torch first, like bench.py --gpus N
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        from saena_amd import capi as c, host
+        from tests import inputs as inp, matrices as mats
+        c.init_host_transport(0, dist)
+        ref = dict(np.load(fn))
+        tag = os.path.basename(fn)[4:].split(".")[0]
+        comm = host.Comm("gpu", "dist", dist)
+        A = host.Matrix(comm)
+        with tempfile.TemporaryDirectory() as tmp:
+            if tag in mats.FILES:
+                A.read_file(mats.path(tag, tmp))
+            elif tag.startswith("poisson"):
+                A.laplacian3D(int(tag[7:]))
+            else:
+                m_, bw = tag[4:].split("_")
+                A.band_matrix(int(m_) // world, int(bw))   # the generator's M is the LOCAL size (aux_functions2.cpp:1296)
+            A.assemble()                                   # the reference's partitioner, over `world` ranks
+        np.testing.assert_array_equal(A.split, ref["split"])
+        lo, hi = int(A.split[rank]), int(A.split[rank + 1])
+        M, n = int(ref["meta"][0]), hi - lo
+        v, v2, rhs2 = inp.v_sin(M)[lo:hi], inp.v2(M)[lo:hi], inp.rhs2(M)[lo:hi]
+
+        def close(got, key, tol):
+            want = ref[key][lo:hi]
+            scale = np.linalg.norm(ref[key]) / np.sqrt(M) * np.sqrt(max(n, 1))
+            assert np.linalg.norm(got - want) <= tol * max(scale, 1e-300), (key, np.linalg.norm(got - want), scale)
+        G = host.device_operator(A)
+        dx, dy, dr = c.DeviceVector(n, v), c.DeviceVector(n), c.DeviceVector(n, rhs2)
+        G.spmv(dx, dy); close(dy.download(), "Av", 1e-13)
+        dx.upload(v2)
+        G.spmv(dx, dy); close(dy.download(), "Av2", 1e-13)
+        G.residual(dx, dr, dy); close(dy.download(), "residual_v2_rhs2", 1e-12)
+        du, ones = c.DeviceVector(n, np.zeros(n)), c.DeviceVector(n, np.ones(n))
+        G.jacobi(3, du, ones); close(du.download(), "jacobi3_rhs1", 1e-12)
+        du.upload(v2)
+        G.jacobi(2, du, dr); close(du.download(), "jacobi2_v2_rhs2", 1e-12)
+        du.upload(np.zeros(n))
+        G.chebyshev(3, 2.0, du, ones); close(du.download(), "cheby3_rhs1", 1e-12)
+        du.upload(v2)
+        G.chebyshev(4, 1.9371, du, dr); close(du.download(), "cheby4_v2_rhs2", 1e-12)
+        Gf = host.device_operator(A, halo_fp32=True)       # matvec_sparse_float: fp32 halo on the wire
+        Gf.spmv(dx, dy); close(dy.download(), "Av2_float", 1e-13)
+        ret[rank] = "ok"
+    except BaseException as e:      # noqa
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(e), e, e.__traceback__))[-2500:]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fixture", ["ref_SiH4.np4.npz", "ref_fxm3_6.np3.npz", "ref_poisson12.np4.npz", "ref_band300_7.np4.npz", "ref_plat362.np2.npz"])
+def test_multirank_library_against_compiled_reference_golden(fixture):
+    """The compiled reference's multi-rank outputs (mpirun -np 2/3/4 of oracle/_ref/ref_dump, tests/golden/) against the
+    LIBRARY's multi-rank path: the product's host assemble with the reference's partitioner over that many processes,
+    sgpu_op_create from this rank's layout, interior + boundary kernels, halos routed through gloo
+    (sgpu_debug_init_host_transport) -- matvec, fp32-halo matvec, residual, Jacobi and Chebyshev sweeps."""
+    import multiprocessing as mp      # not torch's: this process runs the system HIP runtime
+    import socket
+    fn = os.path.join(GOLDEN, fixture)
+    world = int(fixture.split(".np")[1].split(".")[0])
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_golden_worker, args=(r, world, port, fn, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        res = dict(ret)
+    for r in range(world):
+        assert res.get(r) == "ok", f"rank {r}: {res.get(r)}"
