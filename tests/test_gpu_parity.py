@@ -421,6 +421,28 @@ def _golden_worker(rank, world, port, fn, ret):
         G.chebyshev(4, 1.9371, du, dr); close(du.download(), "cheby4_v2_rhs2", 1e-12)
         Gf = host.device_operator(A, halo_fp32=True)       # matvec_sparse_float: fp32 halo on the wire
         Gf.spmv(dx, dy); close(dy.download(), "Av2_float", 1e-13)
+        if "P_ec" in ref:                                  # grid transfers on two partitions: rows by split, columns by splitNew
+            split = A.split
+            pr, pc, pv, Nc = inp.synthetic_P(M)
+            splitNew = ref["splitNew"].astype(np.int32)
+            mine = (pr >= lo) & (pr < hi)
+            P = host.Transfer.prolong(comm, M, Nc, split, splitNew, pr[mine], pc[mine], pv[mine])
+            R = P.transpose()
+            GP, GR = host.device_operator(P), host.device_operator(R)
+            clo, chi = int(splitNew[rank]), int(splitNew[rank + 1])
+            nc = chi - clo
+            dec, dpf, drc = c.DeviceVector(nc, inp.ec(Nc)[clo:chi]), c.DeviceVector(n), c.DeviceVector(nc)
+            GP.spmv(dec, dpf)
+            want = ref["P_ec"][lo:hi]
+            assert np.linalg.norm(dpf.download() - want) <= 1e-13 * max(np.linalg.norm(ref["P_ec"]), 1e-300)
+            dx.upload(v2)
+            GR.spmv(dx, drc)
+            want = ref["R_v2"][clo:chi]
+            assert np.linalg.norm(drc.download() - want) <= 1e-13 * max(np.linalg.norm(ref["R_v2"]), 1e-300)
+            du.upload(rhs2)                                # u -= P e (the V-cycle's correction, fused)
+            GP.prolong_correct(dec, du)
+            want = rhs2 - ref["P_ec"][lo:hi]
+            assert np.linalg.norm(du.download() - want) <= 1e-13 * max(np.linalg.norm(want), 1e-300)
         ret[rank] = "ok"
     except BaseException as e:      # noqa
         import traceback
