@@ -7,16 +7,19 @@ MASTER_* from the env).  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[1]): 3D 7-point Poisson 128^3 -> 126^3 = 2 000 376
 rows, 13 907 376 nnz, fp64 values / int32 indices, operator and vectors resident
-in HBM.  A step = one fine-level SpMV w = A v through sgpu_spmv (the HIP kernel
-k_csr_stream plus, for N>1, the RCCL halo exchange on the second stream).
-value = algorithmic bytes of all ranks' SpMVs / wall time.
-N>1 is weak scaling: every rank owns a 126-plane z-slab of a 128 x 128 x (126 N + 2)
+in HBM.  A step = one fine-level SpMV w = A v through sgpu_spmv (the autotuned HIP kernel,
+k_csr_cc16 here; for N>1 interior rows on the compute stream, pack + RCCL send/recv + boundary
+rows on the halo stream).  value = algorithmic bytes of all ranks' SpMVs
+/ wall time.  N>1 is weak scaling: every rank owns a 126-plane z-slab of a 128 x 128 x (126 N + 2)
 grid (2 000 376 rows per rank), neighbours exchange one 126^2 plane per side.
 
-Extra objects: `roofline` (HBM bound; kernel time from HIP events recorded on the
-compute stream around the timed launches) and `cpu_baseline` (the CPU restatement
-of the reference's matvec -- oracle/, test infrastructure -- timed on this box's
-cores, rank 0, N=1 only; never part of the measured path).
+Extra objects: `roofline` (HBM bound; kernel time from HIP events recorded on the compute stream
+around the timed launches), `check` (one more SpMV, outside the timed region, against the
+host-formed product incl. halo values), `vcycle` (pCG iterations/s and V-cycles/s, host-built
+hierarchy; for N>1 a strong-scaled leg on the global 128^3 problem and `vcycle_weak` on the
+weak-scaled operator) and `cpu_baseline` (the compiled reference's own matvec under mpirun on this
+box's cores -- oracle/_ref, test infrastructure -- or the oracle's restatement as fallback;
+rank 0, N=1 only; never part of the measured path).
 """
 import argparse
 import json
