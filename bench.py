@@ -5,21 +5,31 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it i
 launched by torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE/
 MASTER_* from the env).  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): 3D 7-point Poisson 128^3 -> 126^3 = 2 000 376
+Workload at N=1 (BASELINE.json configs[1]): 3D 7-point Poisson 128^3 -> 126^3 = 2 000 376
 rows, 13 907 376 nnz, fp64 values / int32 indices, operator and vectors resident
 in HBM.  A step = one fine-level SpMV w = A v through sgpu_spmv (the autotuned HIP kernel,
 k_csr_cc16 here; for N>1 interior rows on the compute stream, pack + RCCL send/recv + boundary
 rows on the halo stream).  value = algorithmic bytes of all ranks' SpMVs
-/ wall time.  N>1 is weak scaling: every rank owns a 126-plane z-slab of a 128 x 128 x (126 N + 2)
-grid (2 000 376 rows per rank), neighbours exchange one 126^2 plane per side.
+/ wall time.
+Workload at N>1 (BASELINE.json configs[3]): Poisson 512^3 row-partitioned by the reference's
+nnz-balanced partitioner (src/saena_matrix_repart.cpp:43-170).  At N=8 that is the whole 512^3
+operator (132 651 000 rows, 16.6 M rows / 116 M nnz per GPU); at N=2 and 4 the grid is
+512 x 512 x (round(510 N/8) + 2), i.e. every GPU keeps its 1/8-of-512^3-sized block (weak scaling),
+neighbours exchange one 510^2 plane (2 MB) per side.
 
 Extra objects: `roofline` (HBM bound; kernel time from HIP events recorded on the compute stream
-around the timed launches), `check` (one more SpMV, outside the timed region, against the
-host-formed product incl. halo values), `vcycle` (pCG iterations/s and V-cycles/s, host-built
-hierarchy; for N>1 a strong-scaled leg on the global 128^3 problem and `vcycle_weak` on the
-weak-scaled operator) and `cpu_baseline` (the compiled reference's own matvec under mpirun on this
-box's cores -- oracle/_ref, test infrastructure -- or the oracle's restatement as fallback;
+around the timed launches; states whether the working set is Infinity-Cache resident),
+`spmv_hbm_resident` (N=1: the same measurement on Poisson 256^3, 1.7 GB, beyond the 256 MiB cache;
+per-GPU work of configs[3]), `check` (one more SpMV, outside the timed region, against the
+host-formed product incl. halo values), `vcycle` (pCG iterations/s and V-cycles/s on the global
+128^3 problem, host-built hierarchy; strong-scaled for N>1), `vcycle_config4` (N>1: the same on
+the 512^3-share operator) and `cpu_baseline` (the compiled reference's own matvec under mpirun on
+this box's cores -- oracle/_ref, test infrastructure -- or the oracle's restatement as fallback;
 rank 0, N=1 only; never part of the measured path).
+
+Exit status: 0 only when every requested leg ran; a watchdog expiry, an exception or a fatal
+signal in a multi-rank leg still prints the measured line (with `vcycle_error`) and then exits 3 /
+128+signal, so the launcher sees the failure.
 """
 import argparse
 import json
@@ -39,10 +49,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--m", type=int, default=128, help="grid points per side (reference laplacian3D argument)")
+    ap.add_argument("--m", type=int, default=None, help="grid points per side (reference laplacian3D argument); default 128 at "
+                    "--gpus 1 (BASELINE configs[1]) and 512 at --gpus N>1 (configs[3]: rank r owns its 1/8-of-512^3-sized row block)")
+    ap.add_argument("--m-hbm", type=int, default=256, help="grid of the secondary HBM-resident SpMV figure at --gpus 1 (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
-    ap.add_argument("--vcycle-timeout", type=float, default=360.0, help="watchdog of the multi-rank V-cycle legs, seconds")
+    ap.add_argument("--vcycle-timeout", type=float, default=420.0, help="watchdog of the multi-rank V-cycle legs, seconds")
+    ap.add_argument("--no-config4-vcycle", action="store_true", help="N>1: skip the V-cycle leg on the 512^3-share operator (host setup of 16.6 M rows per rank)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -157,24 +170,23 @@ def verify_spmv(np, host, A, op, x, y, g0):
     M = d["M"]
     f = lambda g: np.sin(0.001 * g)                                          # noqa: E731
     rows = np.repeat(np.arange(M), d["nnzPerRow_local"])
-    want = np.zeros(M)
-    bound = np.zeros(M)
     t = d["val_local"] * f(d["col_local"].astype(np.float64))              # col_local holds GLOBAL ids
-    np.add.at(want, rows, t)
-    np.add.at(bound, rows, np.abs(t))
+    want = np.bincount(rows, weights=t, minlength=M).astype(np.float64)
+    bound = np.bincount(rows, weights=np.abs(t), minlength=M).astype(np.float64)
     hc = A.halo_columns()
     if len(hc):
         slot = np.repeat(np.arange(len(hc)), d["nnzPerCol_remote"])
         t = d["val_remote"] * f(hc[slot].astype(np.float64))
-        np.add.at(want, d["row_remote"], t)
-        np.add.at(bound, d["row_remote"], np.abs(t))
+        want += np.bincount(d["row_remote"], weights=t, minlength=M)
+        bound += np.bincount(d["row_remote"], weights=np.abs(t), minlength=M)
     err = float(np.max(np.abs(got - want)) / max(float(np.max(bound)), 1e-300)) if M else 0.0
     return err, int(M)
 
 
 def pmc_traffic(m, world, kernel_name):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (PMC counters cannot be
-    read from inside the process).  Only for the kernel those passes profiled; None for anything else."""
+    """Memory-side bytes per launch from the COMMITTED rocprofv3 PMC passes of this same command (PMC counters cannot
+    be read from inside the process, so this is never a measurement of the present run: the line says so with
+    `traffic_measured_in_run: false`).  Only for the kernel those passes profiled; None for anything else."""
     table = {"k_csr_cc16<16KiB>": "r01_pmc_spmv_128_cc16.json", "k_csr_stream<16KiB>": "r01_pmc_spmv_128.json"}
     name = table.get(kernel_name)
     path = os.path.join(ROOT, "profiles", name) if name else None
@@ -211,6 +223,42 @@ def _init_context(capi, world, rank, device, uid, dist):
         capi.init_host_transport(device, dist)
     else:
         capi.init(device=device, rank=rank, nranks=world, unique_id=uid)
+
+
+def measure_spmv(capi, host, np, A, rank, steps, warmup, sync_all):
+    """autotuned operator of A on the device; `warmup` untimed launches, then `steps` timed ones between barriers.
+    -> dict(op, info, kernel_name, ms_kernel, wall, B_local, x, y)"""
+    op = host.device_operator(A)
+    if os.environ.get("SAENA_BENCH_VARIANT"):            # pin the kernel (rocprofv3 --pmc perturbs the autotune's timings)
+        op.set_variant(int(os.environ["SAENA_BENCH_VARIANT"]))
+    else:
+        op.autotune()                                    # plan-time choice among the kernel variants (DESIGN.md 4)
+    info = op.info()
+    _, kernel_name = op.variant()
+    M = info["M"]
+    g0 = int(A.split[rank])
+    x = capi.DeviceVector(M, np.sin(0.001 * (g0 + np.arange(M))))
+    y = capi.DeviceVector(M)
+    for _ in range(warmup):
+        op.spmv(x, y)
+    sync_all()
+    t0 = time.perf_counter()
+    ms_kernel = op.time_kernel(0, x, None, y, steps)     # K launches, HIP events on the compute stream
+    capi.check(capi.lib().sgpu_device_sync())
+    sync_all()
+    wall = time.perf_counter() - t0
+    return dict(op=op, info=info, kernel_name=kernel_name, ms_kernel=ms_kernel, wall=wall, B_local=op.algorithmic_bytes(0),
+                x=x, y=y, g0=g0)
+
+
+def stored_bytes(info, kernel_name):
+    """bytes the SpMV's operands occupy in HBM: values, column ids as the chosen kernel stores them, row pointers, x, y"""
+    nnz = info["nnz_local"] + info["nnz_remote"]
+    col_bytes = 2 if "cc16" in kernel_name else 4
+    return (8 + col_bytes) * nnz + 4 * (info["M"] + 1) + 8 * info["N_local"] + 8 * info["M"]
+
+
+INFINITY_CACHE_BYTES = 256 * 2 ** 20                    # MI355X: 256 MiB memory-side cache (MI355X_MICROARCH.md)
 
 
 def main():
@@ -251,7 +299,7 @@ def main():
         _init_context(capi, world, rank, device, uid, dist)
 
     # ---- operator through the host mirror of saena::matrix (product path, no oracle) ----
-    m = args.m
+    m = args.m if args.m else (128 if world == 1 else 512)
     # Setup-time collectives (assemble, hierarchy distribution): over the RCCL communicator at one rank; with more
     # ranks over the gloo group already open for the rendezvous -- that path is exercised at world_size 2-4 by the
     # CPU test-suite, the RCCL one (RcclHostComm) only at one rank so far.  SAENA_BENCH_SETUP_COMM=rccl overrides.
@@ -262,24 +310,11 @@ def main():
         comm = host.Comm("gpu", "rccl")
     A = host.Matrix(comm)
     if world == 1:
-        A.laplacian3D(m).assemble()                      # reference partitioner (trivial at one rank)
-    else:
-        n = m - 2
-        A.laplacian3D(m, m, n * world + 2)
-        split = np.array([r * n * n * n for r in range(world + 1)], np.int32)
-        A.assemble(split)                                # even z-slabs: 126 planes per rank
-    op = host.device_operator(A)
-    if os.environ.get("SAENA_BENCH_VARIANT"):            # pin the kernel (rocprofv3 --pmc perturbs the autotune's timings)
-        op.set_variant(int(os.environ["SAENA_BENCH_VARIANT"]))
-    else:
-        op.autotune()                                    # plan-time choice among the kernel variants
-    info = op.info()
-    variant, kernel_name = op.variant()
-    M = info["M"]
-    g0 = int(A.split[rank])
-    x = capi.DeviceVector(M, np.sin(0.001 * (g0 + np.arange(M))))
-    y = capi.DeviceVector(M)
-    B_local = op.algorithmic_bytes(0)
+        grid = (m, m, m)
+    else:                                                # this many ranks' worth of the m^3 problem's 8 row blocks
+        grid = (m, m, int(round((m - 2) * world / 8.0)) + 2)
+    A.laplacian3D(*grid).assemble()                      # reference partitioner: nnz-balanced contiguous row blocks
+    grid_s = f"{grid[0]}^3" if grid[0] == grid[1] == grid[2] else f"{grid[0]}x{grid[1]}x{grid[2]}"
 
     def sync_all():
         capi.check(capi.lib().sgpu_barrier())
@@ -287,17 +322,12 @@ def main():
             dist.barrier()
 
     # ---- warm-up, then EXACTLY K timed steps between barriers ----
-    for _ in range(args.warmup):
-        op.spmv(x, y)
-    sync_all()
-    t0 = time.perf_counter()
-    ms_kernel = op.time_kernel(0, x, None, y, args.steps)   # K launches, HIP events on the compute stream
-    capi.check(capi.lib().sgpu_device_sync())
-    sync_all()
-    wall = time.perf_counter() - t0
+    R = measure_spmv(capi, host, np, A, rank, args.steps, args.warmup, sync_all)
+    op, info, kernel_name, ms_kernel, wall, B_local = R["op"], R["info"], R["kernel_name"], R["ms_kernel"], R["wall"], R["B_local"]
 
-    err, _ = verify_spmv(np, host, A, op, x, y, g0)        # outside the timed region
+    err, _ = verify_spmv(np, host, A, op, R["x"], R["y"], R["g0"])        # outside the timed region
     B_total = B_local
+    rows_all, halo_all = [info["M"]], [info["nnz_remote"]]
     if dist is not None:
         import torch
         e = torch.tensor([err], dtype=torch.float64)
@@ -309,12 +339,18 @@ def main():
         b = torch.tensor([float(B_local)], dtype=torch.float64)
         dist.all_reduce(b)
         B_total = float(b[0])
+        g = [None] * world
+        dist.all_gather_object(g, (info["M"], info["nnz_remote"]))
+        rows_all, halo_all = [x[0] for x in g], [x[1] for x in g]
 
+    out = None
     if rank == 0:
         sec_per_step = wall / args.steps
         achieved = B_local / (ms_kernel * 1e-3) / 1e9
+        ws = stored_bytes(info, kernel_name)
+        traffic, traffic_src = pmc_traffic(m, world, kernel_name)
         out = {
-            "metric": "fine-level SpMV effective GB/s (3D 7-pt Poisson 128^3, fp64)",
+            "metric": f"fine-level SpMV effective GB/s (3D 7-pt Poisson {grid_s}, fp64)",
             "value": round(B_total / sec_per_step / 1e9, 2),
             "unit": "GB/s",
             "n_gpus": world,
@@ -327,10 +363,15 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"Poisson {m}^3 (Saena laplacian3D, boundary rows removed): SpMV w=Av, "
-                            f"{info['M']} rows x {info['nnz_local'] + info['nnz_remote']} nnz per GPU, int32 indices",
-                "rows_per_gpu": info["M"], "nnz_per_gpu": info["nnz_local"] + info["nnz_remote"],
-                "partition": "1 rank" if world == 1 else f"{world} even z-slabs, RCCL halo of {n * n} doubles per side",
+                "workload": (f"Poisson {grid_s} (Saena laplacian3D, boundary rows removed): SpMV w=Av, "
+                             f"{info['M']} rows x {info['nnz_local'] + info['nnz_remote']} nnz on rank 0, int32 indices"
+                             + ("; BASELINE configs[1]" if world == 1 and m == 128 else "")
+                             + (f"; BASELINE configs[3]: this is {world}/8 of the Poisson {m}^3 operator, one 1/8-sized row block per GPU"
+                                if world > 1 else "")),
+                "rows_per_gpu": rows_all, "nnz_per_gpu": info["nnz_local"] + info["nnz_remote"],
+                "partition": "1 rank" if world == 1 else
+                             f"{world} nnz-balanced contiguous row blocks (reference partitioner), RCCL halo of <= {grid[0] - 2}^2 doubles per side "
+                             f"(remote nnz per rank {halo_all})",
                 "pct_of_hbm_peak": round(B_total / sec_per_step / 1e9 / (HBM_PEAK_GBS * world) * 100, 2),
             },
             "check": {"what": "y = A x of one more SpMV against the host-formed product from the layout arrays, halo values included; "
@@ -341,9 +382,38 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "us_per_launch": round(ms_kernel * 1e3, 3), "algorithmic_bytes": B_local,
-                "traffic": pmc_traffic(m, world, kernel_name)[0], "traffic_source": pmc_traffic(m, world, kernel_name)[1],
+                "working_set_bytes": ws, "cache_resident": bool(ws <= INFINITY_CACHE_BYTES),
+                "note": ("the operator and vectors fit the 256 MiB Infinity Cache: repeated launches are served by it, so `achieved` "
+                         "can exceed what HBM alone sustains (~6.1 TB/s reads); see spmv_hbm_resident for the HBM-bound figure"
+                         if ws <= INFINITY_CACHE_BYTES else "working set beyond the 256 MiB Infinity Cache: HBM-bound"),
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False if traffic is not None else None,
             },
         }
+    # free the big operator's vectors before the legs allocate theirs
+    if world == 1 and not multi and args.m_hbm and args.m_hbm != m:
+        # the same measurement on an operator beyond the Infinity Cache (Poisson 256^3: 16.4 M rows, 114 M nnz, 1.7 GB
+        # algorithmic -- also the per-GPU share of configs[3])
+        A3 = host.Matrix(comm)
+        A3.laplacian3D(args.m_hbm).assemble()
+        steps3, warm3 = max(10, args.steps // 8), max(3, args.warmup // 8)
+        R3 = measure_spmv(capi, host, np, A3, 0, steps3, warm3, sync_all)
+        e3, _ = verify_spmv(np, host, A3, R3["op"], R3["x"], R3["y"], 0)
+        a3 = R3["B_local"] / (R3["ms_kernel"] * 1e-3) / 1e9
+        ws3 = stored_bytes(R3["info"], R3["kernel_name"])
+        out["spmv_hbm_resident"] = {
+            "workload": f"Poisson {args.m_hbm}^3: {R3['info']['M']} rows x {R3['info']['nnz_local']} nnz, same kernel path",
+            "kernel": f"{R3['kernel_name']}, {R3['info']['lanes_per_row']} lane(s)/row", "steps": steps3, "warmup": warm3,
+            "us_per_launch": round(R3["ms_kernel"] * 1e3, 3), "algorithmic_bytes": R3["B_local"], "working_set_bytes": ws3,
+            "cache_resident": bool(ws3 <= INFINITY_CACHE_BYTES), "achieved": round(a3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(a3 / HBM_PEAK_GBS, 4), "check_max_rel_err": e3,
+        }
+        R3["op"].destroy()
+        for k in ("x", "y"):
+            R3[k].free()
+        A3.free()
+        del R3, A3
+
+    if rank == 0:
         if world == 1 and not multi and not args.no_vcycle:
             out["vcycle"] = vcycle_leg(capi, host, A, m)
         if world == 1 and not args.no_cpu_baseline:
@@ -351,7 +421,9 @@ def main():
 
     if multi and not args.no_vcycle:
         # V-cycle / pCG over all ranks, halos over RCCL.  Runs under a watchdog and a fatal-signal printer: whatever
-        # happens in here, rank 0 still prints the SpMV line measured above.
+        # happens in here, rank 0 still prints the SpMV line measured above -- and the process then ends with a
+        # NON-ZERO status (3 for a watchdog expiry or an exception, 128 + signal for a fatal signal), so the launcher
+        # records the failure.
         import threading
 
         legs = {}
@@ -365,36 +437,42 @@ def main():
             return json.dumps(o)
 
         def bail():
+            msg = f"multi-rank V-cycle legs did not finish within {args.vcycle_timeout:.0f} s"
             if rank == 0:
-                print(line(f"multi-rank V-cycle legs did not finish within {args.vcycle_timeout:.0f} s"), flush=True)
-            os._exit(0)
+                print(line(msg), flush=True)
+            print(f"bench.py rank {rank}: {msg}", file=sys.stderr, flush=True)
+            os._exit(3)
         dog = threading.Timer(args.vcycle_timeout, bail)
         dog.daemon = True
         dog.start()
-        # a native crash (GPU fault -> abort, or SIGTERM from the launcher when a sibling rank died) still prints the line
+        # a native crash (GPU fault -> abort) still prints the line, then exits 128 + signal
         fatal = capi.lib().sgpu_debug_on_fatal_print
-        capi.check(fatal(line("a multi-rank V-cycle leg ended with a fatal signal").encode()))
+        capi.check(fatal(line("the 128^3 multi-rank V-cycle leg ended with a fatal signal").encode()))
         try:
-            # (1) parity: the SAME global Poisson m^3 problem as at N=1 (strong scaling), row blocks from the reference's
+            # (1) parity: the SAME global Poisson 128^3 problem as at N=1 (strong scaling), row blocks from the reference's
             #     nnz-balanced partitioner -- the residuals are comparable with the reference's printed digits
             A2 = host.Matrix(comm)
-            A2.laplacian3D(m).assemble()
+            A2.laplacian3D(128 if m >= 128 else m).assemble()
             leg = vcycle_leg(capi, host, A2, m, dist)
             leg["scaling"] = "strong"
-            leg["partition"] = f"{world} nnz-balanced row blocks of the global Poisson {m}^3 operator"
+            leg["partition"] = f"{world} nnz-balanced row blocks of the global Poisson {128 if m >= 128 else m}^3 operator"
             legs["vcycle"] = leg
-            capi.check(fatal(line("the weak-scaled V-cycle leg ended with a fatal signal").encode()))
-            # (2) performance: the weak-scaled operator of the SpMV measurement above (2 000 376 rows per GPU); every
-            #     rank builds only its rows of the hierarchy (row-distributed setup)
-            leg = vcycle_leg(capi, host, A, m, dist)
-            leg["scaling"] = "weak"
-            leg["partition"] = f"{world} even z-slabs of Poisson {m} x {m} x {(m - 2) * world + 2}"
-            legs["vcycle_weak"] = leg
-        except Exception as e:                              # noqa: BLE001 -- reported, never fatal for the SpMV line
+            A2.free()
+            if not args.no_config4_vcycle:
+                capi.check(fatal(line("the configs[3] V-cycle leg ended with a fatal signal").encode()))
+                # (2) configs[3]: the operator of the SpMV measurement above (16.6 M rows per GPU at m = 512); every
+                #     rank builds only its rows of the hierarchy (row-distributed setup)
+                leg = vcycle_leg(capi, host, A, m, dist)
+                leg["scaling"] = "weak"
+                leg["partition"] = f"{world} nnz-balanced row blocks of Poisson {grid_s}"
+                legs["vcycle_config4"] = leg
+        except Exception as e:                              # noqa: BLE001 -- reported with the SpMV line, then a failing status
             dog.cancel()
+            msg = f"{type(e).__name__}: {e}"
             if rank == 0:
-                print(line(f"{type(e).__name__}: {e}"), flush=True)
-            os._exit(0)
+                print(line(msg), flush=True)
+            print(f"bench.py rank {rank}: multi-rank V-cycle leg failed: {msg}", file=sys.stderr, flush=True)
+            os._exit(3)
         dog.cancel()
         capi.check(fatal(None))
         if rank == 0:

@@ -153,17 +153,6 @@ int sgpu_spmv_host(sgpu_op *op, const value_t *v_host, value_t *w_host);
 int sgpu_jacobi_host(sgpu_op *op, int iter, value_t omega, value_t *u_host, const value_t *rhs_host);
 int sgpu_chebyshev_host(sgpu_op *op, int iter, value_t eig_max, value_t *u_host, const value_t *rhs_host);
 
-/* Test hooks for the halo path on a single GPU (RCCL refuses two ranks on one
- * device): sgpu_debug_pack runs the pack kernel (saena_matrix_matvec.cpp:25-26)
- * and downloads the send buffer; sgpu_debug_inject_halo uploads the receive
- * buffer and makes the following applies use the remote part without any
- * exchange.  Tests route the buffers between operators on the host. */
-int sgpu_debug_pack(sgpu_op *op, const value_t *v, value_t *send_host);
-/* diagnostic: time of the x[col] gather alone over the local part, mode 0 = production lane mapping (4 consecutive
- * nnz per lane), 1 = 64 consecutive nnz per gather instruction */
-int sgpu_debug_gather_probe(sgpu_op *op, int mode, const value_t *x, int reps, float *ms);
-int sgpu_debug_inject_halo(sgpu_op *op, const value_t *recv_host);
-
 /* ---- multigrid hierarchy --------------------------------------------------
  * Replaces the Grid array of saena_object (include/grid.h:11-78) for the solve
  * phase: level l holds A[l] and, for l < nlevels-1, P[l] (fine rows) and R[l]
@@ -212,23 +201,6 @@ int sgpu_solve_smoother(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters,
 int sgpu_solve_CG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value_t *res_hist, int hist_cap);
 /* solve_coarsest_CG on the last level only (for tests) */
 int sgpu_coarsest_solve(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters);
-
-/* Host-routed transport (validation without one GPU per rank -- RCCL refuses several ranks on one device): the
- * context of rank `rank` of `nranks` is created WITHOUT an RCCL communicator; every halo exchange is staged through
- * host memory and handed to `exchange`, every scalar reduction to `allreduce_sum`.  All library code above the
- * transport (plans, interior/boundary kernels, V-cycle, solve*, coarsest level on one rank ...) is the multi-rank
- * code.  exchange: send/recv are packed host buffers of `elem_bytes`-sized elements, peers in ascending rank order. */
-typedef int (*sgpu_host_exchange_fn)(void *user, const void *send, const int *send_rank, const int *send_count, int nsend,
-                                     void *recv, const int *recv_rank, const int *recv_count, int nrecv, int elem_bytes);
-typedef int (*sgpu_host_allreduce_fn)(void *user, double *v, int n);
-int sgpu_debug_init_host_transport(int device_id, int rank, int nranks, sgpu_host_exchange_fn exchange,
-                                   sgpu_host_allreduce_fn allreduce_sum, void *user);
-
-/* bench.py only: from now on a fatal signal in this process (SIGSEGV/SIGBUS/SIGABRT/SIGFPE/SIGILL/SIGTERM -- the HIP
- * runtime aborts on a GPU fault, torchrun sends SIGTERM when a sibling rank dies) writes `line` (may be empty) to
- * stdout and ends the process with status 0, so that an optional leg running after the measurement cannot lose the
- * measured line.  NULL restores the default handlers.  `line` is copied. */
-int sgpu_debug_on_fatal_print(const char *line);
 
 /* ---- measurement -----------------------------------------------------------
  * Runs `reps` back-to-back launches of one kernel on the compute stream,

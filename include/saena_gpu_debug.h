@@ -1,0 +1,55 @@
+/*
+ * saena_gpu_debug.h -- test, rehearsal and bench scaffolding exported by libsaena_amd.so.
+ *
+ * NOT part of the drop-in boundary (that is include/saena_gpu.h): nothing a Saena maintainer binds
+ * lives here.  These entry points exist so that the multi-rank code of the library can be validated
+ * on ONE GPU (RCCL refuses several ranks on one device) and so that bench.py can keep a measured line
+ * when an optional later leg dies.  tests/, bench.py and the perf scripts are the only callers.
+ */
+#ifndef SAENA_GPU_DEBUG_H
+#define SAENA_GPU_DEBUG_H
+
+#include "saena_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Halo path on a single GPU: sgpu_debug_pack runs the pack kernel (saena_matrix_matvec.cpp:25-26) and
+ * downloads the send buffer; sgpu_debug_inject_halo uploads the receive buffer and makes the following
+ * applies use the remote part without any exchange.  Tests route the buffers between operators on the host. */
+int sgpu_debug_pack(sgpu_op *op, const value_t *v, value_t *send_host);
+int sgpu_debug_inject_halo(sgpu_op *op, const value_t *recv_host);
+/* An operator with remote entries applied in a context that has neither a communicator nor a host transport nor
+ * an injected halo is an error (SGPU_ERR_STATE): the result would silently miss the remote part.  allow != 0
+ * lifts that for this operator: only its local part is applied (plan/launch tests whose numbers mean nothing). */
+int sgpu_debug_allow_local_only(sgpu_op *op, int allow);
+/* diagnostic: time of the x[col] gather alone over the local part, mode 0 = production lane mapping (4 consecutive
+ * nnz per lane), 1 = 64 consecutive nnz per gather instruction */
+int sgpu_debug_gather_probe(sgpu_op *op, int mode, const value_t *x, int reps, float *ms);
+
+/* Host-routed transport (validation without one GPU per rank): the context of rank `rank` of `nranks` is created
+ * WITHOUT an RCCL communicator; every halo exchange is staged through host memory and handed to `exchange`, every
+ * scalar reduction to `allreduce_sum`.  All library code above the transport (plans, interior/boundary kernels,
+ * V-cycle, solve*, coarse levels agglomerated onto fewer ranks ...) is the multi-rank code.  exchange: send/recv are
+ * packed host buffers of `elem_bytes`-sized elements, peers in ascending rank order. */
+typedef int (*sgpu_host_exchange_fn)(void *user, const void *send, const int *send_rank, const int *send_count, int nsend,
+                                     void *recv, const int *recv_rank, const int *recv_count, int nrecv, int elem_bytes);
+typedef int (*sgpu_host_allreduce_fn)(void *user, double *v, int n);
+int sgpu_debug_init_host_transport(int device_id, int rank, int nranks, sgpu_host_exchange_fn exchange,
+                                   sgpu_host_allreduce_fn allreduce_sum, void *user);
+
+/* bench.py only: from now on a fatal signal in this process (SIGSEGV/SIGBUS/SIGABRT/SIGFPE/SIGILL -- the HIP runtime
+ * aborts on a GPU fault) writes `line` (may be empty) to stdout, a one-line reason to stderr, and ends the process
+ * with status 128 + signal: the line measured before an optional later leg is kept, and the failure still reaches
+ * the launcher as a failure.  SIGTERM is not trapped.  NULL restores the default handlers.  `line` is copied. */
+int sgpu_debug_on_fatal_print(const char *line);
+
+/* number of kernel launches + graph launches + RCCL group calls the library has enqueued since sgpu_init
+ * (tests: "fewer launches per V-cycle"); counts host-side enqueues, not GPU work */
+int sgpu_debug_launch_count(long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAENA_GPU_DEBUG_H */

@@ -42,7 +42,8 @@ class AmgParams(C.Structure):
     ]
 
 
-# every symbol include/saena_gpu.h declares: name -> (restype, argtypes)
+# every symbol include/saena_gpu.h (the boundary) and include/saena_gpu_debug.h (test scaffolding) declare:
+# name -> (restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = {
     "sgpu_last_error": (C.c_char_p, []),
@@ -91,6 +92,8 @@ SYMBOLS = {
     "sgpu_amg_profile_matvecs": (C.c_int, [_VP, C.c_int, _PD]),
     "sgpu_coarsest_solve": (C.c_int, [_VP, _VP, _VP, _PI]),
     "sgpu_debug_on_fatal_print": (C.c_int, [C.c_char_p]),
+    "sgpu_debug_launch_count": (C.c_int, [C.POINTER(C.c_long)]),
+    "sgpu_debug_allow_local_only": (C.c_int, [_VP, C.c_int]),
     "sgpu_debug_init_host_transport": (C.c_int, [C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
     "sgpu_time_kernel": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.POINTER(C.c_float)]),
     "sgpu_algorithmic_bytes": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64)]),
@@ -339,6 +342,9 @@ class Operator:
         check(lib().sgpu_debug_pack(self.h, v.ptr, out.ctypes.data_as(_PD)))
         return out
 
+    def debug_allow_local_only(self, allow=True):
+        check(lib().sgpu_debug_allow_local_only(self.h, 1 if allow else 0))
+
     def debug_inject_halo(self, recv):
         recv = _ad(recv)
         check(lib().sgpu_debug_inject_halo(self.h, recv.ctypes.data_as(_PD)))
@@ -442,6 +448,12 @@ class Amg:
                 self.destroy()
         except Exception:
             pass
+
+
+def launch_count():
+    n = C.c_long()
+    check(lib().sgpu_debug_launch_count(C.byref(n)))
+    return n.value
 
 
 def dot(x, y):

@@ -9,8 +9,24 @@
 #include <numeric>
 #include <iomanip>
 #include <sstream>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace saena_host {
+
+namespace {
+struct AsmTimer {         // SAENA_SETUP_TIMING=1: phase times of assemble() on stderr
+    bool on = std::getenv("SAENA_SETUP_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[assemble] %-28s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
+} // namespace
 
 long lower_bound2(const index_t *left, const index_t *right, index_t val) {
     // aux_functions.h:39-58: position p with split[p] <= val < split[p+1]
@@ -41,6 +57,34 @@ static std::vector<T> route(Comm &comm, const std::vector<T> &recs, const std::v
     std::vector<size_t> fill(off.begin(), off.end() - 1);
     for (size_t i = 0; i < recs.size(); ++i) send[fill[dest[i]]++] = recs[i];
     return comm.alltoallv_records(send, cnt);
+}
+
+template <class T, class KeyFn>
+static std::vector<T> route(Comm &comm, std::vector<T> &&recs, const std::vector<index_t> &split, KeyFn key) {
+    if (comm.nranks == 1) return std::move(recs);
+    return route(comm, static_cast<const std::vector<T> &>(recs), split, key);
+}
+
+// Column-major order of entries that arrive row-major sorted (what the generators, the dedup pass and a route()
+// over ascending row blocks all produce): a counting sort by column keeps rows ascending inside a column, one O(n)
+// pass instead of an O(n log n) comparison sort -- 114 M entries of Poisson 256^3: 25 s -> 1.5 s.  Falls back to
+// std::sort when the input is not row-major sorted or the column range is too wide for a count array.
+static void sort_col_major(std::vector<cooEntry> &e) {
+    if (e.size() < 2) return;
+    index_t cmin = e[0].col, cmax = e[0].col;
+    bool sorted = true;
+    for (size_t i = 0; i < e.size(); ++i) {
+        cmin = std::min(cmin, e[i].col); cmax = std::max(cmax, e[i].col);
+        if (i && row_major(e[i], e[i - 1])) sorted = false;
+    }
+    const size_t range = (size_t)cmax - (size_t)cmin + 1;
+    if (!sorted || range > 8 * e.size() + (1u << 20)) { std::sort(e.begin(), e.end(), col_major); return; }
+    std::vector<size_t> at(range + 1, 0);
+    for (const auto &x : e) at[(size_t)(x.col - cmin) + 1]++;
+    for (size_t c = 0; c < range; ++c) at[c + 1] += at[c];
+    std::vector<cooEntry> out(e.size());
+    for (const auto &x : e) out[at[(size_t)(x.col - cmin)]++] = x;
+    e.swap(out);
 }
 
 // every rank's list, concatenated in rank order, on every rank
@@ -174,6 +218,7 @@ int saena_matrix::writeMatrixToFile(const std::string &name) const {
 void saena_matrix::setup_initial_data() {
     Comm &c = *comm;
     const int np = c.nranks;
+    AsmTimer tm;
     // global row count = largest row index + 1 (:126-128)
     long mx = -1;
     for (const auto &e : data_in) mx = std::max<long>(mx, std::max(e.row, e.col));
@@ -184,21 +229,27 @@ void saena_matrix::setup_initial_data() {
     const index_t ofst = Mbig_with_bound / np;
     for (int i = 0; i < np; ++i) split0[i] = i * ofst;
     split0[np] = Mbig_with_bound;
-    std::vector<cooEntry> mine = route(c, data_in, split0, [](const cooEntry &e) { return e.row; });
+    std::vector<cooEntry> mine = route(c, std::move(data_in), split0, [](const cooEntry &e) { return e.row; });
     data_in.clear(); data_in.shrink_to_fit();
-    std::stable_sort(mine.begin(), mine.end(), row_major);
-    // duplicates: add or keep the last one; drop |val| <= ALMOST_ZERO (:147-165)
-    std::vector<cooEntry> wb;
-    wb.reserve(mine.size());
-    for (size_t i = 0; i < mine.size(); ++i) {
-        value_t tmp = mine[i].val;
-        while (i + 1 < mine.size() && mine[i + 1].row == mine[i].row && mine[i + 1].col == mine[i].col) {
-            ++i;
-            tmp = add_duplicates ? tmp + mine[i].val : mine[i].val;
+    if (!std::is_sorted(mine.begin(), mine.end(), row_major))       // (the generators set() their entries in this order already)
+        std::stable_sort(mine.begin(), mine.end(), row_major);
+    // duplicates: add or keep the last one; drop |val| <= ALMOST_ZERO (:147-165).  Compacted in place (the write
+    // position never overtakes the read position): no second 16 B/entry array.
+    std::vector<cooEntry> &wb = mine;
+    {
+        size_t w = 0;
+        for (size_t i = 0; i < mine.size(); ++i) {
+            const index_t r = mine[i].row, cl = mine[i].col;
+            value_t tmp = mine[i].val;
+            while (i + 1 < mine.size() && mine[i + 1].row == r && mine[i + 1].col == cl) {
+                ++i;
+                tmp = add_duplicates ? tmp + mine[i].val : mine[i].val;
+            }
+            if (std::fabs(tmp) > SAENA_ALMOST_ZERO) mine[w++] = cooEntry(r, cl, tmp);
         }
-        if (std::fabs(tmp) > SAENA_ALMOST_ZERO) wb.emplace_back(mine[i].row, mine[i].col, tmp);
+        mine.resize(w);
     }
-    mine.clear(); mine.shrink_to_fit();
+    tm.lap("  route + sort + dedup");
 
     bound_row_global.clear();
     Mbig = Mbig_with_bound;
@@ -219,19 +270,30 @@ void saena_matrix::setup_initial_data() {
             remove_boundary = false;                     // :332-335
         } else {
             const auto &B = bound_row_global;
-            auto new_idx = [&B](index_t x) { return x - (index_t)(std::lower_bound(B.begin(), B.end(), x) - B.begin()); };
-            auto is_bnd = [&B](index_t x) { return std::binary_search(B.begin(), B.end(), x); };
-            std::vector<cooEntry> in;
-            in.reserve(wb.size());
-            for (const auto &e : wb) {
-                if (is_bnd(e.row)) continue;
-                if (is_bnd(e.col)) throw std::runtime_error("saena_matrix: interior row couples to a removed boundary node");
-                in.emplace_back(new_idx(e.row), new_idx(e.col), e.val);
+            // renumbering table over the index range this rank's entries touch: -1 = removed, else the new id
+            // (two binary searches per entry over the 390 K boundary nodes of 256^3 cost 20 s of a 64 s assemble)
+            index_t lo = Mbig_with_bound, hi = -1;
+            for (const auto &e : wb) { lo = std::min(lo, std::min(e.row, e.col)); hi = std::max(hi, std::max(e.row, e.col)); }
+            std::vector<index_t> tab(hi >= lo ? (size_t)(hi - lo) + 1 : 0);
+            {
+                size_t b = (size_t)(std::lower_bound(B.begin(), B.end(), lo) - B.begin());   // boundary nodes below lo
+                for (index_t x = lo; x <= hi; ++x) {
+                    if (b < B.size() && B[b] == x) { tab[(size_t)(x - lo)] = -1; ++b; }
+                    else tab[(size_t)(x - lo)] = x - (index_t)b;
+                }
             }
-            wb.swap(in);
+            size_t w = 0;                                   // compacted in place
+            for (size_t i = 0; i < wb.size(); ++i) {
+                const index_t r = tab[(size_t)(wb[i].row - lo)], cc = tab[(size_t)(wb[i].col - lo)];
+                if (r < 0) continue;
+                if (cc < 0) throw std::runtime_error("saena_matrix: interior row couples to a removed boundary node");
+                wb[w++] = cooEntry(r, cc, wb[i].val);
+            }
+            wb.resize(w);
             Mbig = Mbig_with_bound - (index_t)B.size();
         }
     }
+    tm.lap("  boundary removal");
     entry.swap(wb);      // row-major, whole rows, global (renumbered) ids; ownership still by split0
     nnz_l = (nnz_t)entry.size();
     nnz_g = c.sum(nnz_l);
@@ -278,8 +340,8 @@ void saena_matrix::repartition_nnz_initial() {
         split[nprocs] = Mbig;
     }
     // move the entries to their owners (saena_matrix_repart.cpp:293 MPI_Alltoallv) and sort column-major
-    entry = route(c, entry, split, [](const cooEntry &e) { return e.row; });
-    std::sort(entry.begin(), entry.end(), col_major);
+    entry = route(c, std::move(entry), split, [](const cooEntry &e) { return e.row; });
+    sort_col_major(entry);
     M = split[c.rank + 1] - split[c.rank];
     nnz_l = (nnz_t)entry.size();
 }
@@ -303,9 +365,10 @@ void saena_matrix::matrix_setup() {            // saena_matrix_setup.cpp:507-560
 }
 
 int saena_matrix::assemble() {                 // saena_matrix_setup.cpp:4-17
-    setup_initial_data();
-    repartition_nnz_initial();
-    matrix_setup();
+    AsmTimer tm;
+    setup_initial_data();      tm.lap("setup_initial_data");
+    repartition_nnz_initial(); tm.lap("repartition_nnz_initial");
+    matrix_setup();            tm.lap("matrix_setup");
     return 0;
 }
 
@@ -315,8 +378,8 @@ int saena_matrix::assemble_with_split(const std::vector<index_t> &split_in) {
     setup_initial_data();
     if (split_in.back() != Mbig) throw std::runtime_error("assemble_with_split: split does not cover the matrix");
     split = split_in;
-    entry = route(c, entry, split, [](const cooEntry &e) { return e.row; });
-    std::sort(entry.begin(), entry.end(), col_major);
+    entry = route(c, std::move(entry), split, [](const cooEntry &e) { return e.row; });
+    sort_col_major(entry);
     M = split[c.rank + 1] - split[c.rank];
     nnz_l = (nnz_t)entry.size();
     matrix_setup();
@@ -377,17 +440,17 @@ void DistLayout::build(Comm &c, const std::vector<cooEntry> &entry, const std::v
     nnzPerRow_local.assign((size_t)M, 0);
     recvCount.assign((size_t)nprocs, 0);
     nnzPerProcScan.assign((size_t)nprocs + 1, 0);
-    std::vector<cooEntry> ent_loc_row;
-    ent_loc_row.reserve((size_t)nnz_l);
+    std::vector<std::pair<nnz_t, nnz_t>> loc_runs;                       // [begin, end) runs of `entry` that are local
     nnz_t i = 0;
     while (i < nnz_l) {                                                  // :828-859
         const long procNum = owner_of(split_col, entry[i].col);
         if (procNum == rank) {
+            const nnz_t b = i;
             while (i < nnz_l && entry[i].col < split_col[procNum + 1]) {
                 ++nnzPerRow_local[entry[i].row - split_row[rank]];
-                ent_loc_row.emplace_back(entry[i].row - split_row[rank], entry[i].col, entry[i].val);
                 ++i;
             }
+            loc_runs.emplace_back(b, i);
         } else {
             const nnz_t tmp = i;
             while (i < nnz_l && entry[i].col < split_col[procNum + 1]) {
@@ -405,20 +468,25 @@ void DistLayout::build(Comm &c, const std::vector<cooEntry> &entry, const std::v
             nnzPerProcScan[procNum + 1] = i - tmp;
         }
     }
-    nnz_l_local = (nnz_t)ent_loc_row.size();
+    nnz_l_local = 0;
+    for (const auto &r : loc_runs) nnz_l_local += r.second - r.first;
     nnz_l_remote = (nnz_t)row_remote.size();
     col_remote_size = (index_t)vElement_remote.size();
     recvCount[rank] = 0;
     // :905 row-major order.  The local entries arrive column-major (rows ascending inside a column), so a counting
-    // sort by row -- the row lengths are known -- yields (row, column) order in one pass instead of an O(n log n) sort.
-    row_local.resize((size_t)nnz_l_local); col_local.resize((size_t)nnz_l_local); val_local.resize((size_t)nnz_l_local);
+    // sort by row -- the row lengths are known -- yields (row, column) order in one pass instead of an O(n log n) sort,
+    // straight from `entry` (no intermediate copy).  row_local (which the reference fills and its matvec never
+    // reads) is not materialised: it is the row-pointer expansion of nnzPerRow_local.
+    col_local.resize((size_t)nnz_l_local); val_local.resize((size_t)nnz_l_local);
     {
         std::vector<nnz_t> at((size_t)M + 1, 0);
         for (index_t r = 0; r < M; ++r) at[r + 1] = at[r] + nnzPerRow_local[r];
-        for (const auto &e : ent_loc_row) {
-            const nnz_t k = at[e.row]++;
-            row_local[k] = e.row; col_local[k] = e.col; val_local[k] = e.val;
-        }
+        const index_t r0 = split_row[rank];
+        for (const auto &run : loc_runs)
+            for (nnz_t k2 = run.first; k2 < run.second; ++k2) {
+                const nnz_t k = at[entry[k2].row - r0]++;
+                col_local[k] = entry[k2].col; val_local[k] = entry[k2].val;
+            }
     }
     for (int p = 1; p < nprocs + 1; ++p) nnzPerProcScan[p] += nnzPerProcScan[p - 1];   // :948-950
 

@@ -40,7 +40,7 @@ struct DistLayout {
     index_t col_offset = 0;        // split_col[rank]
     nnz_t   nnz_l_local = 0, nnz_l_remote = 0;
     index_t col_remote_size = 0;
-    std::vector<index_t> nnzPerRow_local, row_local, col_local;
+    std::vector<index_t> nnzPerRow_local, col_local;   // (the reference also fills row_local; nothing reads it)
     std::vector<value_t> val_local;
     std::vector<index_t> nnzPerCol_remote, row_remote, col_remote, col_remote2, vElement_remote;
     std::vector<value_t> val_remote;

@@ -6,6 +6,7 @@
 // overlaps the local SpMV exactly where the reference overlaps MPI_Isend/Irecv
 // with its local loop (src/saena_matrix_matvec.cpp:32-80).  See apply().
 #include "../../include/saena_gpu.h"
+#include "../../include/saena_gpu_debug.h"
 #include "kernels.hip.h"
 #include "host/comm.h"
 
@@ -26,6 +27,9 @@
 namespace {
 
 thread_local std::string g_err;
+long g_launches = 0;          // host-side enqueues (kernels, graph launches, RCCL groups): sgpu_debug_launch_count
+uint64_t g_plan_generation = 0;   // bumped whenever an operator's kernel plan changes: captured graphs made before are stale
+#define SGPU_LAUNCH(...) do { ++g_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -77,7 +81,7 @@ struct Ctx {
     sgpu_host_allreduce_fn ared = nullptr;
     void                  *xuser = nullptr;
     bool multi() const { return comm != nullptr || xchg != nullptr; }
-    std::vector<char> peer_seen;   // RCCL connects a peer lazily at the first send/recv with it: see apply()
+    std::vector<char> peer_seen;   // RCCL connects a peer lazily at the first send/recv with it (bit 0 send, bit 1 recv): see apply()
 };
 Ctx g;
 
@@ -88,6 +92,9 @@ int host_allreduce(double *v, int n) {
     if (g.ared(g.xuser, v, n) != 0) return fail(SGPU_ERR_RCCL, "host transport: allreduce callback failed");
     return SGPU_OK;
 }
+
+// sum of a few host doubles over the ranks (setup-time decisions every rank must take alike); identity at one rank
+int global_sum(double *v, int n);
 
 struct DevBuf {
     double *p = nullptr;
@@ -238,6 +245,7 @@ struct sgpu_op {
     std::vector<int> sendRank, sendCount, sendDispl, recvRank, recvCount, recvDispl;
     int     halo_fp32 = 0;
     bool    injected = false;     // test hook: halo supplied by sgpu_debug_inject_halo
+    bool    local_only_ok = false; // test hook: sgpu_debug_allow_local_only
     std::vector<double> h_val;   // host copy of the values of small local parts (coarsest-level factorisation)
     unsigned *skip = nullptr;     // bitmask over the M rows: set = boundary row (has remote entries), written by k_csr_boundary
     int     bnd_lanes = 1;        // lanes per boundary row
@@ -337,23 +345,23 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
             epi == sk::EPI_SPMV ? sk::k_dense_rows<sk::EPI_SPMV> : epi == sk::EPI_RESIDUAL ? sk::k_dense_rows<sk::EPI_RESIDUAL>
             : epi == sk::EPI_JACOBI ? sk::k_dense_rows<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows<sk::EPI_CHEBY0>
             : epi == sk::EPI_CHEBYK ? sk::k_dense_rows<sk::EPI_CHEBYK> : sk::k_dense_rows<sk::EPI_SUB>;
-        hipLaunchKernelGGL(kd, dim3((P.nrows + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, (const double *)P.dense, P.nrows, P.ncols);
+        SGPU_LAUNCH(kd, dim3((P.nrows + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, (const double *)P.dense, P.nrows, P.ncols);
     } else if (P.variant == 3 || P.variant == 4) {                       // 16-bit compressed columns
         const int k = P.variant - 3;
         if (!P.cc_ok[k]) return fail(SGPU_ERR_STATE, "compressed columns of plan %d were not built", k);
         a.blk_row = k ? P.blk_row_big : P.blk_row;
         a.nblk = k ? P.nblk_big : P.nblk;
         a.segtab = P.segtab[k]; a.ccol = P.ccol[k];
-        hipLaunchKernelGGL(pick<1>(epi, P.lanes, k == 1, halo), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+        SGPU_LAUNCH(pick<1>(epi, P.lanes, k == 1, halo), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
     } else if (P.variant == 2) {                                  // vector CSR
         const int rpb = sk::BLOCK / P.lanes;
         a.blk_row = nullptr; a.nblk = 0;
-        hipLaunchKernelGGL(pick_vec(epi, P.lanes, halo), dim3((P.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
+        SGPU_LAUNCH(pick_vec(epi, P.lanes, halo), dim3((P.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
     } else {                                                      // 32-bit columns, 16 / 32 KiB tiles
         const bool big = P.variant == 1;
         a.blk_row = big ? P.blk_row_big : P.blk_row;
         a.nblk = big ? P.nblk_big : P.nblk;
-        hipLaunchKernelGGL(pick<0>(epi, P.lanes, big, halo), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+        SGPU_LAUNCH(pick<0>(epi, P.lanes, big, halo), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
     }
     HIPCHK(hipGetLastError());
     return SGPU_OK;
@@ -395,7 +403,7 @@ int launch_boundary(sgpu_op *op, int epi, const double *x, double *y, const EpiA
     b.h_ptr = op->rem.row_ptr; b.h_col = op->rem.col; b.h_val = op->rem.val;
     b.halo = op->recv_buf; b.halo_f = halo_is_f32 ? op->recv_f : nullptr;
     const int rpb = sk::BLOCK / op->bnd_lanes;
-    hipLaunchKernelGGL(pick_bnd(epi, op->bnd_lanes), dim3((b.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, stream, b);
+    SGPU_LAUNCH(pick_bnd(epi, op->bnd_lanes), dim3((b.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, stream, b);
     HIPCHK(hipGetLastError());
     return SGPU_OK;
 }
@@ -407,8 +415,8 @@ int apply_host_transport(sgpu_op *op, int epi, const double *x, double *y, const
     std::vector<char> hs((size_t)op->vIndexSize * eb), hr((size_t)op->recvSize * eb);
     if (op->vIndexSize) {
         const dim3 grid(std::min(sk::PACK_MAX_BLOCKS, (op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK));
-        if (f32) hipLaunchKernelGGL(sk::k_pack_f32, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_f, op->vIndexSize, (const uint64_t *)nullptr, (uint64_t)0);
-        else hipLaunchKernelGGL(sk::k_pack, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_buf, op->vIndexSize, 0, (const uint64_t *)nullptr, (uint64_t)0);
+        if (f32) SGPU_LAUNCH(sk::k_pack_f32, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_f, op->vIndexSize, (const uint64_t *)nullptr, (uint64_t)0);
+        else SGPU_LAUNCH(sk::k_pack, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_buf, op->vIndexSize, 0, (const uint64_t *)nullptr, (uint64_t)0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hs.data(), f32 ? (const void *)op->send_f : (const void *)op->send_buf, hs.size(), hipMemcpyDeviceToHost, g.cs));
     }
@@ -438,7 +446,13 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
             CHK(launch_part(op->loc, epi, x, y, e, op->skip));
             return launch_boundary(op, epi, x, y, e, false, g.cs);
         }
-        return launch_part(op->loc, epi, x, y, e);      // no communicator: the local part is the whole operator
+        // an operator with remote entries but no way to fetch them (no communicator, no host transport, no injected
+        // halo): the local part alone would be a silently wrong product (a binding that forgot the unique id, or a
+        // 1-rank context fed N-rank layouts).  sgpu_debug_allow_local_only lifts this for plan/launch tests.
+        if ((op->has_remote || op->recvSize) && !g.multi() && !op->local_only_ok)
+            return fail(SGPU_ERR_STATE, "operator has %d halo entries but this context has no communicator (sgpu_init was given nranks=%d, no unique id)",
+                        op->recvSize, g.nranks);
+        return launch_part(op->loc, epi, x, y, e);      // no halo: the local part is the whole operator
     }
     const bool f32 = op->halo_fp32 != 0;                 // both ends of a link must agree: the flag alone decides the wire type
     const uint64_t n = ++g.seq;
@@ -454,10 +468,12 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     // e.g. while it connects a new peer, always completes; and an error return leaves no stream waiting.)
     // The first exchange with a peer makes RCCL set up the connection inside ncclGroupEnd (allocations, IPC handles,
     // possibly device-wide synchronisation): that one runs in the plainest mode, events, with no polling kernel around.
+    // (tracked per DIRECTION: RCCL sets the send side and the receive side of a peer up separately, so an operator
+    // that only sends to r followed by one that only receives from r is two fresh connections)
     bool fresh_peer = false;
     if (g.peer_seen.size() != (size_t)g.nranks) g.peer_seen.assign((size_t)g.nranks, 0);
-    for (int r : op->sendRank) if (!g.peer_seen[(size_t)r]) { fresh_peer = true; g.peer_seen[(size_t)r] = 1; }
-    for (int r : op->recvRank) if (!g.peer_seen[(size_t)r]) { fresh_peer = true; g.peer_seen[(size_t)r] = 1; }
+    for (int r : op->sendRank) if (!(g.peer_seen[(size_t)r] & 1)) { fresh_peer = true; g.peer_seen[(size_t)r] |= 1; }
+    for (int r : op->recvRank) if (!(g.peer_seen[(size_t)r] & 2)) { fresh_peer = true; g.peer_seen[(size_t)r] |= 2; }
     const bool K = g.inkernel_sync && op->loc.nblk > 0 && !fresh_peer;
     const bool V = g.value_ops && !fresh_peer;
     if (K) {
@@ -470,7 +486,7 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     auto hs_chain = [&]() -> int {
         const bool pack_waits = K && op->vIndexSize > 0;
         if (K && !pack_waits) {
-            hipLaunchKernelGGL(sk::k_flag_wait, dim3(1), dim3(64), 0, g.hs, (const uint64_t *)g.kflag_x, n);
+            SGPU_LAUNCH(sk::k_flag_wait, dim3(1), dim3(64), 0, g.hs, (const uint64_t *)g.kflag_x, n);
             HIPCHK(hipGetLastError());
         } else if (!K) {
             if (V) HIPCHK(hipStreamWaitValue64(g.hs, g.flag_x, n, hipStreamWaitValueGte, ~0ull));
@@ -479,8 +495,8 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
         if (op->vIndexSize) {
             const dim3 grid(std::min(sk::PACK_MAX_BLOCKS, (op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK));
             const uint64_t *flag = pack_waits ? g.kflag_x : nullptr;
-            if (f32) hipLaunchKernelGGL(sk::k_pack_f32, grid, dim3(sk::BLOCK), 0, g.hs, x, op->vIndex, op->send_f, op->vIndexSize, flag, n);
-            else hipLaunchKernelGGL(sk::k_pack, grid, dim3(sk::BLOCK), 0, g.hs, x, op->vIndex, op->send_buf, op->vIndexSize, 0, flag, n);
+            if (f32) SGPU_LAUNCH(sk::k_pack_f32, grid, dim3(sk::BLOCK), 0, g.hs, x, op->vIndex, op->send_f, op->vIndexSize, flag, n);
+            else SGPU_LAUNCH(sk::k_pack, grid, dim3(sk::BLOCK), 0, g.hs, x, op->vIndex, op->send_buf, op->vIndexSize, 0, flag, n);
             HIPCHK(hipGetLastError());
         }
         NCCLCHK(ncclGroupStart());
@@ -493,6 +509,7 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
             else NCCLCHK(ncclRecv(op->recv_buf + op->recvDispl[i], (size_t)op->recvCount[i], ncclDouble, op->recvRank[i], g.comm, g.hs));
         }
         NCCLCHK(ncclGroupEnd());
+        ++g_launches;
         if (op->has_remote) CHK(launch_boundary(op, epi, x, y, e, f32, g.hs));
         return SGPU_OK;
     };
@@ -500,9 +517,9 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     CHK(st);
     // join: nothing later on cs may see y (or overwrite x and the send buffers) before hs is through
     if (K) {
-        hipLaunchKernelGGL(sk::k_flag_set, dim3(1), dim3(64), 0, g.hs, g.kflag_h, n);
+        SGPU_LAUNCH(sk::k_flag_set, dim3(1), dim3(64), 0, g.hs, g.kflag_h, n);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(sk::k_flag_wait, dim3(1), dim3(64), 0, g.cs, (const uint64_t *)g.kflag_h, n);
+        SGPU_LAUNCH(sk::k_flag_wait, dim3(1), dim3(64), 0, g.cs, (const uint64_t *)g.kflag_h, n);
         HIPCHK(hipGetLastError());
         return SGPU_OK;
     }
@@ -530,7 +547,7 @@ int grid_for(size_t n) { return (int)std::min<size_t>(2048, std::max<size_t>(1, 
 // iter Jacobi sweeps ping-ponging u <-> alt; *out = buffer holding the result.
 int zero_sweep(sgpu_op *op, int cheby, double c0, const double *rhs, double *y, double *d) {
     if (op->M == 0) return SGPU_OK;
-    hipLaunchKernelGGL(sk::k_zero_sweep, dim3(grid_for(2 * (size_t)op->M)), dim3(sk::BLOCK), 0, g.cs, cheby, c0, rhs, (const double *)op->inv_diag,
+    SGPU_LAUNCH(sk::k_zero_sweep, dim3(grid_for(2 * (size_t)op->M)), dim3(sk::BLOCK), 0, g.cs, cheby, c0, rhs, (const double *)op->inv_diag,
                        y, d, (size_t)op->M);
     HIPCHK(hipGetLastError());
     return SGPU_OK;
@@ -587,8 +604,8 @@ int cheby_pp(sgpu_op *op, int iter, double eig_max, double *u, double *alt, cons
 
 int dot_local_async(const double *x, const double *y, size_t n, double *dout) {
     const int nb = (int)std::min<size_t>(g.n_partials, std::max<size_t>(1, (n + sk::BLOCK - 1) / sk::BLOCK));
-    hipLaunchKernelGGL(sk::k_dot_partial, dim3(nb), dim3(sk::BLOCK), 0, g.cs, x, y, n, g.partials);
-    hipLaunchKernelGGL(sk::k_reduce_partials, dim3(1), dim3(sk::BLOCK), 0, g.cs, g.partials, nb, dout);
+    SGPU_LAUNCH(sk::k_dot_partial, dim3(nb), dim3(sk::BLOCK), 0, g.cs, x, y, n, g.partials);
+    SGPU_LAUNCH(sk::k_reduce_partials, dim3(1), dim3(sk::BLOCK), 0, g.cs, g.partials, nb, dout);
     HIPCHK(hipGetLastError());
     return SGPU_OK;
 }
@@ -611,8 +628,8 @@ int dot_nblocks(size_t n) { return (int)std::min<size_t>(g.n_partials, std::max<
 // u -= (S[ia]/S[ib]) p; r -= (S[ia]/S[ib]) h; S[iout] = global r.r of the new r; *host_out = the same (ONE host sync)
 int pcg_update_dev(int ia, int ib, const double *p, const double *h, double *u, double *r, size_t n, int iout, double *host_out) {
     const int nb = dot_nblocks(n);
-    hipLaunchKernelGGL(sk::k_pcg_update_dev, dim3(nb), dim3(sk::BLOCK), 0, g.cs, (const double *)g.dscalar, ia, ib, p, h, u, r, n, g.partials);
-    hipLaunchKernelGGL(sk::k_reduce_partials, dim3(1), dim3(sk::BLOCK), 0, g.cs, g.partials, nb, g.dscalar + iout);
+    SGPU_LAUNCH(sk::k_pcg_update_dev, dim3(nb), dim3(sk::BLOCK), 0, g.cs, (const double *)g.dscalar, ia, ib, p, h, u, r, n, g.partials);
+    SGPU_LAUNCH(sk::k_reduce_partials, dim3(1), dim3(sk::BLOCK), 0, g.cs, g.partials, nb, g.dscalar + iout);
     HIPCHK(hipGetLastError());
     if (g.comm) NCCLCHK(ncclAllReduce(g.dscalar + iout, g.dscalar + iout, 1, ncclDouble, ncclSum, g.comm, g.cs));
     HIPCHK(hipMemcpyAsync(g.hscalar + iout, g.dscalar + iout, sizeof(double), hipMemcpyDeviceToHost, g.cs));
@@ -626,12 +643,25 @@ int pcg_update_dev(int ia, int ib, const double *p, const double *h, double *u, 
     return SGPU_OK;
 }
 int pcg_direction_dev(int ia, int ib, const double *z, double *p, size_t n) {
-    hipLaunchKernelGGL(sk::k_pcg_direction_dev, dim3(grid_for(2 * n)), dim3(sk::BLOCK), 0, g.cs, (const double *)g.dscalar, ia, ib, z, p, n);
+    SGPU_LAUNCH(sk::k_pcg_direction_dev, dim3(grid_for(2 * n)), dim3(sk::BLOCK), 0, g.cs, (const double *)g.dscalar, ia, ib, z, p, n);
     HIPCHK(hipGetLastError());
     return SGPU_OK;
 }
 
 const double JACOBI_OMEGA_REF = (double)(float)(2.0 / 3);   // saena_matrix.h:182
+
+int global_sum(double *v, int n) {
+    if (n > 8) return fail(SGPU_ERR_ARG, "global_sum: at most 8 values");
+    if (g.xchg) return host_allreduce(v, n);
+    if (g.comm) {
+        HIPCHK(hipMemcpyAsync(g.dscalar + 8, v, n * sizeof(double), hipMemcpyHostToDevice, g.cs));
+        NCCLCHK(ncclAllReduce(g.dscalar + 8, g.dscalar + 8, (size_t)n, ncclDouble, ncclSum, g.comm, g.cs));
+        HIPCHK(hipMemcpyAsync(g.hscalar + 8, g.dscalar + 8, n * sizeof(double), hipMemcpyDeviceToHost, g.cs));
+        HIPCHK(hipStreamSynchronize(g.cs));
+        for (int i = 0; i < n; ++i) v[i] = g.hscalar[8 + i];
+    }
+    return SGPU_OK;
+}
 
 } // namespace
 
@@ -768,7 +798,7 @@ int sgpu_vec_download(value_t *host, const value_t *dev, size_t n) {
 int sgpu_vec_fill(value_t *dev, value_t a, size_t n) {
     CHK(need_ctx());
     if (n == 0) return SGPU_OK;
-    hipLaunchKernelGGL(sk::k_fill, dim3(grid_for(n)), dim3(sk::BLOCK), 0, g.cs, dev, a, n);
+    SGPU_LAUNCH(sk::k_fill, dim3(grid_for(n)), dim3(sk::BLOCK), 0, g.cs, dev, a, n);
     HIPCHK(hipGetLastError());
     return SGPU_OK;
 }
@@ -780,7 +810,7 @@ int sgpu_vec_copy(value_t *dst, const value_t *src, size_t n) {
 int sgpu_vec_axpby(value_t a, const value_t *x, value_t b, value_t *y, size_t n) {
     CHK(need_ctx());
     if (n == 0) return SGPU_OK;
-    hipLaunchKernelGGL(sk::k_axpby, dim3(grid_for(n)), dim3(sk::BLOCK), 0, g.cs, a, x, b, y, n);
+    SGPU_LAUNCH(sk::k_axpby, dim3(grid_for(n)), dim3(sk::BLOCK), 0, g.cs, a, x, b, y, n);
     HIPCHK(hipGetLastError());
     return SGPU_OK;
 }
@@ -930,6 +960,7 @@ int sgpu_op_info(const sgpu_op *op, index_t *M, index_t *N_local, nnz_t *nnz_loc
 
 int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
+    ++g_plan_generation;                                 // captured V-cycle graphs that launch this operator are stale now
     if (lanes == 0) { op->loc.lanes = auto_lanes(op->loc.nrows, op->loc.nblk); return SGPU_OK; }
     if (lanes < 1 || lanes > 64 || (lanes & (lanes - 1))) return fail(SGPU_ERR_ARG, "lanes_per_row must be a power of two in [1,64]");
     op->loc.lanes = lanes;
@@ -955,6 +986,7 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
         if (!op->loc.cc_ok[variant - 3]) return fail(SGPU_ERR_ARG, "this operator's blocks touch more than 16 column segments (or hold a long row)");
     }
     op->loc.variant = variant;
+    ++g_plan_generation;
     return SGPU_OK;
 }
 
@@ -982,8 +1014,13 @@ int sgpu_op_autotune(sgpu_op *op) {
     // lists (a rank's blocks may be too scattered for 16-bit columns), so no collective may run in here.
     EpiArgs e; e.rhs = r.p; e.inv_diag = op->inv_diag; e.u = x.p; e.c0 = JACOBI_OMEGA_REF;
     const int epi = kind == 1 ? sk::EPI_JACOBI : sk::EPI_SPMV;
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    ++g_plan_generation;                                 // frees/replaces buffers captured graphs may reference
+    struct Guard {                                       // an error return inside the sweep leaves the operator as it was
+        sgpu_op *op; int v, l; hipEvent_t e0 = nullptr, e1 = nullptr; bool armed = true;
+        ~Guard() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); if (armed) { op->loc.variant = v; op->loc.lanes = l; } }
+    } guard{op, op->loc.variant, op->loc.lanes};
+    HIPCHK(hipEventCreate(&guard.e0)); HIPCHK(hipEventCreate(&guard.e1));
+    const hipEvent_t e0 = guard.e0, e1 = guard.e1;
     for (int round = 0; round < 2; ++round)
         for (int v : variants)
             for (int gl : lanes) {
@@ -998,7 +1035,7 @@ int sgpu_op_autotune(sgpu_op *op) {
                 ms /= reps;
                 if (round == 1 && ms < best) { best = ms; bv = v; bg = gl; }
             }
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    guard.armed = false;
     op->loc.variant = bv; op->loc.lanes = bg;
     if (bv != 5 && op->loc.dense) { hipFree(op->loc.dense); op->loc.dense = nullptr; }
     for (int k = 0; k < 2; ++k)                       // free the compressed arrays of the plans that lost
@@ -1054,7 +1091,7 @@ int sgpu_debug_pack(sgpu_op *op, const value_t *v, value_t *send_host) {
     CHK(need_ctx());
     if (!op || !v) return fail(SGPU_ERR_ARG, "null argument");
     if (op->vIndexSize == 0) return SGPU_OK;
-    hipLaunchKernelGGL(sk::k_pack, dim3((op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
+    SGPU_LAUNCH(sk::k_pack, dim3((op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs,
                        v, op->vIndex, op->send_buf, op->vIndexSize, op->halo_fp32, (const uint64_t *)nullptr, (uint64_t)0);
     HIPCHK(hipGetLastError());
     return sgpu_vec_download(send_host, op->send_buf, (size_t)op->vIndexSize);
@@ -1069,7 +1106,7 @@ int sgpu_debug_gather_probe(sgpu_op *op, int mode, const value_t *x, int reps, f
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, g.cs));
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(sk::k_gather_probe, dim3(grid), dim3(sk::BLOCK), 0, g.cs, op->loc.col, x, g.dscalar, nnz, mode);
+        SGPU_LAUNCH(sk::k_gather_probe, dim3(grid), dim3(sk::BLOCK), 0, g.cs, op->loc.col, x, g.dscalar, nnz, mode);
     HIPCHK(hipEventRecord(e1, g.cs));
     HIPCHK(hipEventSynchronize(e1));
     HIPCHK(hipEventElapsedTime(ms, e0, e1));
@@ -1140,10 +1177,16 @@ struct sgpu_amg {
         for (auto p_ : rhs) hipFree(p_);
         for (auto p_ : u) hipFree(p_);
         for (auto p_ : alt) hipFree(p_);
-        for (auto &c : graphs) { hipGraphExecDestroy(c.exec); hipGraphDestroy(c.graph); }
+        drop_graphs();
         hipFree(Ainv); hipFree(alt0); hipFree(r); hipFree(rho); hipFree(hh); hipFree(p);
     }
     std::vector<Captured> graphs;
+    uint64_t graph_gen = 0;            // g_plan_generation the graphs were captured under
+    bool coarse_host_driven = false;   // coarsest level too large for the LDS-resident solvers: host-driven CG, no graph capture
+    void drop_graphs() {
+        for (auto &c : graphs) { hipGraphExecDestroy(c.exec); hipGraphDestroy(c.graph); }
+        graphs.clear();
+    }
 };
 
 namespace {
@@ -1154,7 +1197,7 @@ int coarse_cg_single(sgpu_amg *h, sgpu_op *A, double *u, const double *rhs, int 
     a.row_ptr = A->loc.row_ptr; a.col = A->loc.col; a.val = A->loc.val; a.n = A->M;
     a.rhs = rhs; a.u = u; a.max_iter = h->prm.CG_coarsest_max_iter; a.tol = h->prm.CG_coarsest_tol;
     a.iters_out = iters ? g.dint + 1 : nullptr;
-    hipLaunchKernelGGL(sk::k_coarse_cg, dim3(1), dim3(sk::CG_BLOCK), 0, g.cs, a);
+    SGPU_LAUNCH(sk::k_coarse_cg, dim3(1), dim3(sk::CG_BLOCK), 0, g.cs, a);
     HIPCHK(hipGetLastError());
     if (iters) {
         HIPCHK(hipMemcpyAsync(g.hint + 1, g.dint + 1, sizeof(int), hipMemcpyDeviceToHost, g.cs));
@@ -1201,15 +1244,17 @@ int coarse_cg_dist(sgpu_amg *h, sgpu_op *A, double *u, const double *rhs, int *i
 int coarse_solve(sgpu_amg *h, double *u, const double *rhs, int *iters) {
     sgpu_op *A = h->A[h->nlevels - 1];
     if (h->Ainv) {
-        hipLaunchKernelGGL(sk::k_dense_solve, dim3(1), dim3(sk::CG_BLOCK), 0, g.cs, h->Ainv, rhs, u, (int)A->M);
+        SGPU_LAUNCH(sk::k_dense_solve, dim3(1), dim3(sk::CG_BLOCK), 0, g.cs, h->Ainv, rhs, u, (int)A->M);
         HIPCHK(hipGetLastError());
         if (iters) *iters = 0;
         return SGPU_OK;
     }
-    if (h->coarse_local) {
+    if (h->coarse_local && !h->coarse_host_driven) {
         if (A->M == 0) { if (iters) *iters = 0; return SGPU_OK; }      // this rank holds no coarsest rows
         return coarse_cg_single(h, A, u, rhs, iters);
     }
+    // row-partitioned coarsest operator, or one with more than CG_MAXN rows (coarsening stalled, max_level cut-off):
+    // the reference's CG has no size limit (saena_object_solve.cpp:14-114) -- host-driven loop over the device kernels
     return coarse_cg_dist(h, A, u, rhs, iters);
 }
 
@@ -1266,9 +1311,14 @@ int vcycle0_eager(sgpu_amg *h, double *u, const double *rhs, bool u_zero) {
 
 // u_zero: the caller guarantees a zero iterate WITHOUT having written it (see vcycle_level)
 int vcycle0(sgpu_amg *h, double *u, const double *rhs, bool u_zero = false) {
-    if (!h->prm.use_graph || g.multi()) return vcycle0_eager(h, u, rhs, u_zero);
+    if (!h->prm.use_graph || g.multi() || h->coarse_host_driven) return vcycle0_eager(h, u, rhs, u_zero);
+    if (!h->graphs.empty() && h->graph_gen != g_plan_generation) {   // an operator was retuned since the capture: the graphs
+        HIPCHK(hipStreamSynchronize(g.cs));                           // may launch kernels on freed plan buffers
+        h->drop_graphs();
+    }
+    h->graph_gen = g_plan_generation;
     for (auto &c : h->graphs)
-        if (c.u == u && c.rhs == rhs && c.u_zero == u_zero) { HIPCHK(hipGraphLaunch(c.exec, g.cs)); return SGPU_OK; }
+        if (c.u == u && c.rhs == rhs && c.u_zero == u_zero) { ++g_launches; HIPCHK(hipGraphLaunch(c.exec, g.cs)); return SGPU_OK; }
     sgpu_amg::Captured c{u, rhs, u_zero, nullptr, nullptr};
     HIPCHK(hipStreamBeginCapture(g.cs, hipStreamCaptureModeThreadLocal));
     const int st = vcycle0_eager(h, u, rhs, u_zero);
@@ -1281,7 +1331,7 @@ int vcycle0(sgpu_amg *h, double *u, const double *rhs, bool u_zero = false) {
         h->graphs.erase(h->graphs.begin());
     }
     h->graphs.push_back(c);
-    HIPCHK(hipGraphLaunch(c.exec, g.cs));
+    ++g_launches; HIPCHK(hipGraphLaunch(c.exec, g.cs));
     return SGPU_OK;
 }
 
@@ -1329,27 +1379,20 @@ int sgpu_amg_create(int nlevels, sgpu_op *const *A, sgpu_op *const *P, sgpu_op *
     // direct coarsest solve: one rank, or a coarsest level that lives whole on one rank (no halo on any rank:
     // the setup shrinks small levels onto rank 0, ranks holding zero rows have nothing to solve)
     bool coarse_local = !g.multi();
-    if (g.xchg) {
+    bool coarse_big = A[nlevels - 1]->M > sk::CG_MAXN;   // more rows than the LDS-resident solvers hold (on any rank)
+    if (g.multi()) {
         sgpu_op *Ac = A[nlevels - 1];
-        double has_halo = (Ac->vIndexSize || Ac->recvSize) ? 1.0 : 0.0;
-        CHK(host_allreduce(&has_halo, 1));
-        coarse_local = has_halo == 0.0;
-    }
-    if (g.comm) {
-        sgpu_op *Ac = A[nlevels - 1];
-        int has_halo = (Ac->vIndexSize || Ac->recvSize) ? 1 : 0;
-        HIPCHK(hipMemcpyAsync(g.dint, &has_halo, sizeof(int), hipMemcpyHostToDevice, g.cs));
-        NCCLCHK(ncclAllReduce(g.dint, g.dint, 1, ncclInt, ncclSum, g.comm, g.cs));
-        HIPCHK(hipMemcpyAsync(g.hint, g.dint, sizeof(int), hipMemcpyDeviceToHost, g.cs));
-        HIPCHK(hipStreamSynchronize(g.cs));
-        coarse_local = g.hint[0] == 0;
+        double flags[2] = {(Ac->vIndexSize || Ac->recvSize) ? 1.0 : 0.0, coarse_big ? 1.0 : 0.0};
+        CHK(global_sum(flags, 2));
+        coarse_local = flags[0] == 0.0;
+        coarse_big = flags[1] != 0.0;
     }
     h->coarse_local = coarse_local;
-    if (h->prm.coarse_solver == 1 && coarse_local && A[nlevels - 1]->M > 0) {
+    h->coarse_host_driven = coarse_local && coarse_big;   // the same on every rank: the host-driven CG is collective
+    if (h->prm.coarse_solver == 1 && coarse_local && A[nlevels - 1]->M > 0 && !h->coarse_host_driven) {
         // dense inverse by Gauss-Jordan with partial pivoting (host, once)
         sgpu_op *Ac = A[nlevels - 1];
         const int n = Ac->M;
-        if (n > sk::CG_MAXN || (n > 0 && Ac->h_val.empty())) return fail(SGPU_ERR_ARG, "coarsest level too large for the dense direct solve (%d rows)", n);
         std::vector<double> a((size_t)n * n, 0.0), inv((size_t)n * n, 0.0);
         for (int i = 0; i < n; ++i) {
             inv[(size_t)i * n + i] = 1.0;
@@ -1399,8 +1442,7 @@ int sgpu_amg_set_solve_params(sgpu_amg *h, int solver_max_iter, double solver_to
         }
     if (smoother != h->prm.smoother || preSmooth != h->prm.preSmooth || postSmooth != h->prm.postSmooth) {
         HIPCHK(hipStreamSynchronize(g.cs));
-        for (auto &c : h->graphs) { hipGraphExecDestroy(c.exec); hipGraphDestroy(c.graph); }
-        h->graphs.clear();
+        h->drop_graphs();
     }
     h->prm.solver_max_iter = solver_max_iter; h->prm.solver_tol = solver_tol;
     h->prm.smoother = smoother; h->prm.preSmooth = preSmooth; h->prm.postSmooth = postSmooth;
@@ -1570,12 +1612,18 @@ int sgpu_solve_CG(sgpu_amg *h, value_t *u, const value_t *rhs, int *iters, value
 // ---- bench.py safety net ----
 static char  g_fatal_line[1 << 16];
 static size_t g_fatal_len = 0;
-static void fatal_handler(int) {
+static void fatal_handler(int sig) {
     if (g_fatal_len) { ssize_t r = write(1, g_fatal_line, g_fatal_len); (void)r; }
-    _exit(0);
+    char msg[64] = "libsaena_amd: fatal signal ";          // async-signal-safe: no stdio
+    size_t n = strlen(msg);
+    if (sig >= 10) msg[n++] = (char)('0' + sig / 10);
+    msg[n++] = (char)('0' + sig % 10);
+    msg[n++] = '\n';
+    ssize_t r = write(2, msg, n); (void)r;
+    _exit(128 + sig);                                     // the failure stays a failure for the launcher
 }
 int sgpu_debug_on_fatal_print(const char *line) {
-    const int sigs[] = {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL, SIGTERM};
+    const int sigs[] = {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL};   // not SIGTERM: being told to stop is not a measured run
     if (!line) {
         for (int sg : sigs) signal(sg, SIG_DFL);
         g_fatal_len = 0;
@@ -1591,6 +1639,18 @@ int sgpu_debug_on_fatal_print(const char *line) {
     sa.sa_handler = fatal_handler;
     sigemptyset(&sa.sa_mask);
     for (int sg : sigs) sigaction(sg, &sa, nullptr);
+    return SGPU_OK;
+}
+
+int sgpu_debug_launch_count(long *launches) {
+    if (!launches) return fail(SGPU_ERR_ARG, "null argument");
+    *launches = g_launches;
+    return SGPU_OK;
+}
+
+int sgpu_debug_allow_local_only(sgpu_op *op, int allow) {
+    if (!op) return fail(SGPU_ERR_ARG, "null op");
+    op->local_only_ok = allow != 0;
     return SGPU_OK;
 }
 

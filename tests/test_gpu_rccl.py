@@ -26,22 +26,55 @@ def test_rccl_loopback(torch_first, mode):
     assert out.returncode == 0 and "RCCL_LOOPBACK_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
-def test_bench_two_ranks_rehearsal():
-    """`bench.py --gpus 2` exactly as the driver launches it, with both ranks on this one card: SAENA_BENCH_NO_RCCL=1
-    routes halos through the host transport (RCCL refuses two ranks per device).  stdout must be ONE JSON line whose
-    SpMV self-check -- halo values included -- passes."""
-    import json
+def _bench_rehearsal(nproc, extra, timeout=900):
+    """`bench.py --gpus N` exactly as the driver launches it, with all ranks on this one card: SAENA_BENCH_NO_RCCL=1
+    routes halos through the host transport (RCCL refuses two ranks per device)."""
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SAENA_BENCH_NO_RCCL="1", SAENA_BENCH_DEVICE="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "10", "--warmup", "2", "--no-vcycle"]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", str(nproc), "--steps", "10", "--warmup", "2"] + extra
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_two_ranks_rehearsal():
+    """stdout must be ONE JSON line whose SpMV self-check -- halo values included -- passes; the workload is the
+    N/8 share of the m^3 problem under the reference partitioner (configs[3] at m = 512, N = 8; m = 128 here)."""
+    import json
+    out = _bench_rehearsal(2, ["--m", "128", "--no-vcycle"])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout[-3000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rows_per_gpu"] == 2000376
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert sum(d["config"]["rows_per_gpu"]) == 126 * 126 * 32 and "128x128x34" in d["metric"]      # round(126 * 2 / 8) = 32 planes
     assert d["check"]["ok"] is True, d["check"]
+    assert d["roofline"]["traffic_measured_in_run"] in (None, False) and "working_set_bytes" in d["roofline"]
+
+
+def test_bench_four_ranks_rehearsal_with_vcycle_legs():
+    """the whole --gpus 4 run (both V-cycle legs over the row-distributed hierarchies) through the host transport:
+    exit status 0, the 128^3 strong leg reproduces the reference's printed line"""
+    import json
+    out = _bench_rehearsal(4, ["--m", "64"], timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert "vcycle_error" not in d
+    v = d["vcycle"]
+    assert v["pcg_iterations"] >= 1 and v["relative_residual"] <= 1e-8
+    assert d["vcycle_config4"]["relative_residual"] <= 1e-8 and d["check"]["ok"] is True
+
+
+def test_bench_failure_in_a_multi_rank_leg_is_a_failing_exit_status():
+    """a watchdog expiry in the V-cycle legs still prints the measured SpMV line (with vcycle_error) but the run ENDS
+    NON-ZERO: a fault or hang in the first real multi-GPU run must reach the driver as a failure"""
+    import json
+    out = _bench_rehearsal(2, ["--m", "64", "--vcycle-timeout", "0.05"])
+    assert out.returncode != 0, out.stdout[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert "did not finish" in d["vcycle_error"] and d["check"]["ok"] is True and d["value"] > 0
+    assert "bench.py rank" in out.stderr

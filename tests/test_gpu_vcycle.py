@@ -374,6 +374,14 @@ def _dist_gpu_worker(rank, world, port, ret):
         S = host.AmgSolver(A, host.options(L, **host.OPTIONS001)).to_device()
         splits = [S.level_split(l) for l in range(S.num_levels)]
         assert any(s[rank + 1] == s[rank] for s in splits[1:]) or rank == 0, "some level should be empty on ranks > 0"
+        # no communicator in this context: applying an operator that has halo entries is an error (SGPU_ERR_STATE) ...
+        with pytest.raises(Exception, match="no communicator"):
+            S.solve_pCG(np.ones(A.num_local_rows))
+        # ... unless the test opts in, operator by operator, to local-only applies
+        for l in range(S.num_levels):
+            for which in (0, 1, 2):
+                if which == 0 or l < S.num_levels - 1:
+                    S.device_op(l, which).debug_allow_local_only()
         u, it, hist, ok = S.solve_pCG(np.ones(A.num_local_rows))
         assert np.all(np.isfinite(u)) and it >= 1
         ret[rank] = "ok"
@@ -387,8 +395,9 @@ def _dist_gpu_worker(rank, world, port, ret):
 def test_distributed_hierarchy_reaches_the_device():
     """The product flow of one rank of a 3-rank run -- row-distributed setup over gloo, saena_amg_to_device
     (sgpu_op_create with 3-rank halo plans, levels this rank owns no rows of, sgpu_amg_create), solve_pCG -- in a
-    1-rank GPU context per process.  Without a communicator only the local parts are applied, so the numbers mean
-    nothing; the point is that every call on real distributed layouts succeeds (RCCL refuses 3 ranks on one card)."""
+    1-rank GPU context per process.  Without a communicator such operators refuse to run; with the explicit debug
+    opt-in (sgpu_debug_allow_local_only) only the local parts are applied, so the numbers mean nothing; the point is
+    that every call on real distributed layouts succeeds (RCCL refuses 3 ranks on one card)."""
     # the standard library's multiprocessing, NOT torch's: importing torch here would load its bundled HIP runtime
     # next to the system one this process already initialised (two runtimes in one process abort at exit); the
     # children import torch first, like `bench.py --gpus N`

@@ -168,6 +168,8 @@ def test_abi_symbols_present():
     L = capi.lib()
     strip = lambda t: re.sub(r"/\*.*?\*/", "", t, flags=re.S)
     hdr = strip(open(os.path.join(ROOT, "include", "saena_gpu.h")).read())
+    assert "sgpu_debug" not in hdr, "test scaffolding belongs in include/saena_gpu_debug.h, not in the boundary header"
+    hdr += strip(open(os.path.join(ROOT, "include", "saena_gpu_debug.h")).read())
     declared = set(re.findall(r"\b(sgpu_[a-z_A-Z0-9]+)\s*\(", hdr))
     assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
     for name in declared:
@@ -196,17 +198,22 @@ def test_gpu_path_fails_loudly_without_device():
     assert "LOUD" in out.stdout or "INIT_OK" in out.stdout, out.stdout + out.stderr
 
 
-def test_fatal_signal_prints_the_measured_line():
-    """sgpu_debug_on_fatal_print (bench.py's safety net for its optional multi-rank leg): a fatal signal writes the
-    registered line to stdout and ends the process with status 0 (no GPU needed: no compute call is made)"""
+def test_fatal_signal_prints_the_measured_line_and_fails():
+    """sgpu_debug_on_fatal_print (bench.py's safety net for its optional multi-rank legs): a fatal signal writes the
+    registered line to stdout, a reason to stderr, and ends the process with status 128 + signal -- the failure must
+    reach the launcher as a failure (no GPU needed: no compute call is made).  SIGTERM is not trapped."""
+    import signal
     import subprocess
     code = ("import os, signal\n"
             "from saena_amd import capi\n"
             "capi.lib().sgpu_debug_on_fatal_print(b'{\"metric\": \"x\"}')\n"
-            "os.kill(os.getpid(), signal.SIGABRT)\n"
+            "os.kill(os.getpid(), signal.%s)\n"
             "print('not reached')\n")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
-    assert out.returncode == 0 and out.stdout == '{"metric": "x"}\n', (out.returncode, out.stdout, out.stderr[-500:])
+    out = subprocess.run([sys.executable, "-c", code % "SIGABRT"], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 128 + signal.SIGABRT and out.stdout == '{"metric": "x"}\n', (out.returncode, out.stdout, out.stderr[-500:])
+    assert "fatal signal 6" in out.stderr
+    out = subprocess.run([sys.executable, "-c", code % "SIGTERM"], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == -signal.SIGTERM and out.stdout == "", (out.returncode, out.stdout)
 
 
 def test_write_matrix_to_file_roundtrip(tmp_path):
