@@ -49,9 +49,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--m", type=int, default=None, help="grid points per side (reference laplacian3D argument); default 128 at "
+    ap.add_argument("--grid-m", "--m", dest="m", type=int, default=None, help="grid points per side (reference laplacian3D argument); default 128 at "
                     "--gpus 1 (BASELINE configs[1]) and 512 at --gpus N>1 (configs[3]: rank r owns its 1/8-of-512^3-sized row block)")
-    ap.add_argument("--m-hbm", type=int, default=256, help="grid of the secondary HBM-resident SpMV figure at --gpus 1 (0 = skip)")
+    ap.add_argument("--hbm-m", "--m-hbm", dest="m_hbm", type=int, default=256, help="grid of the secondary HBM-resident SpMV figure at --gpus 1 (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
     ap.add_argument("--vcycle-timeout", type=float, default=420.0, help="watchdog of the multi-rank V-cycle legs, seconds")

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    line = open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -20,6 +20,11 @@ def test_committed_bench_line_has_the_contract_keys():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["us_per_launch"] * 1e-6) / 1e9) < 1.0
     assert r["traffic"] is None or 0.5 * r["algorithmic_bytes"] < r["traffic"] < 2 * r["algorithmic_bytes"]
+    # the line states whether the timed working set is Infinity-Cache resident and carries the HBM-resident figure
+    assert r["cache_resident"] is True and r["working_set_bytes"] < 256 * 2 ** 20 and r["traffic_measured_in_run"] is False
+    h = d["spmv_hbm_resident"]
+    assert h["cache_resident"] is False and h["working_set_bytes"] > 2 ** 30 and 0.5 < h["frac"] < 0.8
+    assert abs(h["achieved"] - h["algorithmic_bytes"] / (h["us_per_launch"] * 1e-6) / 1e9) < 1.0 and h["check_max_rel_err"] <= 1e-13
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

@@ -55,11 +55,15 @@ def test_config1_poisson128_operators_against_reference_norm_pins(capi):
     u = capi.DeviceVector(M, np.zeros(M))
     op.jacobi(3, u, rhs)
     uj = u.download()
-    assert abs(np.dot(uj, uj) - pin["jacobi3_sq"]) <= 1e-12 * pin["jacobi3_sq"]
+    # the pin is the reference's own (reassociated, -Ofast) sum of 2e6 squares: it differs by 1.5e-11 between the reference's
+    # 1- and 8-rank runs (ref_norm_pins.json), so 1e-10 is the resolution of this pin (tests/test_oracle_pins.py uses the same)
+    assert abs(np.dot(uj, uj) - pin["jacobi3_sq"]) <= 1e-10 * pin["jacobi3_sq"]
     u.upload(np.zeros(M))
     op.chebyshev(3, 2.0, u, rhs)
     uc = u.download()
-    assert abs(np.dot(uc, uc) - pin["cheby3_sq"]) <= 1e-12 * pin["cheby3_sq"]
+    # element-wise, at 1e-12: the oracle's restatement of the same three sweeps is pinned to the reference's VECTORS at
+    # small sizes (tests/test_oracle_pins.py) and the GPU sweeps are bit-exact against it there (tests/test_gpu_parity.py)
+    assert abs(np.dot(uc, uc) - pin["cheby3_sq"]) <= 1e-10 * pin["cheby3_sq"]
     # the autotuned production kernel (more lanes per row, 16-bit columns) agrees to rounding
     op.autotune()
     op.spmv(x, y)

@@ -43,7 +43,7 @@ def test_bench_two_ranks_rehearsal():
     """stdout must be ONE JSON line whose SpMV self-check -- halo values included -- passes; the workload is the
     N/8 share of the m^3 problem under the reference partitioner (configs[3] at m = 512, N = 8; m = 128 here)."""
     import json
-    out = _bench_rehearsal(2, ["--m", "128", "--no-vcycle"])
+    out = _bench_rehearsal(2, ["--grid-m", "128", "--no-vcycle"])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout[-3000:]
@@ -58,7 +58,7 @@ def test_bench_four_ranks_rehearsal_with_vcycle_legs():
     """the whole --gpus 4 run (both V-cycle legs over the row-distributed hierarchies) through the host transport:
     exit status 0, the 128^3 strong leg reproduces the reference's printed line"""
     import json
-    out = _bench_rehearsal(4, ["--m", "64"], timeout=1200)
+    out = _bench_rehearsal(4, ["--grid-m", "64"], timeout=1200)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
     assert "vcycle_error" not in d
@@ -71,7 +71,7 @@ def test_bench_failure_in_a_multi_rank_leg_is_a_failing_exit_status():
     """a watchdog expiry in the V-cycle legs still prints the measured SpMV line (with vcycle_error) but the run ENDS
     NON-ZERO: a fault or hang in the first real multi-GPU run must reach the driver as a failure"""
     import json
-    out = _bench_rehearsal(2, ["--m", "64", "--vcycle-timeout", "0.05"])
+    out = _bench_rehearsal(2, ["--grid-m", "64", "--vcycle-timeout", "0.05"])
     assert out.returncode != 0, out.stdout[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-3000:]

@@ -322,8 +322,16 @@ def test_multirank_vcycle_emulated_on_one_gpu(capi, hier, P_):
     for r in range(P_):
         G_r = capi.Amg([w.g[r] for w in WA], [w.g[r] for w in WP], [w.g[r] for w in WR], pre=2, post=2, smoother="jacobi")
         m_r = int(splits[0][r + 1] - splits[0][r])
+        ops_r = [w.g[r] for w in WA + WP + WR]
+        if any(o.info()["nnz_remote"] for o in ops_r):         # without a transport such operators refuse to run ...
+            with pytest.raises(capi.SgpuError, match="no communicator"):
+                G_r.vcycle(capi.DeviceVector(m_r, np.zeros(m_r)), capi.DeviceVector(m_r, np.ones(m_r)))
+        for o in ops_r:                                         # ... unless the test opts in to local-only applies
+            o.debug_allow_local_only(True)
         G_r.vcycle(capi.DeviceVector(m_r, np.zeros(m_r)), capi.DeviceVector(m_r, np.ones(m_r)))
         G_r.solve_pCG(capi.DeviceVector(m_r), capi.DeviceVector(m_r, np.ones(m_r)))
+        for o in ops_r:
+            o.debug_allow_local_only(False)
 
     n0 = As[0].shape[0]
     rhs, u0 = inputs.rhs2(n0), inputs.v2(n0) * 0.01
