@@ -58,10 +58,12 @@ struct SpmvArgs {
     double        c1;        // d1
     int           nblk;
     const unsigned *skip;    // bitmask of rows this launch must NOT write (boundary rows, owned by k_csr_boundary), or nullptr
-    // 16-bit compressed columns (k_csr_cc16): per block 16 segment bases (multiples of 4096), per nnz
-    // (segment slot << 12) | (column & 4095)
-    const int            *segtab;   // [nblk*16]
+    // 16-bit compressed columns (k_csr_cc16): per block a table of segment bases (multiples of 2^cc_ob), per nnz
+    // (segment slot << cc_ob) | (column & (2^cc_ob - 1)); cc_ob in {12,...,8} = 16 ... 256 table slots per block
+    const int            *segtab;   // bases of all blocks, block b owns [segptr[b], segptr[b+1])
+    const int            *segptr;   // [nblk+1]
     const unsigned short *ccol;     // [nnz] (padded)
+    int                   cc_ob;    // offset bits
     // in-kernel fork to the halo stream (multi-rank interior launch only, else nullptr): block 0 stores
     // *flag_x = seq when it starts -- stream order: everything earlier on the compute stream is complete, so
     // the halo stream's pack, which polls the flag, may read x.
@@ -118,6 +120,41 @@ __device__ __forceinline__ void epilogue(const SpmvArgs &a, int r, double s) {
     } else if constexpr (EPI == EPI_SUB) {
         a.y[r] = a.y[r] - s;
     }
+}
+
+// ---- stream loads.  val / col are read exactly once per launch; the x[col] gathers next to them live on reuse in the
+// CU's 32 KiB vector L1.  Tried (SAENA_STREAM_NT=1): non-temporal (`nt`) stream loads, so that the tiles of stream
+// data would not sweep the x lines out of L1.  Measured on the 256^3 hierarchy (profiles/r02_perf_levels_256_nt.log):
+// every level got SLOWER (L0 335 -> 381 us, L1 1327 -> 1534 us, L2 629 -> 678 us), so plain loads stay the default.
+typedef double   sk_d2v __attribute__((ext_vector_type(2)));
+typedef int      sk_i4v __attribute__((ext_vector_type(4)));
+typedef unsigned sk_u2v __attribute__((ext_vector_type(2)));
+#ifndef SAENA_STREAM_NT
+#define SAENA_STREAM_NT 0
+#endif
+__device__ __forceinline__ double2 ld_stream_d2(const double *p) {
+#if SAENA_STREAM_NT
+    const sk_d2v v = __builtin_nontemporal_load(reinterpret_cast<const sk_d2v *>(p));
+    double2 r; r.x = v.x; r.y = v.y; return r;
+#else
+    return *reinterpret_cast<const double2 *>(p);
+#endif
+}
+__device__ __forceinline__ int4 ld_stream_i4(const int *p) {
+#if SAENA_STREAM_NT
+    const sk_i4v v = __builtin_nontemporal_load(reinterpret_cast<const sk_i4v *>(p));
+    int4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
+#else
+    return *reinterpret_cast<const int4 *>(p);
+#endif
+}
+__device__ __forceinline__ uint2 ld_stream_u2(const unsigned short *p) {
+#if SAENA_STREAM_NT
+    const sk_u2v v = __builtin_nontemporal_load(reinterpret_cast<const sk_u2v *>(p));
+    uint2 r; r.x = v.x; r.y = v.y; return r;
+#else
+    return *reinterpret_cast<const uint2 *>(p);
+#endif
 }
 
 // contiguous chunk of the grid per XCD (blocks b, b+8, ... share an XCD)
@@ -188,9 +225,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
             const int q = tid + it * BLOCK;
             if (q < nq) {
                 const int idx = a0 + 4 * q;
-                const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
-                const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
-                const int4    c   = *reinterpret_cast<const int4 *>(a.col + idx);
+                const double2 v01 = ld_stream_d2(a.val + idx);
+                const double2 v23 = ld_stream_d2(a.val + idx + 2);
+                const int4    c   = ld_stream_i4(a.col + idx);
                 double2 o01, o23;
                 o01.x = v01.x * a.x[c.x];
                 o01.y = v01.y * a.x[c.y];
@@ -212,9 +249,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
             int q = tid + it * BLOCK;
             q = q < qlast ? q : qlast;
             const int idx = a0 + 4 * q;
-            v01[it] = *reinterpret_cast<const double2 *>(a.val + idx);
-            v23[it] = *reinterpret_cast<const double2 *>(a.val + idx + 2);
-            c[it]   = *reinterpret_cast<const int4 *>(a.col + idx);
+            v01[it] = ld_stream_d2(a.val + idx);
+            v23[it] = ld_stream_d2(a.val + idx + 2);
+            c[it]   = ld_stream_i4(a.col + idx);
         }
         double2 o01[ITER], o23[ITER];
 #pragma unroll
@@ -256,25 +293,51 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
 
 // ---------------------------------------------------------------------------
 // K1d: k_csr_stream with 16-bit compressed column ids.  The kernel is HBM-bound, so bytes are time:
-// a row block of a mesh-like operator touches only a few 4096-column segments (a 7-point stencil: the
-// three z-planes; a smoothed-aggregation coarse level: five), so each column is stored as a 4-bit slot
-// into the block's table of <= 16 segment bases plus a 12-bit offset: 10 B/nnz instead of 12.  Operators
-// whose blocks touch more than 16 segments keep the 32-bit kernel (decided per operator at plan time).
-// Arithmetic and summation order are those of k_csr_stream (bit-identical results).
+// a row block of a mesh-like operator touches only a few column segments (a 7-point stencil: its
+// three z-planes; a smoothed-aggregation coarse level: a 3D neighbourhood = a few dozen short runs), so each
+// column is stored as a slot into the block's table of segment bases plus an offset inside the segment:
+// 10 B/nnz instead of 12.  The slot/offset split is chosen per operator at plan time: 4+12 bits (16 segments of
+// 4096 columns) for stencil-like levels, up to 8+8 bits (256 segments of 256 columns) for the coarse levels whose
+// rows hold hundreds to thousands of entries.  Operators with a block that touches more than 256 segments keep
+// the 32-bit kernel.  Arithmetic and summation order are those of k_csr_stream (bit-identical results).
 __device__ __forceinline__ bool stray(int k, int p0, int p1) { return k < p0 || k >= p1; }
+constexpr int CC_MAXSEG = 256;
 
 template <int EPI, int G, int CAPV, bool HALO>
 __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
     constexpr int LDSN = CAPV + 8;
     __shared__ __attribute__((aligned(16))) double lds[LDSN];
-    __shared__ int seg[16];
+    __shared__ int seg[CC_MAXSEG];
     const int tid = threadIdx.x;
     if constexpr (HALO) fork_signal(a);
     const int b   = xcd_remap(blockIdx.x, a.nblk);
     const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
     const int p0 = a.row_ptr[r0], p1 = a.row_ptr[r1];
-    if (tid < 16) seg[tid] = a.segtab[b * 16 + tid];
+    {
+        const int s0 = a.segptr[b], ns = a.segptr[b + 1] - s0;      // ns <= CC_MAXSEG = BLOCK
+        if (tid < ns) seg[tid] = a.segtab[s0 + tid];
+    }
     __syncthreads();
+    const int ob = a.cc_ob;
+    const unsigned om = (1u << ob) - 1u;
+
+    if (r1 - r0 == 1 && p1 - p0 > CAPV) {             // ---- one long row (its block has a table of its own)
+        double s = 0.0;
+        for (int k = p0 + tid; k < p1; k += BLOCK) {
+            const unsigned c = a.ccol[k];
+            s += a.val[k] * a.x[seg[c >> ob] + (int)(c & om)];
+        }
+        s = group_sum<64>(s);
+        if ((tid & 63) == 0) lds[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double t = lds[0];
+#pragma unroll
+            for (int w = 1; w < BLOCK / 64; ++w) t += lds[w];
+            epilogue<EPI, HALO>(a, r0, t);
+        }
+        return;
+    }
 
     const int a0 = p0 & ~3;
     const int nq = (p1 - a0 + 3) >> 2;
@@ -285,14 +348,14 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
             const int q = tid + it * BLOCK;
             if (q < nq) {
                 const int idx = a0 + 4 * q;
-                const double2 v01 = *reinterpret_cast<const double2 *>(a.val + idx);
-                const double2 v23 = *reinterpret_cast<const double2 *>(a.val + idx + 2);
-                const uint2   c   = *reinterpret_cast<const uint2 *>(a.ccol + idx);
+                const double2 v01 = ld_stream_d2(a.val + idx);
+                const double2 v23 = ld_stream_d2(a.val + idx + 2);
+                const uint2   c   = ld_stream_u2(a.ccol + idx);
                 const unsigned c0 = c.x & 0xffffu, c1 = c.x >> 16, c2 = c.y & 0xffffu, c3 = c.y >> 16;
-                int j0 = seg[c0 >> 12] + (int)(c0 & 4095u), j1 = seg[c1 >> 12] + (int)(c1 & 4095u);
-                int j2 = seg[c2 >> 12] + (int)(c2 & 4095u), j3 = seg[c3 >> 12] + (int)(c3 & 4095u);
+                int j0 = seg[c0 >> ob] + (int)(c0 & om), j1 = seg[c1 >> ob] + (int)(c1 & om);
+                int j2 = seg[c2 >> ob] + (int)(c2 & om), j3 = seg[c3 >> ob] + (int)(c3 & om);
                 if (q == 0 || q == nq - 1) {          // quads shared with a neighbouring block: its ids were packed
-                    j0 = stray(idx, p0, p1) ? 0 : j0; //  against ANOTHER segment table and may decode past the end of x
+                    j0 = stray(idx, p0, p1) ? 0 : j0; //  against ANOTHER segment table and may decode to anything
                     j1 = stray(idx + 1, p0, p1) ? 0 : j1;
                     j2 = stray(idx + 2, p0, p1) ? 0 : j2;
                     j3 = stray(idx + 3, p0, p1) ? 0 : j3;
@@ -315,16 +378,16 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
             int q = tid + it * BLOCK;
             q = q < qlast ? q : qlast;
             const int idx = a0 + 4 * q;
-            v01[it] = *reinterpret_cast<const double2 *>(a.val + idx);
-            v23[it] = *reinterpret_cast<const double2 *>(a.val + idx + 2);
-            c[it]   = *reinterpret_cast<const uint2 *>(a.ccol + idx);
+            v01[it] = ld_stream_d2(a.val + idx);
+            v23[it] = ld_stream_d2(a.val + idx + 2);
+            c[it]   = ld_stream_u2(a.ccol + idx);
         }
         double2 o01[ITER], o23[ITER];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const unsigned c0 = c[it].x & 0xffffu, c1 = c[it].x >> 16, c2 = c[it].y & 0xffffu, c3 = c[it].y >> 16;
-            int j0 = seg[c0 >> 12] + (int)(c0 & 4095u), j1 = seg[c1 >> 12] + (int)(c1 & 4095u);
-            int j2 = seg[c2 >> 12] + (int)(c2 & 4095u), j3 = seg[c3 >> 12] + (int)(c3 & 4095u);
+            int j0 = seg[c0 >> ob] + (int)(c0 & om), j1 = seg[c1 >> ob] + (int)(c1 & om);
+            int j2 = seg[c2 >> ob] + (int)(c2 & om), j3 = seg[c3 >> ob] + (int)(c3 & om);
             int q = tid + it * BLOCK;
             q = q < qlast ? q : qlast;
             if (q == 0 || q == qlast) {               // quads shared with a neighbouring block (see above)
@@ -391,6 +454,59 @@ __global__ __launch_bounds__(BLOCK) void k_csr_vector(const SpmvArgs a, int nrow
             sum += v1 * a.x[c1];
         }
         if (k < p1) sum += a.val[k] * a.x[a.col[k]];
+    }
+    sum = group_sum<G>(sum);
+    if (r < nrows && l == 0) {
+        epilogue<EPI, HALO>(a, r, sum);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1e: wave-streamed CSR for LONG rows (hundreds to thousands of entries): G lanes own one row and stream it
+// straight from global memory with 16-byte loads (a lane takes 4 consecutive nnz, two quads in flight per lane),
+// accumulate in registers and combine with shuffles -- no LDS staging, no barrier, so a CU keeps its full 32 waves
+// in flight whatever the row length.  The row-block kernels above hold one 16/32 KiB tile per workgroup: a 2 000-entry
+// row fills half a 32 KiB tile and only 4-5 such workgroups fit a CU, which leaves the memory pipe short of bytes in
+// flight (measured on a 2 160-nnz/row box stencil: 4.65 TB/s against 5.9 TB/s for full tiles).
+// Quads are aligned to 4 entries like in k_csr_stream; entries of the neighbouring rows that share a quad are
+// multiplied by zero (their columns are valid, the arrays are padded by 8 zero entries).
+template <int EPI, int G, bool HALO>
+__global__ __launch_bounds__(BLOCK) void k_csr_wave(const SpmvArgs a, int nrows) {
+    constexpr int RPB = BLOCK / G;
+    const int nb = (nrows + RPB - 1) / RPB;
+    if constexpr (HALO) fork_signal(a);
+    const int b = xcd_remap(blockIdx.x, nb);
+    const int tid = threadIdx.x;
+    const int r = b * RPB + tid / G, l = tid % G;
+    double sum = 0.0;
+    if (r < nrows) {
+        const int p0 = a.row_ptr[r], p1 = a.row_ptr[r + 1];
+        const int a0 = p0 & ~3;
+        const int nq = (p1 - a0 + 3) >> 2;
+        for (int q = l; q < nq; q += 2 * G) {
+            const int i0 = a0 + 4 * q;
+            const bool two = q + G < nq;
+            const int i1 = two ? i0 + 4 * G : i0;               // (a lane without a second quad re-reads its first)
+            double2 v01 = ld_stream_d2(a.val + i0);
+            double2 v23 = ld_stream_d2(a.val + i0 + 2);
+            const int4 c = ld_stream_i4(a.col + i0);
+            double2 w01 = ld_stream_d2(a.val + i1);
+            double2 w23 = ld_stream_d2(a.val + i1 + 2);
+            const int4 d = ld_stream_i4(a.col + i1);
+            const double x0 = a.x[c.x], x1 = a.x[c.y], x2 = a.x[c.z], x3 = a.x[c.w];
+            const double y0 = a.x[d.x], y1 = a.x[d.y], y2 = a.x[d.z], y3 = a.x[d.w];
+            if (i0 < p0 || i0 + 4 > p1) {                         // first / last quad of the row: drop the neighbours' entries
+                v01.x = stray(i0, p0, p1) ? 0.0 : v01.x;     v01.y = stray(i0 + 1, p0, p1) ? 0.0 : v01.y;
+                v23.x = stray(i0 + 2, p0, p1) ? 0.0 : v23.x; v23.y = stray(i0 + 3, p0, p1) ? 0.0 : v23.y;
+            }
+            if (!two) { w01.x = w01.y = w23.x = w23.y = 0.0; }
+            else if (i1 + 4 > p1) {
+                w01.x = stray(i1, p0, p1) ? 0.0 : w01.x;     w01.y = stray(i1 + 1, p0, p1) ? 0.0 : w01.y;
+                w23.x = stray(i1 + 2, p0, p1) ? 0.0 : w23.x; w23.y = stray(i1 + 3, p0, p1) ? 0.0 : w23.y;
+            }
+            sum += v01.x * x0; sum += v01.y * x1; sum += v23.x * x2; sum += v23.y * x3;
+            sum += w01.x * y0; sum += w01.y * y1; sum += w23.x * y2; sum += w23.y * y3;
+        }
     }
     sum = group_sum<G>(sum);
     if (r < nrows && l == 0) {

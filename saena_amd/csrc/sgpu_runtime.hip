@@ -22,6 +22,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -127,14 +128,16 @@ struct CsrPart {
     int     ncols = 0;
     std::vector<double> h_val;    // host copy of the values, kept only while a dense form is still possible
     // 16-bit compressed columns (variants 3/4): per plan ([0] 16 KiB, [1] 32 KiB) a segment table and packed column ids
-    int            *segtab[2] = {nullptr, nullptr};
+    int            *segtab[2] = {nullptr, nullptr}, *segptr[2] = {nullptr, nullptr};
     unsigned short *ccol[2] = {nullptr, nullptr};
     bool            cc_ok[2] = {false, false};
+    int             cc_ob[2] = {12, 12};   // offset bits of the slot/offset split (12: 16 segments of 4096 columns ... 8: 256 of 256)
+    char            cc_tried[2] = {0, 0};  // build_cc16 ran and found no split that fits (do not try again)
     std::vector<int> h_rp, h_col, h_blk, h_blk_big;   // host copies kept for build_cc16 / the coarsest factorisation
     void free_all() {
         hipFree(row_ptr); hipFree(col); hipFree(blk_row); hipFree(blk_row_big); hipFree(rows); hipFree(val); hipFree(dense);
         dense = nullptr;
-        for (int k = 0; k < 2; ++k) { hipFree(segtab[k]); hipFree(ccol[k]); segtab[k] = nullptr; ccol[k] = nullptr; }
+        for (int k = 0; k < 2; ++k) { hipFree(segtab[k]); hipFree(segptr[k]); hipFree(ccol[k]); segtab[k] = segptr[k] = nullptr; ccol[k] = nullptr; }
         row_ptr = col = blk_row = blk_row_big = rows = nullptr; val = nullptr;
     }
 };
@@ -198,34 +201,72 @@ int build_dense(CsrPart &P) {
     return SGPU_OK;
 }
 
-// 16-bit compressed columns of plan k: (slot << 12) | (col & 4095) with <= 16 segment bases per block.
+// 16-bit compressed columns of plan k: (slot << ob) | (col & (2^ob - 1)) with <= 2^(16-ob) segment bases per block.
+// ob is the largest of 12..8 for which every block's distinct segments fit its slots (fewest table entries to read);
+// blocks are independent, so the encoding runs on a few host threads.
+int host_threads() {
+    const char *e = std::getenv("SAENA_SETUP_THREADS");
+    int n = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(n, 16));
+}
 int build_cc16(CsrPart &P, int k) {
-    if (P.cc_ok[k] || P.h_rp.empty()) return SGPU_OK;
+    if (P.cc_ok[k] || P.cc_tried[k] || P.h_rp.empty()) return SGPU_OK;
+    P.cc_tried[k] = 1;
     const std::vector<int> &blk = k ? P.h_blk_big : P.h_blk;
-    const int cap = k ? sk::CAP_BIG : sk::CAP;
     const int nblk = (int)blk.size() - 1;
-    std::vector<int> segtab((size_t)nblk * 16, 0);
+    if (nblk == 0) return SGPU_OK;
+    const int ncols = std::max(1, P.ncols);
+    const int nt = std::min(host_threads(), std::max(1, nblk / 64));
     std::vector<unsigned short> ccol(P.h_col.size() + 8, 0);
-    for (int b = 0; b < nblk; ++b) {
-        const int p0 = P.h_rp[blk[b]], p1 = P.h_rp[blk[b + 1]];
-        if (p1 - p0 > cap) return SGPU_OK;                       // long-row blocks keep the 32-bit kernel
-        int nseg = 0;
-        int *tab = &segtab[(size_t)b * 16];
-        for (int p = p0; p < p1; ++p) {
-            const int sgm = P.h_col[p] >> 12;
-            int slot = -1;
-            for (int t = nseg - 1; t >= 0; --t) if (tab[t] == (sgm << 12)) { slot = t; break; }
-            if (slot < 0) {
-                if (nseg == 16) return SGPU_OK;                   // too scattered for 4-bit slots
-                tab[nseg] = sgm << 12; slot = nseg++;
+    for (int ob = 12; ob >= 8; --ob) {
+        const int maxseg = 1 << (16 - ob), nsegs_total = (ncols >> ob) + 1;
+        std::vector<std::vector<int>> tabs((size_t)nt);         // per thread: the tables of its blocks, concatenated
+        std::vector<int> cnt((size_t)nblk, 0);
+        std::vector<char> bad((size_t)nt, 0);
+        auto work = [&](int t) {
+            const int b0 = (int)((long)nblk * t / nt), b1 = (int)((long)nblk * (t + 1) / nt);
+            std::vector<int> slot_of((size_t)nsegs_total, -1), uniq;
+            for (int b = b0; b < b1 && !bad[(size_t)t]; ++b) {
+                const int p0 = P.h_rp[blk[b]], p1 = P.h_rp[blk[b + 1]];
+                uniq.clear();
+                int last = -1;
+                for (int p = p0; p < p1; ++p) {                 // distinct segments of the block
+                    const int sgm = P.h_col[p] >> ob;
+                    if (sgm == last) continue;
+                    last = sgm;
+                    if (slot_of[(size_t)sgm] < 0) { slot_of[(size_t)sgm] = 0; uniq.push_back(sgm); }
+                }
+                if ((int)uniq.size() > maxseg) { bad[(size_t)t] = 1; for (int u : uniq) slot_of[(size_t)u] = -1; break; }
+                std::sort(uniq.begin(), uniq.end());            // ascending bases: the table does not depend on the entry order
+                for (size_t i = 0; i < uniq.size(); ++i) { slot_of[(size_t)uniq[i]] = (int)i; tabs[(size_t)t].push_back(uniq[i] << ob); }
+                cnt[(size_t)b] = (int)uniq.size();
+                const int om = (1 << ob) - 1;
+                for (int p = p0; p < p1; ++p)
+                    ccol[(size_t)p] = (unsigned short)((slot_of[(size_t)(P.h_col[p] >> ob)] << ob) | (P.h_col[p] & om));
+                for (int u : uniq) slot_of[(size_t)u] = -1;
             }
-            ccol[p] = (unsigned short)((slot << 12) | (P.h_col[p] & 4095));
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
         }
+        bool ok = true;
+        for (char c : bad) ok = ok && !c;
+        if (!ok) continue;                                       // too scattered for this split: try more, smaller segments
+        std::vector<int> segptr((size_t)nblk + 1, 0), segtab;
+        for (int b = 0; b < nblk; ++b) segptr[(size_t)b + 1] = segptr[(size_t)b] + cnt[(size_t)b];
+        segtab.reserve((size_t)segptr.back() + 1);
+        for (auto &t : tabs) segtab.insert(segtab.end(), t.begin(), t.end());
+        CHK(dev_upload(&P.segtab[k], segtab.data(), segtab.size(), 1));
+        CHK(dev_upload(&P.segptr[k], segptr.data(), segptr.size()));
+        CHK(dev_upload(&P.ccol[k], ccol.data(), ccol.size()));
+        P.cc_ob[k] = ob;
+        P.cc_ok[k] = true;
+        return SGPU_OK;
     }
-    CHK(dev_upload(&P.segtab[k], segtab.data(), segtab.size()));
-    CHK(dev_upload(&P.ccol[k], ccol.data(), ccol.size()));
-    P.cc_ok[k] = true;
-    return SGPU_OK;
+    return SGPU_OK;                                              // a block touches more than 256 segments of 256 columns
 }
 
 } // namespace
@@ -246,6 +287,7 @@ struct sgpu_op {
     int     halo_fp32 = 0;
     bool    injected = false;     // test hook: halo supplied by sgpu_debug_inject_halo
     bool    local_only_ok = false; // test hook: sgpu_debug_allow_local_only
+    std::string vname;            // sgpu_op_get_variant's kernel name (owns the string it returns)
     std::vector<double> h_val;   // host copy of the values of small local parts (coarsest-level factorisation)
     unsigned *skip = nullptr;     // bitmask over the M rows: set = boundary row (has remote entries), written by k_csr_boundary
     int     bnd_lanes = 1;        // lanes per boundary row
@@ -320,6 +362,27 @@ VecKernelFn pick_vec_h(int epi, int lanes) {
     }
 }
 VecKernelFn pick_vec(int epi, int lanes, bool halo) { return halo ? pick_vec_h<true>(epi, lanes) : pick_vec_h<false>(epi, lanes); }
+template <int EPI, bool H>
+VecKernelFn pick_wave_g(int lanes) {
+    switch (lanes) {
+        case 1: case 2: case 4: case 8:  return sk::k_csr_wave<EPI, 8, H>;
+        case 16: return sk::k_csr_wave<EPI, 16, H>;
+        case 32: return sk::k_csr_wave<EPI, 32, H>;
+        default: return sk::k_csr_wave<EPI, 64, H>;
+    }
+}
+template <bool H>
+VecKernelFn pick_wave_h(int epi, int lanes) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return pick_wave_g<sk::EPI_SPMV, H>(lanes);
+        case sk::EPI_RESIDUAL: return pick_wave_g<sk::EPI_RESIDUAL, H>(lanes);
+        case sk::EPI_JACOBI:   return pick_wave_g<sk::EPI_JACOBI, H>(lanes);
+        case sk::EPI_CHEBY0:   return pick_wave_g<sk::EPI_CHEBY0, H>(lanes);
+        case sk::EPI_CHEBYK:   return pick_wave_g<sk::EPI_CHEBYK, H>(lanes);
+        default:               return pick_wave_g<sk::EPI_SUB, H>(lanes);
+    }
+}
+VecKernelFn pick_wave(int epi, int lanes, bool halo) { return halo ? pick_wave_h<true>(epi, lanes) : pick_wave_h<false>(epi, lanes); }
 
 struct EpiArgs {
     const double *rhs = nullptr, *inv_diag = nullptr, *u = nullptr;
@@ -335,7 +398,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.row_ptr = P.row_ptr; a.col = P.col; a.val = P.val;
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
-    a.segtab = nullptr; a.ccol = nullptr;
+    a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12;
     const bool halo = skip != nullptr || seq != 0;
     if (P.variant == 5) {                                         // dense rows, one wave per row
         if (!P.dense) return fail(SGPU_ERR_STATE, "the dense form was not built");
@@ -351,8 +414,12 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         if (!P.cc_ok[k]) return fail(SGPU_ERR_STATE, "compressed columns of plan %d were not built", k);
         a.blk_row = k ? P.blk_row_big : P.blk_row;
         a.nblk = k ? P.nblk_big : P.nblk;
-        a.segtab = P.segtab[k]; a.ccol = P.ccol[k];
+        a.segtab = P.segtab[k]; a.segptr = P.segptr[k]; a.ccol = P.ccol[k]; a.cc_ob = P.cc_ob[k];
         SGPU_LAUNCH(pick<1>(epi, P.lanes, k == 1, halo), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
+    } else if (P.variant == 6) {                                  // wave-streamed long rows, 16-byte loads
+        const int gl = std::max(8, P.lanes), rpb = sk::BLOCK / gl;
+        a.blk_row = nullptr; a.nblk = 0;
+        SGPU_LAUNCH(pick_wave(epi, gl, halo), dim3((P.nrows + rpb - 1) / rpb), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
     } else if (P.variant == 2) {                                  // vector CSR
         const int rpb = sk::BLOCK / P.lanes;
         a.blk_row = nullptr; a.nblk = 0;
@@ -398,7 +465,7 @@ int launch_boundary(sgpu_op *op, int epi, const double *x, double *y, const EpiA
     b.s.flag_x = nullptr; b.s.seq = 0;
     b.s.row_ptr = op->loc.row_ptr; b.s.col = op->loc.col; b.s.val = op->loc.val; b.s.blk_row = nullptr; b.s.nblk = 0;
     b.s.x = x; b.s.y = y; b.s.rhs = e.rhs; b.s.inv_diag = e.inv_diag; b.s.u = e.u; b.s.d = e.d; b.s.c0 = e.c0; b.s.c1 = e.c1;
-    b.s.skip = nullptr; b.s.segtab = nullptr; b.s.ccol = nullptr;
+    b.s.skip = nullptr; b.s.segtab = nullptr; b.s.segptr = nullptr; b.s.ccol = nullptr; b.s.cc_ob = 12;
     b.rows = op->rem.rows; b.nrows = op->rem.nrows;
     b.h_ptr = op->rem.row_ptr; b.h_col = op->rem.col; b.h_val = op->rem.val;
     b.halo = op->recv_buf; b.halo_f = halo_is_f32 ? op->recv_f : nullptr;
@@ -969,21 +1036,31 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows"};
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave"};
     if (variant) *variant = op->loc.variant;
-    if (kernel_name) *kernel_name = names[op->loc.variant];
+    if (kernel_name) {
+        const int v = op->loc.variant;
+        if (v == 3 || v == 4) {      // name the slot/offset split of the compressed columns: "k_csr_cc16<32KiB,5+11>"
+            char buf[64];
+            snprintf(buf, sizeof buf, "k_csr_cc16<%s,%d+%d>", v == 3 ? "16KiB" : "32KiB", 16 - op->loc.cc_ob[v - 3], op->loc.cc_ob[v - 3]);
+            const_cast<sgpu_op *>(op)->vname = buf;
+            *kernel_name = op->vname.c_str();
+        } else {
+            *kernel_name = names[v];
+        }
+    }
     return SGPU_OK;
 }
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 5) return fail(SGPU_ERR_ARG, "variant must be 0..5");
+    if (variant < 0 || variant > 6) return fail(SGPU_ERR_ARG, "variant must be 0..6");
     if (variant == 5) {
         if (op->has_remote) return fail(SGPU_ERR_ARG, "the dense form serves operators without a halo");
         CHK(build_dense(op->loc));
-    } else if (variant >= 3) {
+    } else if (variant == 3 || variant == 4) {
         CHK(build_cc16(op->loc, variant - 3));
-        if (!op->loc.cc_ok[variant - 3]) return fail(SGPU_ERR_ARG, "this operator's blocks touch more than 16 column segments (or hold a long row)");
+        if (!op->loc.cc_ok[variant - 3]) return fail(SGPU_ERR_ARG, "a row block of this operator touches more than 256 column segments of 256 columns");
     }
     op->loc.variant = variant;
     ++g_plan_generation;
@@ -1008,6 +1085,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     int bv = 0, bg = g0;
     std::vector<int> variants = {0, 1, 2};
     for (int k = 0; k < 2; ++k) { CHK(build_cc16(op->loc, k)); if (op->loc.cc_ok[k]) variants.push_back(3 + k); }
+    if (op->loc.nnz >= 256 * (int64_t)std::max(1, op->loc.nrows)) variants.push_back(6);   // long rows: the wave-streamed kernel
     if (!op->has_remote && !op->loc.h_val.empty() && (double)op->loc.nnz >= 0.5 * (double)op->loc.nrows * op->loc.ncols && build_dense(op->loc) == SGPU_OK)
         variants.push_back(5);                         // at least half full: the dense form moves fewer bytes
     // Only the LOCAL part is timed, without the halo exchange: ranks may end up with different candidate
@@ -1040,8 +1118,8 @@ int sgpu_op_autotune(sgpu_op *op) {
     if (bv != 5 && op->loc.dense) { hipFree(op->loc.dense); op->loc.dense = nullptr; }
     for (int k = 0; k < 2; ++k)                       // free the compressed arrays of the plans that lost
         if (op->loc.cc_ok[k] && bv != 3 + k) {
-            hipFree(op->loc.segtab[k]); hipFree(op->loc.ccol[k]);
-            op->loc.segtab[k] = nullptr; op->loc.ccol[k] = nullptr; op->loc.cc_ok[k] = false;
+            hipFree(op->loc.segtab[k]); hipFree(op->loc.segptr[k]); hipFree(op->loc.ccol[k]);
+            op->loc.segtab[k] = op->loc.segptr[k] = nullptr; op->loc.ccol[k] = nullptr; op->loc.cc_ok[k] = false; op->loc.cc_tried[k] = 0;
         }
     return SGPU_OK;
 }

@@ -109,21 +109,16 @@ def test_spmv_lane_variants(capi, name, lanes):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6])
 def test_kernel_variants(capi, name, variant):
-    """32 KiB tiles / vector CSR / 16-bit compressed columns (16 and 32 KiB): same results as the default kernel"""
+    """32 KiB tiles / vector CSR / 16-bit compressed columns (16 and 32 KiB tiles; long rows included) / wave-streamed
+    long rows: same results as the default kernel"""
     entries, M = get_problem(name)
     A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
     G = util.gpu_operator(A)
-    if variant >= 3:
-        try:
-            G.set_variant(variant)
-        except capi.SgpuError:
-            # refused, not mis-computed: rows longer than the tile, or blocks touching > 16 column segments
-            assert name in ("band3000_1400", "irregular5000")
-            return
-    else:
-        G.set_variant(variant)
+    G.set_variant(variant)                # the compressed-column forms serve every one of these operators
+    if variant in (3, 4):
+        assert "k_csr_cc16" in G.variant()[1]
     x, rhs = inputs.v2(M), inputs.rhs2(M)
     bound = abs_bound(entries, M, x)
     dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
@@ -131,13 +126,66 @@ def test_kernel_variants(capi, name, variant):
         G.set_lanes_per_row(lanes)
         G.spmv(dx, dy)
         got, want = dy.download(), A.matvec(x)
-        if lanes == 1 and variant != 2 and (name != "band3000_1400" or variant in (1, 4)):
+        if lanes == 1 and variant not in (2, 6) and (name != "band3000_1400" or variant in (1, 4)):
             np.testing.assert_array_equal(got, want)          # stream variants keep the sequential row sum
         else:
             assert np.all(np.abs(got - want) <= TOL_SPMV * bound + 1e-300)
         du = capi.DeviceVector(M, x)
         G.jacobi(2, du, dr)
         assert rel(du.download(), A.jacobi(2, x, rhs)) <= TOL_SMOOTH
+
+
+def _clustered_operator(M, N, clusters, seed):
+    """rectangular operator whose rows touch `clusters` runs of 8 consecutive columns spread over all N columns; the 64
+    rows of a group share their clusters (a row block then touches a few hundred short segments far apart)"""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for g0 in range(0, M, 64):
+        starts = np.sort(rng.choice((N - 8) // 8, size=clusters, replace=False)) * 8 + rng.integers(0, 8)
+        c = (starts[:, None] + np.arange(8)[None, :]).ravel()
+        c = c[c < N]
+        for r in range(g0, min(g0 + 64, M)):
+            rows.append(np.full(len(c), r)); cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    vals = np.sin(0.3 * rows + 0.7 * cols) + 1.5
+    return orc.coo_from_arrays(rows.astype(np.int32), cols.astype(np.int32), vals)
+
+
+@pytest.mark.parametrize("clusters,split_expected", [(40, "wider"), (6, "4+12")])
+def test_compressed_columns_slot_offset_split(capi, clusters, split_expected):
+    """The 16-bit column form picks its slot/offset split per operator: 4+12 bits when a block's columns sit in <= 16
+    segments of 4096, more slots of smaller segments (down to 8+8) when they sit in many short clusters far apart -- and
+    an operator whose blocks touch more than 256 segments of 256 columns is refused, not mis-computed."""
+    M, N = 2048, 1 << 20
+    entries = _clustered_operator(M, N, clusters, 5)
+    A = orc.OracleOp(entries, M, N, orc.split_even(M, 1), orc.split_even(N, 1), square=False)
+    G = util.gpu_operator(A)
+    x = inputs.v2(N)
+    want = A.matvec(x)
+    dx, dy = capi.DeviceVector(N, x), capi.DeviceVector(M)
+    for variant in (3, 4):
+        G.set_variant(variant)
+        name = G.variant()[1]
+        if split_expected == "4+12":
+            assert "4+12" in name, name
+        else:
+            assert "k_csr_cc16" in name and "4+12" not in name, name
+        G.set_lanes_per_row(1)
+        G.spmv(dx, dy)
+        np.testing.assert_array_equal(dy.download(), want)      # same products, same sequential row sum as the 32-bit kernel
+    # uniformly random columns over 2^20: > 256 segments per block whatever the split
+    rng = np.random.default_rng(3)
+    rows = np.repeat(np.arange(M), 24)
+    cols = rng.integers(0, N, size=rows.size)
+    key = np.unique(rows.astype(np.int64) * N + cols)
+    e2 = orc.coo_from_arrays((key // N).astype(np.int32), (key % N).astype(np.int32), np.ones(key.size))
+    A2 = orc.OracleOp(e2, M, N, orc.split_even(M, 1), orc.split_even(N, 1), square=False)
+    G2 = util.gpu_operator(A2)
+    with pytest.raises(capi.SgpuError, match="256 column segments"):
+        G2.set_variant(3)
+    G2.autotune()                                               # the plan-time choice simply leaves the form out
+    G2.spmv(dx, dy)
+    assert np.all(np.abs(dy.download() - A2.matvec(x)) <= TOL_SPMV * 24 * np.max(np.abs(x)))
 
 
 @pytest.mark.parametrize("name", ["poisson12", "poisson20", "band300_7", "irregular5000"])
