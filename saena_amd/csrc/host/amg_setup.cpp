@@ -658,16 +658,16 @@ void amg_hierarchy::distribute(Comm &c, const std::vector<index_t> &split0) {
     dist.clear();
     dist.resize((size_t)n);
     dist[0].split = split0;
+    level_stride.assign((size_t)n, 1);
     for (int l = 1; l < n; ++l) {
         const index_t rows = levels[l].A->Mbig;
         std::vector<index_t> sp((size_t)np + 1, rows);
         sp[0] = 0;
-        if (rows > shrink_rows) {
-            const auto &roots = levels[l - 1].roots;            // splitNew[r] = #roots below the fine boundary
-            for (int r = 1; r < np; ++r)
-                sp[r] = (index_t)(std::lower_bound(roots.begin(), roots.end(), dist[l - 1].split[r]) - roots.begin());
-        }                                                       // else: everything on rank 0 (sp = 0, rows, rows, ...)
-        dist[l].split = sp;
+        const auto &roots = levels[l - 1].roots;                // splitNew[r] = #roots below the fine boundary
+        for (int r = 1; r < np; ++r)
+            sp[r] = (index_t)(std::lower_bound(roots.begin(), roots.end(), dist[l - 1].split[r]) - roots.begin());
+        level_stride[(size_t)l] = next_stride((long)levels[l].A->nnz_g, rows, np, level_stride[(size_t)l - 1]);
+        dist[l].split = merge_split(sp, level_stride[(size_t)l]);
     }
     for (int l = 0; l < n; ++l) {
         dist_level &d = dist[l];
@@ -683,6 +683,42 @@ void amg_hierarchy::distribute(Comm &c, const std::vector<index_t> &split0) {
             d.R.build(c, slice_entries(g.R.L, spc[c.rank], spc[c.rank + 1]), spc, d.split);  // coarse rows, fine columns
         }
     }
+}
+
+// ---- agglomeration policy (see amg_setup.h) ----
+int amg_hierarchy::next_stride(long nnzC, index_t rowsC, int np, int stride_prev) const {
+    double chain = shrink_chain_us;
+    index_t rows_rule = shrink_rows;
+    if (const char *e = std::getenv("SAENA_SHRINK_CHAIN_US")) chain = std::atof(e);
+    if (const char *e = std::getenv("SAENA_SHRINK_ROWS")) rows_rule = (index_t)std::atol(e);
+    if (np == 1) return 1;
+    if (stride_prev >= np) return np;
+    if (rowsC <= rows_rule) return np;
+    if (chain <= 0) return stride_prev;
+    const double T1 = 12.0 * (double)nnzC / shrink_bw * 1e6 + shrink_launch_us;     // us per apply on one GPU
+    if (T1 <= chain) return np;                                                      // decide_shrinking_c: one rank
+    const int active = (np + stride_prev - 1) / stride_prev;
+    const double compute = T1 / active;
+    if (active > 1 && chain > 2.0 * compute) {                                       // decide_shrinking: comm > 2 x compute
+        int f = (int)std::floor(chain / compute / 5.0);
+        f = std::max(2, std::min(4, f));
+        return std::min(np, stride_prev * f);
+    }
+    return stride_prev;
+}
+
+// shrink_set_params (src/saena_matrix_shrink.cpp:120-129): ranks that are not a multiple of `stride` hand their block
+// to the preceding multiple
+std::vector<index_t> amg_hierarchy::merge_split(const std::vector<index_t> &splitNew, int stride) {
+    std::vector<index_t> sp = splitNew;
+    const int np = (int)sp.size() - 1;
+    if (stride <= 1) return sp;
+    int root = np;
+    for (int proc = np - 1; proc > 0; --proc) {
+        if (proc % stride == 0) root = proc;
+        else sp[(size_t)proc] = sp[(size_t)root];
+    }
+    return sp;
 }
 
 // ===========================================================================
@@ -795,6 +831,27 @@ std::vector<cooEntry> csr_entries_colmajor(const Csr &M, index_t row_lo) {
     return e;
 }
 
+// every row of this rank's block goes to rank `dest`; returns the rows this rank receives, concatenated in source-rank
+// order (blocks are ascending row ranges held by ascending ranks, so the result is the merged block in row order)
+Csr rehome_rows(Comm &c, const Csr &X, int dest) {
+    const int np = c.nranks;
+    std::vector<int> scr((size_t)np, 0), sce((size_t)np, 0);
+    std::vector<nnz_t> len((size_t)X.nrows);
+    for (index_t i = 0; i < X.nrows; ++i) len[i] = X.ptr[i + 1] - X.ptr[i];
+    scr[(size_t)dest] = X.nrows;
+    sce[(size_t)dest] = (int)X.col.size();
+    const std::vector<nnz_t> rlen = c.alltoallv_records(len, scr);
+    Csr Y;
+    Y.ncols = X.ncols;
+    Y.col = c.alltoallv_records(X.col, sce);
+    Y.val = c.alltoallv_records(X.val, sce);
+    Y.nrows = (index_t)rlen.size();
+    Y.ptr.assign((size_t)Y.nrows + 1, 0);
+    for (index_t i = 0; i < Y.nrows; ++i) Y.ptr[i + 1] = Y.ptr[i] + rlen[i];
+    if ((size_t)Y.ptr[Y.nrows] != Y.col.size()) throw std::runtime_error("rehome_rows: length mismatch");
+    return Y;
+}
+
 struct AggState { index_t agg; char decided, is_root; char pad[2]; };
 
 } // namespace
@@ -881,6 +938,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
     levels.resize(1);
     levels[0].A = Ad;
     dist.clear();
+    level_stride.assign(1, 1);
 
     // level 0: this rank's rows as CSR with global columns (entry is column-major)
     std::vector<index_t> split = Ad->split;
@@ -1060,10 +1118,10 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             if ((unsigned)new_size <= least_row_threshold) ret_val = 1;
             else if (static_cast<float>(new_size) / Mbig > row_reduction_up_thrshld) ret_val = 1;
         }
-        // coarse partition: by the owner of the root; small levels live on rank 0 (saena_matrix_shrink.cpp:167-265)
+        // coarse partition: by the owner of the root (ranks the previous levels agglomerated away own no fine rows, hence
+        // no roots); whether THIS level is agglomerated further is decided below, once its operator exists
         std::vector<index_t> splitC = splitNew;
-        if (new_size <= shrink_rows) { splitC.assign((size_t)np + 1, new_size); splitC[0] = 0; }
-        const index_t clo = splitC[me], chi = splitC[me + 1];
+        index_t clo = splitC[me], chi = splitC[me + 1];
 
         // ---- P = (I - omega D^-1 A) P_tentative: local fine rows, global coarse columns ----
         std::vector<index_t> aggcExt = aggc;
@@ -1144,6 +1202,26 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         }
         pt.lap("filter");
 
+        // ---- agglomeration (amg_setup.h): merge the blocks of consecutive ranks, move R's and Ac's rows to the group's first rank ----
+        {
+            long nnzC = (long)AcN.col.size();
+            c.allreduce_sum_i64(&nnzC, 1);
+            if (level_stride.size() <= (size_t)l) level_stride.resize((size_t)l + 1, 1);
+            const int stride_prev = level_stride[(size_t)l];
+            const int stride = next_stride(nnzC, new_size, np, stride_prev);
+            level_stride.push_back(stride);
+            if (stride > stride_prev) {
+                splitC = merge_split(splitNew, stride);
+                const int root = stride >= np ? 0 : me - me % stride;
+                R = rehome_rows(c, R, root);
+                AcN = rehome_rows(c, AcN, root);
+                clo = splitC[me]; chi = splitC[me + 1];
+                if (R.nrows != chi - clo || AcN.nrows != chi - clo) throw std::runtime_error("agglomeration: merged block has the wrong size");
+                if (std::getenv("SAENA_SETUP_TIMING") && me == 0)
+                    fprintf(stderr, "[setup L%d] level %d (%d rows, %ld nnz) agglomerated: rank stride %d -> %d\n", l, l + 1, new_size, nnzC, stride_prev, stride);
+            }
+            pt.lap("agglomeration");
+        }
         // ---- this level's transfer operators in the reference's layout ----
         {
             dist_level &d = dist.back();

@@ -74,7 +74,27 @@ public:
     std::vector<dist_level> dist;
     std::unique_ptr<saena_matrix> A_global;      // the gathered fine operator (one-rank replica)
     std::unique_ptr<Comm> self_comm;
-    index_t shrink_rows = 4096;
+    // Agglomeration of coarse levels onto fewer ranks -- the reference's shrinking (saena_matrix::decide_shrinking /
+    // decide_shrinking_c / shrink_set_params / shrink_cpu, src/saena_matrix_shrink.cpp:3-265, called from
+    // compute_coarsen, src/saena_object_setup2.cpp:249-318) restated for one GPU per rank.  The reference times a dummy
+    // matvec per level and shrinks by a factor 2..4 when communication exceeds twice the computation, and puts the
+    // coarsest level on one rank.  Here the two times are a model with measured constants: one GPU applies the level in
+    // T1 = 12 B x nnz / shrink_bw + shrink_launch_us, a multi-rank apply costs at least the exchange chain
+    // shrink_chain_us (pack -> RCCL send/recv -> boundary rows: 23 us, profiles/r01_halo_loopback.md and
+    // profiles/r02_halo_loopback_modes.log).  Rules, evaluated after the coarse operator exists (its nnz is known):
+    //   T1 <= chain                      -> the whole level lives on rank 0 (no exchange at all below this level);
+    //   chain > 2 x T1 / active ranks    -> merge groups of f = clamp(floor(chain / compute / 5), 2, 4) consecutive active
+    //                                       ranks onto the first of each group (shrink_set_params' rule: ranks k f own rows);
+    //   rows <= shrink_rows              -> rank 0 (a row-count override, off by default).
+    // SAENA_SHRINK_CHAIN_US / SAENA_SHRINK_ROWS override; chain 0 disables agglomeration.  The vectors need no
+    // repartition step (Grid::repart_u / repart_back_u, src/grid.cpp:99-163): R's rows and P's columns are laid out on
+    // the agglomerated partition, so R r lands where the coarse level lives and P e leaves from there -- the move rides
+    // the transfer operators' own halo exchange.
+    double  shrink_chain_us = 23.0, shrink_bw = 5e12, shrink_launch_us = 3.0;
+    index_t shrink_rows = 0;
+    std::vector<int> level_stride;               // per level: rank r owns rows iff r % stride == 0 (1 = all ranks, >= nranks = rank 0 only)
+    int  next_stride(long nnzC, index_t rowsC, int np, int stride_prev) const;
+    static std::vector<index_t> merge_split(const std::vector<index_t> &splitNew, int stride);
     int setup_distributed(saena_matrix *A_dist, const amg_options &o);
     // the distributed setup proper: every rank builds its rows of every level (fills `dist` only)
     int setup_rows_distributed(saena_matrix *A_dist, const amg_options &o);

@@ -287,6 +287,7 @@ struct sgpu_op {
     int     halo_fp32 = 0;
     bool    injected = false;     // test hook: halo supplied by sgpu_debug_inject_halo
     bool    local_only_ok = false; // test hook: sgpu_debug_allow_local_only
+    bool    single_stream = false; // exchange and rows on the compute stream, in order (short local kernels): apply() mode S
     std::string vname;            // sgpu_op_get_variant's kernel name (owns the string it returns)
     std::vector<double> h_val;   // host copy of the values of small local parts (coarsest-level factorisation)
     unsigned *skip = nullptr;     // bitmask over the M rows: set = boundary row (has remote entries), written by k_csr_boundary
@@ -475,6 +476,22 @@ int launch_boundary(sgpu_op *op, int epi, const double *x, double *y, const EpiA
     return SGPU_OK;
 }
 
+// the halo exchange proper: one grouped send/recv per neighbour (src/saena_matrix_matvec.cpp:32-41 MPI_Irecv/Isend)
+int exchange_group(sgpu_op *op, bool f32, hipStream_t st) {
+    NCCLCHK(ncclGroupStart());
+    for (size_t i = 0; i < op->sendRank.size(); ++i) {
+        if (f32) NCCLCHK(ncclSend(op->send_f + op->sendDispl[i], (size_t)op->sendCount[i], ncclFloat, op->sendRank[i], g.comm, st));
+        else NCCLCHK(ncclSend(op->send_buf + op->sendDispl[i], (size_t)op->sendCount[i], ncclDouble, op->sendRank[i], g.comm, st));
+    }
+    for (size_t i = 0; i < op->recvRank.size(); ++i) {
+        if (f32) NCCLCHK(ncclRecv(op->recv_f + op->recvDispl[i], (size_t)op->recvCount[i], ncclFloat, op->recvRank[i], g.comm, st));
+        else NCCLCHK(ncclRecv(op->recv_buf + op->recvDispl[i], (size_t)op->recvCount[i], ncclDouble, op->recvRank[i], g.comm, st));
+    }
+    NCCLCHK(ncclGroupEnd());
+    ++g_launches;
+    return SGPU_OK;
+}
+
 // Host-routed exchange: pack -> host -> callback -> device, then the same interior / boundary kernels, all on cs.
 int apply_host_transport(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     const bool f32 = op->halo_fp32 != 0;
@@ -522,8 +539,23 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
         return launch_part(op->loc, epi, x, y, e);      // no halo: the local part is the whole operator
     }
     const bool f32 = op->halo_fp32 != 0;                 // both ends of a link must agree: the flag alone decides the wire type
-    const uint64_t n = ++g.seq;
     const unsigned *skip = op->has_remote ? op->skip : nullptr;
+    if (op->single_stream) {
+        // S  one stream.  A SHORT local kernel has nothing to hide the exchange behind, and the fork/join between the
+        //    two streams then costs more than it overlaps: pack -> send/recv group -> interior rows -> boundary rows,
+        //    all on cs, in stream order (4 enqueues instead of 6, no flag, no event; capturable in a hipGraph).
+        if (op->vIndexSize) {
+            const dim3 grid(std::min(sk::PACK_MAX_BLOCKS, (op->vIndexSize + sk::BLOCK - 1) / sk::BLOCK));
+            if (f32) SGPU_LAUNCH(sk::k_pack_f32, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_f, op->vIndexSize, (const uint64_t *)nullptr, (uint64_t)0);
+            else SGPU_LAUNCH(sk::k_pack, grid, dim3(sk::BLOCK), 0, g.cs, x, op->vIndex, op->send_buf, op->vIndexSize, 0, (const uint64_t *)nullptr, (uint64_t)0);
+            HIPCHK(hipGetLastError());
+        }
+        CHK(exchange_group(op, f32, g.cs));
+        CHK(launch_part(op->loc, epi, x, y, e, skip));
+        if (op->has_remote) CHK(launch_boundary(op, epi, x, y, e, f32, g.cs));
+        return SGPU_OK;
+    }
+    const uint64_t n = ++g.seq;
     // Three ways to express the two dependencies (fork: hs after cs's earlier work; join: cs after hs), fastest first:
     //  K  flags polled by kernels: block 0 of the interior launch stores flag_x = n when it starts, the pack launch
     //     polls it; a one-wave k_flag_set behind the boundary kernel stores flag_h = n, a one-wave k_flag_wait on cs
@@ -566,17 +598,7 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
             else SGPU_LAUNCH(sk::k_pack, grid, dim3(sk::BLOCK), 0, g.hs, x, op->vIndex, op->send_buf, op->vIndexSize, 0, flag, n);
             HIPCHK(hipGetLastError());
         }
-        NCCLCHK(ncclGroupStart());
-        for (size_t i = 0; i < op->sendRank.size(); ++i) {
-            if (f32) NCCLCHK(ncclSend(op->send_f + op->sendDispl[i], (size_t)op->sendCount[i], ncclFloat, op->sendRank[i], g.comm, g.hs));
-            else NCCLCHK(ncclSend(op->send_buf + op->sendDispl[i], (size_t)op->sendCount[i], ncclDouble, op->sendRank[i], g.comm, g.hs));
-        }
-        for (size_t i = 0; i < op->recvRank.size(); ++i) {
-            if (f32) NCCLCHK(ncclRecv(op->recv_f + op->recvDispl[i], (size_t)op->recvCount[i], ncclFloat, op->recvRank[i], g.comm, g.hs));
-            else NCCLCHK(ncclRecv(op->recv_buf + op->recvDispl[i], (size_t)op->recvCount[i], ncclDouble, op->recvRank[i], g.comm, g.hs));
-        }
-        NCCLCHK(ncclGroupEnd());
-        ++g_launches;
+        CHK(exchange_group(op, f32, g.hs));
         if (op->has_remote) CHK(launch_boundary(op, epi, x, y, e, f32, g.hs));
         return SGPU_OK;
     };
@@ -999,6 +1021,16 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         if (op->vIndexSize) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->send_f), (size_t)op->vIndexSize * sizeof(float)));
         if (op->recvSize) HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->recv_f), (size_t)op->recvSize * sizeof(float)));
     }
+    {   // Two streams pay when the interior kernel is long enough to hide part of the exchange chain behind.
+        // SAENA_SINGLE_STREAM_NNZ overrides the nnz threshold (0: never).
+        // Measured with RCCL self send/recv (profiles/r02_halo_loopback_modes.log): the GPU-side chain is ~23 us either
+        // way, but the two-stream form takes 23-25 us of HOST time to enqueue against 15 us for the one-stream form, so
+        // applies whose local kernel runs under ~5 us (< 1 M nnz) are host-bound on two streams (28 vs 25 us drained);
+        // from ~10 us of local work on, the overlap wins (32 planes: 27 vs 31 us).
+        long thr = 1000 * 1000;
+        if (const char *e = std::getenv("SAENA_SINGLE_STREAM_NNZ")) thr = std::atol(e);
+        op->single_stream = (long)d->nnz_l_local < thr;
+    }
     // same-device dependencies only: no system-scope fence needed (saves ~2 us per hop, tools/hop_bench.hip)
     HIPCHK(hipEventCreateWithFlags(&op->ev_x, hipEventDisableTiming | hipEventDisableSystemFence));
     HIPCHK(hipEventCreateWithFlags(&op->ev_halo, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -1259,11 +1291,21 @@ struct sgpu_amg {
         hipFree(Ainv); hipFree(alt0); hipFree(r); hipFree(rho); hipFree(hh); hipFree(p);
     }
     std::vector<Captured> graphs;
+    // Multi-rank: the levels agglomerated onto this rank (no operator with a halo from level `tail_level` down) form a
+    // sub-V-cycle without any communication; it is captured once and replayed as ONE graph launch per V-cycle instead
+    // of ~8 launches per level.  Ranks that own no rows of those levels launch nothing at all for them.
+    int  tail_level = -1;
+    bool tail_capturing = false;
+    hipGraph_t tail_graph = nullptr;
+    hipGraphExec_t tail_exec = nullptr;
+    double *tail_out = nullptr;        // which of u[tail_level] / alt[tail_level] holds the sub-V-cycle's result
     uint64_t graph_gen = 0;            // g_plan_generation the graphs were captured under
     bool coarse_host_driven = false;   // coarsest level too large for the LDS-resident solvers: host-driven CG, no graph capture
     void drop_graphs() {
         for (auto &c : graphs) { hipGraphExecDestroy(c.exec); hipGraphDestroy(c.graph); }
         graphs.clear();
+        if (tail_exec) { hipGraphExecDestroy(tail_exec); tail_exec = nullptr; }
+        if (tail_graph) { hipGraphDestroy(tail_graph); tail_graph = nullptr; }
     }
 };
 
@@ -1349,8 +1391,39 @@ int smooth_pp(sgpu_amg *h, int l, int iter, double *u, double *alt, const double
 // u_zero: the iterate is zero by construction (every coarse level, :1249; the fine level when the V-cycle
 // preconditions CG, :2640) and the buffer's CONTENT is not read: the first pre-smoothing sweep then needs no
 // pass over the matrix (k_zero_sweep) and the zero fill itself is skipped.  Results are those of the plain sweep.
+int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, double **out, bool u_zero);
+
+// the communication-free sub-V-cycle from `tail_level` down as one graph launch (captured at its first use)
+int tail_run(sgpu_amg *h, double **out) {
+    const int l = h->tail_level;
+    if (h->tail_exec && h->graph_gen != g_plan_generation) { HIPCHK(hipStreamSynchronize(g.cs)); h->drop_graphs(); }
+    if (!h->tail_exec) {
+        h->graph_gen = g_plan_generation;
+        h->tail_capturing = true;
+        hipError_t e = hipStreamBeginCapture(g.cs, hipStreamCaptureModeThreadLocal);
+        int st = SGPU_OK;
+        if (e == hipSuccess) {
+            st = vcycle_level(h, l, h->u[l], h->alt[l], h->rhs[l], &h->tail_out, true);
+            e = hipStreamEndCapture(g.cs, &h->tail_graph);
+            if (e == hipSuccess && st == SGPU_OK) e = hipGraphInstantiate(&h->tail_exec, h->tail_graph, nullptr, nullptr, 0);
+        }
+        h->tail_capturing = false;
+        if (e != hipSuccess || st != SGPU_OK) {          // not capturable here: run these levels eagerly from now on
+            (void)hipGetLastError();
+            h->drop_graphs();
+            h->tail_level = -1;
+            return vcycle_level(h, l, h->u[l], h->alt[l], h->rhs[l], out, true);
+        }
+    }
+    ++g_launches;
+    HIPCHK(hipGraphLaunch(h->tail_exec, g.cs));
+    *out = h->tail_out;
+    return SGPU_OK;
+}
+
 int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, double **out, bool u_zero) {
     const size_t n = (size_t)h->A[l]->M;
+    if (l == h->tail_level && !h->tail_capturing && u_zero && u == h->u[l] && alt == h->alt[l] && rhs == h->rhs[l]) return tail_run(h, out);
     if (l == h->nlevels - 1) {                             // :991-1057
         if (u_zero && !h->Ainv) CHK(sgpu_vec_fill(u, 0.0, n));      // the CG solvers start from the iterate; the dense solve overwrites it
         CHK(coarse_solve(h, u, rhs, nullptr));
@@ -1494,6 +1567,15 @@ int sgpu_amg_create(int nlevels, sgpu_op *const *A, sgpu_op *const *P, sgpu_op *
     }
     for (int l = 0; l < nlevels - 1; ++l)          // no allocation may happen inside a graph capture
         if (h->prm.smoother == 1) CHK(ensure_d(A[l]));
+    if (g.multi() && h->prm.use_graph && h->coarse_local && !h->coarse_host_driven && !std::getenv("SAENA_NO_TAIL_GRAPH")) {
+        auto halo_free = [](const sgpu_op *o) { return o->vIndexSize == 0 && o->recvSize == 0; };
+        int Lt = nlevels;
+        for (int l = nlevels - 1; l >= 1; --l) {
+            if (!halo_free(A[l]) || (l < nlevels - 1 && (!halo_free(P[l]) || !halo_free(R[l])))) break;
+            Lt = l;
+        }
+        if (Lt < nlevels && A[Lt]->M > 0) h->tail_level = Lt;      // (a rank without rows there has nothing to launch anyway)
+    }
     const size_t n0 = (size_t)A[0]->M;
     HIPCHK(alloc(&h->alt0, n0));
     HIPCHK(alloc(&h->r, n0)); HIPCHK(alloc(&h->rho, n0)); HIPCHK(alloc(&h->hh, n0)); HIPCHK(alloc(&h->p, n0));

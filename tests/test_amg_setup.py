@@ -89,12 +89,25 @@ def test_chebyshev_eig_estimate():
 
 
 # ---- multi-rank: redundant setup + per-level row partition (over gloo, no GPU) ----
-def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False):
+# agglomeration policies of the coarse levels (host/amg_setup.h), by environment:
+POLICIES = {
+    # round 1's rule: levels of <= 4096 rows live on rank 0, nothing else moves (keeps several distributed coarse levels at test size)
+    "rows4096": {"SAENA_SHRINK_CHAIN_US": "0", "SAENA_SHRINK_ROWS": "4096"},
+    # the default model (23 us exchange chain against the level's one-GPU time): at test size every coarse level goes to rank 0
+    "model": {},
+    # the same model with a 3.5 us chain, so that its intermediate rule fires at test size: groups of 2 ranks merge
+    # (ranks 0, 2 stay active) before the smallest levels go to rank 0
+    "stride": {"SAENA_SHRINK_CHAIN_US": "3.5"},
+}
+
+
+def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, policy="rows4096"):
     import os
     import sys
     import torch.distributed as dist
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
+    os.environ.update(POLICIES[policy])
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         from tests.test_host_layout import assert_layout_equal, oracle_layout
@@ -120,7 +133,20 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False):
         splits = [S.level_split(l) for l in range(S.num_levels)]
         np.testing.assert_array_equal(splits[0], A.split)
         assert any(np.all(s[1:] == s[-1]) for s in splits[1:]), "small levels must shrink onto rank 0"
-        assert any(len(set(s.tolist())) == world + 1 for s in splits[1:]), "a large coarse level must stay distributed"
+        owners = [[r for r in range(world) if s[r + 1] > s[r]] for s in splits]
+        if policy == "rows4096":
+            assert any(len(set(s.tolist())) == world + 1 for s in splits[1:]), "a large coarse level must stay distributed"
+        elif policy == "model":
+            assert all(o == [0] for o in owners[1:]), owners
+        else:
+            assert any(o == list(range(0, world, 2)) for o in owners[1:]), owners       # groups of 2 merged onto ranks 0, 2
+            assert all(set(owners[l + 1]) <= set(owners[l]) for l in range(len(owners) - 1)), owners   # agglomeration is monotone
+        def empty_in_the_middle(sp):      # an empty block followed by a non-empty one
+            ne = [sp[r + 1] > sp[r] for r in range(world)]
+            return any((not ne[r]) and any(ne[r + 1:]) for r in range(world))
+
+        import scipy.sparse as sp_
+        import torch
         for l in range(S.num_levels):
             assert splits[l][-1] == S1.level_info(l)["rows"]
             for which in ((0, 1, 2) if l < S.num_levels - 1 else (0,)):
@@ -129,10 +155,51 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False):
                 rs = splits[l] if which != 2 else splits[l + 1]
                 cs = splits[l] if which == 0 else (splits[l + 1] if which == 1 else splits[l])
                 nrows, ncols = rs[-1], cs[-1]
-                O = orc.OracleOp(ent, nrows, ncols, rs, cs, square=(which == 0))
-                want = oracle_layout(O, rank)
-                want.pop("col_remote")
-                assert_layout_equal(S.level_layout(l, which), want, f"level {l} op {which} rank {rank}")
+                got = S.level_layout(l, which)
+                if not (empty_in_the_middle(rs) or empty_in_the_middle(cs)):
+                    O = orc.OracleOp(ent, nrows, ncols, rs, cs, square=(which == 0))
+                    want = oracle_layout(O, rank)
+                    want.pop("col_remote")
+                    assert_layout_equal(got, want, f"level {l} op {which} rank {rank}")
+                    continue
+                # A partition whose owners are every k-th rank (k-rank agglomeration) is not one the reference -- hence the
+                # oracle -- can lay out: its owner search (aux_functions.h:39-58) returns the FIRST of equal split values,
+                # i.e. an empty rank, because the reference drops the idle ranks from the communicator instead
+                # (shrink_cpu).  These layouts are checked by what they compute: y = A x through the layout arrays with
+                # the halo moved over gloo by the layout's own send/recv plan, against the one-rank operator.
+                r_ = np.repeat(np.arange(glob["M"]), glob["nnzPerRow_local"])
+                Aglob = sp_.csr_matrix((glob["val_local"], (r_, glob["col_local"])), shape=(nrows, ncols))
+                xg = np.sin(0.37 * np.arange(ncols) + 0.1)
+                want_y = (Aglob @ xg)[rs[rank]:rs[rank + 1]]
+                bound = (abs(Aglob) @ abs(xg))[rs[rank]:rs[rank + 1]]
+                d = got
+                x = xg[cs[rank]:cs[rank + 1]]
+                M = d["M"]
+                assert M == rs[rank + 1] - rs[rank] and d["N_local"] == len(x) and d["col_offset"] == cs[rank]
+                rows_ = np.repeat(np.arange(M), d["nnzPerRow_local"])
+                y = np.bincount(rows_, weights=d["val_local"] * x[d["col_local"] - d["col_offset"]], minlength=M).astype(np.float64)
+                send = x[d["vIndex"]]
+                reqs, bufs, so, ro = [], [], 0, 0
+                for q, cnt in zip(d["sendProcRank"], d["sendProcCount"]):
+                    assert cs[q + 1] > cs[q] or rs[q + 1] > rs[q]
+                    reqs.append(dist.isend(torch.from_numpy(send[so:so + cnt].copy()), int(q)))
+                    so += cnt
+                for q, cnt in zip(d["recvProcRank"], d["recvProcCount"]):
+                    assert cs[q + 1] > cs[q], "a halo source must own columns"
+                    t = torch.empty(int(cnt), dtype=torch.float64)
+                    bufs.append(t)
+                    reqs.append(dist.irecv(t, int(q)))
+                for rq in reqs:
+                    rq.wait()
+                recv = np.concatenate([t.numpy() for t in bufs]) if bufs else np.zeros(0)
+                assert len(recv) == len(d["nnzPerCol_remote"])
+                if len(recv):
+                    slot = np.repeat(np.arange(len(recv)), d["nnzPerCol_remote"])
+                    y += np.bincount(d["row_remote"], weights=d["val_remote"] * recv[slot], minlength=M)
+                assert np.all(np.abs(y - want_y) <= 1e-13 * bound + 1e-300), f"level {l} op {which} rank {rank}"
+                if which == 0 and M:
+                    dg = Aglob.diagonal()[rs[rank]:rs[rank + 1]]
+                    np.testing.assert_array_equal(d["inv_diag"], 1.0 / dg)
         ret[rank] = "ok"
     except BaseException as e:      # noqa
         import traceback
@@ -141,9 +208,11 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,smoother,world,slab", [("rows", "jacobi", 3, False), ("rows", "chebyshev", 4, False), ("rows", "jacobi", 4, True),
-                                                      ("gathered", "jacobi", 2, False)])
-def test_distributed_hierarchy_gloo(mode, smoother, world, slab, monkeypatch):
+@pytest.mark.parametrize("mode,smoother,world,slab,policy", [("rows", "jacobi", 3, False, "rows4096"), ("rows", "chebyshev", 4, False, "rows4096"),
+                                                             ("rows", "jacobi", 4, True, "rows4096"), ("gathered", "jacobi", 2, False, "rows4096"),
+                                                             ("rows", "jacobi", 4, False, "model"), ("rows", "chebyshev", 4, False, "stride"),
+                                                             ("gathered", "jacobi", 4, False, "stride")])
+def test_distributed_hierarchy_gloo(mode, smoother, world, slab, policy, monkeypatch):
     """The hierarchy built over several ranks -- every rank building only its rows of every level (the default), or the
     older gather-then-slice form -- is the one-rank hierarchy bit for bit: every level's A, P and R layout equals the
     oracle's layout of the one-rank operator under that level's partition."""
@@ -155,7 +224,7 @@ def test_distributed_hierarchy_gloo(mode, smoother, world, slab, monkeypatch):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 30 if slab else 24, ret, smoother, slab)) for r in range(world)]
+        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 30 if slab else 24, ret, smoother, slab, policy)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:

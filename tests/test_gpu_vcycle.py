@@ -431,12 +431,18 @@ def test_distributed_hierarchy_reaches_the_device():
         assert res.get(r) == "ok", f"rank {r}: {res.get(r)}"
 
 
-def _transport_worker(rank, world, port, smoother, ret, float_level=3):
+# agglomeration policies of the coarse levels (host/amg_setup.h; tests/test_amg_setup.py POLICIES)
+POLICIES = {"rows4096": {"SAENA_SHRINK_CHAIN_US": "0", "SAENA_SHRINK_ROWS": "4096"}, "model": {}, "stride": {"SAENA_SHRINK_CHAIN_US": "3.5"}}
+
+
+def _transport_worker(rank, world, port, smoother, ret, float_level=3, policy="rows4096", env=None):
     import os
     import sys
     import torch.distributed as dist                      # torch first (its HIP runtime), like bench.py --gpus N
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
+    os.environ.update(POLICIES[policy])
+    os.environ.update(env or {})
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         from saena_amd import capi as c, host
@@ -447,8 +453,17 @@ def _transport_worker(rank, world, port, smoother, ret, float_level=3):
         S = host.AmgSolver(A, host.options(L, **dict(host.OPTIONS001, smoother=smoother, float_level=float_level))).to_device()
         u, it, hist, ok = S.solve_pCG(A.laplacian3D_rhs())
         u2, it2, hist2, ok2 = S.solve(A.laplacian3D_rhs())
+        # launches of one V-cycle on this rank (kernels + graph launches; the host transport has no RCCL groups)
+        M = A.num_local_rows
+        du, dr = c.DeviceVector(M, np.zeros(M)), c.DeviceVector(M, A.laplacian3D_rhs())
+        c.check(c.lib().sgpu_vcycle(S.device_handle(), du.ptr, dr.ptr))
+        n0 = c.launch_count()
+        c.check(c.lib().sgpu_vcycle(S.device_handle(), du.ptr, dr.ptr))
+        launches = c.launch_count() - n0
+        owners = [[r for r in range(world) if S.level_split(l)[r + 1] > S.level_split(l)[r]] for l in range(S.num_levels)]
         ret[rank] = ("ok", it, [float(h) for h in hist], bool(ok), it2, float(hist2[-1]), bool(ok2),
-                     [S.level_info(l)["rows"] for l in range(S.num_levels)], [int(x) for x in A.split])
+                     [S.level_info(l)["rows"] for l in range(S.num_levels)], [int(x) for x in A.split], launches, owners,
+                     u.tobytes())
     except BaseException as e:      # noqa
         import traceback
         ret[rank] = ("".join(traceback.format_exception(type(e), e, e.__traceback__)),)
@@ -456,16 +471,7 @@ def _transport_worker(rank, world, port, smoother, ret, float_level=3):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,smoother,float_level", [(3, "jacobi", 3), (4, "chebyshev", 3), (3, "jacobi", 0)],
-                         ids=["3-jacobi", "4-chebyshev", "3-jacobi-fp32-halos"])
-def test_multirank_solve_through_the_library(capi, world, smoother, float_level):
-    """The LIBRARY's multi-rank solve (sgpu_solve_pCG / sgpu_solve over the row-distributed hierarchy: interior and
-    boundary kernels, shrunk coarse levels, dense coarsest solve on rank 0, global dots) with several processes on
-    this one card, halos and reductions routed through gloo (sgpu_debug_init_host_transport) because RCCL needs one
-    device per rank.  Poisson 32^3, options001: the reference prints 7 iterations, 7.227341e+03 -> 2.246251e-05 with
-    Jacobi, the same digits at 1, 2 and 4 ranks (SURVEY.md 6).  (Its Chebyshev figure depends on the eigenvalue
-    estimates of that run -- the reference starts Lanczos from a random vector -- so the Chebyshev case is held
-    against this library's own one-rank solve instead.)"""
+def _run_transport(world, smoother, float_level=3, policy="rows4096", env=None):
     import multiprocessing as mp      # not torch's: this process already runs the system HIP runtime
     import socket
     with socket.socket() as sk:
@@ -474,7 +480,7 @@ def test_multirank_solve_through_the_library(capi, world, smoother, float_level)
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=_transport_worker, args=(r, world, port, smoother, ret, float_level)) for r in range(world)]
+        procs = [ctx.Process(target=_transport_worker, args=(r, world, port, smoother, ret, float_level, policy, env)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -485,7 +491,45 @@ def test_multirank_solve_through_the_library(capi, world, smoother, float_level)
         res = dict(ret)
     for r in range(world):
         assert res.get(r) and res[r][0] == "ok", f"rank {r}: {res.get(r)}"
-    _, it, hist, ok, it2, last2, ok2, rows, split = res[0]
+    return res
+
+
+def test_multirank_tail_of_the_vcycle_is_one_graph_launch(capi):
+    """Levels agglomerated onto rank 0 form a communication-free sub-V-cycle: rank 0 replays it as ONE captured graph
+    (fewer launches per V-cycle), the other ranks launch nothing for those levels, and the results are bit-identical
+    with the eager form (SAENA_NO_TAIL_GRAPH=1)."""
+    world = 3
+    a = _run_transport(world, "jacobi", policy="rows4096")
+    b = _run_transport(world, "jacobi", policy="rows4096", env={"SAENA_NO_TAIL_GRAPH": "1"})
+    owners = a[0][10]
+    n_tail = sum(1 for o in owners if o == [0])                       # levels living on rank 0 only
+    assert n_tail >= 2, owners
+    for r in range(world):
+        assert a[r][2] == b[r][2] and a[r][11] == b[r][11], "graph replay of the tail must not change a single bit"
+    # rank 0: every tail level but the last costs >= 8 launches eagerly (smoother sweeps, residual, R, P); as a graph the whole tail is 1
+    assert a[0][9] <= b[0][9] - 6 * (n_tail - 1), (a[0][9], b[0][9], owners)
+    assert all(a[r][9] == b[r][9] for r in range(1, world)), "ranks without rows of the tail launch nothing for it either way"
+
+
+@pytest.mark.parametrize("world,smoother,float_level,policy", [(3, "jacobi", 3, "rows4096"), (4, "chebyshev", 3, "rows4096"), (3, "jacobi", 0, "rows4096"),
+                                                               (4, "jacobi", 3, "model"), (4, "jacobi", 3, "stride"), (4, "chebyshev", 3, "stride")],
+                         ids=["3-jacobi", "4-chebyshev", "3-jacobi-fp32-halos", "4-jacobi-model", "4-jacobi-stride", "4-chebyshev-stride"])
+def test_multirank_solve_through_the_library(capi, world, smoother, float_level, policy):
+    """The LIBRARY's multi-rank solve (sgpu_solve_pCG / sgpu_solve over the row-distributed hierarchy: interior and
+    boundary kernels, shrunk coarse levels, dense coarsest solve on rank 0, global dots) with several processes on
+    this one card, halos and reductions routed through gloo (sgpu_debug_init_host_transport) because RCCL needs one
+    device per rank.  Poisson 32^3, options001: the reference prints 7 iterations, 7.227341e+03 -> 2.246251e-05 with
+    Jacobi, the same digits at 1, 2 and 4 ranks (SURVEY.md 6).  (Its Chebyshev figure depends on the eigenvalue
+    estimates of that run -- the reference starts Lanczos from a random vector -- so the Chebyshev case is held
+    against this library's own one-rank solve instead.)  Policies: round 1's row rule, the default cost model (every
+    coarse level of this small problem on rank 0) and the k-rank agglomeration (ranks 0 and 2 of 4 stay active on the
+    middle levels: operators whose halo partners are every second rank)."""
+    res = _run_transport(world, smoother, float_level, policy)
+    _, it, hist, ok, it2, last2, ok2, rows, split, launches, owners, _u = res[0]
+    if policy == "model":
+        assert all(o == [0] for o in owners[1:]), owners
+    if policy == "stride":
+        assert [0, 2] in owners, owners
     assert all(res[r][1:7] == res[0][1:7] for r in range(world)), "every rank must report the same global history"
     assert rows == [27000, 13500, 1420, 253, 69]
     assert ok and it == 7
