@@ -151,7 +151,7 @@ def _clustered_operator(M, N, clusters, seed):
     return orc.coo_from_arrays(rows.astype(np.int32), cols.astype(np.int32), vals)
 
 
-@pytest.mark.parametrize("clusters,split_expected", [(40, "wider"), (6, "4+12")])
+@pytest.mark.parametrize("clusters,split_expected", [(40, "wider"), (4, "4+12")])
 def test_compressed_columns_slot_offset_split(capi, clusters, split_expected):
     """The 16-bit column form picks its slot/offset split per operator: 4+12 bits when a block's columns sit in <= 16
     segments of 4096, more slots of smaller segments (down to 8+8) when they sit in many short clusters far apart -- and
