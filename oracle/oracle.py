@@ -101,6 +101,7 @@ def lib():
         L.orc_op_free.argtypes = [C.POINTER(Op)]
         for f in ("orc_matvec", "orc_matvec_float"):
             getattr(L, f).argtypes = [C.POINTER(Op), _PD, _PD]
+        L.orc_matvec_dense.argtypes = [C.POINTER(Op), _PD, _PD, C.c_int]
         for f in ("orc_residual", "orc_residual_negative"):
             getattr(L, f).argtypes = [C.POINTER(Op), _PD, _PD, _PD]
         L.orc_jacobi.argtypes = [C.POINTER(Op), C.c_int, _PD, _PD]
@@ -231,6 +232,13 @@ class OracleOp:
         v = np.ascontiguousarray(v, np.float64)
         w = np.empty(self.Mbig)
         lib().orc_matvec_float(self.p, _pd(v), _pd(w))
+        return w
+
+    def matvec_dense(self, v, as_float=False):
+        """saena_matrix_dense::matvec_dense(_float) on the dense form of this (square) operator"""
+        v = np.ascontiguousarray(v, np.float64)
+        w = np.empty(self.Mbig)
+        lib().orc_matvec_dense(self.p, _pd(v), _pd(w), 1 if as_float else 0)
         return w
 
     def residual(self, u, rhs):

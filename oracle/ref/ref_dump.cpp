@@ -22,9 +22,11 @@
 //   saena_matrix::residual                include/saena_matrix.tpp:16-23
 //   prolong_matrix::findLocalRemote/matvec   src/prolong_matrix.cpp:18-378, :489-624
 //   restrict_matrix::transposeP/matvec    src/restrict_matrix.cpp:10-494, :612-744
+//   saena_matrix_dense::convert_saena_matrix / matvec_dense(_float)   src/saena_matrix_dense.cpp:763-793, :181-340
 #include "saena_matrix.h"
 #include "prolong_matrix.h"
 #include "restrict_matrix.h"
+#include "saena_matrix_dense.h"
 
 #include <cmath>
 #include <cstdio>
@@ -224,6 +226,15 @@ int main(int argc, char **argv) {
 
         A.matvec_sparse_float(v2.data(), w.data());
         write_raw(pfx + "Av2_float", "f64", gather_d(w.data(), M));
+
+        if (A.Mbig <= 4000) {     // the reference's dense storage of the same operator (`switch_to_dense`), ring GEMV
+            saena_matrix_dense D;
+            D.convert_saena_matrix(&A);
+            D.matvec_dense(v2.data(), w.data());
+            write_raw(pfx + "Av2_dense", "f64", gather_d(w.data(), M));
+            D.matvec_dense_float(v2.data(), w.data());
+            write_raw(pfx + "Av2_dense_float", "f64", gather_d(w.data(), M));
+        }
 
         if (light) {
             if (!g_rank) printf("%s np=%d Mbig=%d nnz_g=%ld  |Av|^2=%.16g\n", tag.c_str(), g_np, (int)A.Mbig, (long)A.nnz_g, pins[0]);

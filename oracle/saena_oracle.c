@@ -760,3 +760,33 @@ double orc_time_matvec(orc_op *op, const value_t *v, value_t *w, int reps, int t
 double orc_time_jacobi(orc_op *op, value_t *u, const value_t *rhs, int reps, int threads) {
     return tb_run(op, NULL, NULL, u, rhs, reps, threads, 1);
 }
+
+/* ---- dense storage (src/saena_matrix_dense.cpp) ---- */
+void orc_matvec_dense(orc_op *op, const value_t *v, value_t *w, int as_float) {
+    const int np = op->nprocs;
+    const index_t Nbig = op->Nbig;
+    for (int rank = 0; rank < np; ++rank) {
+        orc_rankop *R = &op->r[rank];
+        const index_t M = R->M;
+        /* convert_saena_matrix, :763-793: entry[(row - split[rank]) * Nbig + col] = val */
+        value_t *entry = xcalloc((size_t)(M > 0 ? M : 1) * (size_t)Nbig, sizeof(value_t));
+        nnz_t k = 0;
+        for (index_t i = 0; i < M; ++i)
+            for (index_t t = 0; t < R->nnzPerRow_local[i]; ++t, ++k) entry[(size_t)i * Nbig + R->col_local[k]] = R->val_local[k];
+        for (nnz_t q = 0; q < R->nnz_l_remote; ++q) entry[(size_t)R->row_remote[q] * Nbig + R->col_remote2[q]] = R->val_remote[q];
+        value_t *wl = w + R->row_ofst;
+        for (index_t i = 0; i < M; ++i) wl[i] = 0.0;                     /* :208 */
+        for (int kk = rank; kk < rank + np; ++kk) {                      /* :217 ring: own block first */
+            const int owner = kk % np;
+            const index_t jst = op->split_col[owner], jend = op->split_col[owner + 1] - jst;
+            for (index_t i = 0; i < M; ++i) {
+                const value_t *entry_p = entry + (size_t)i * Nbig + jst;
+                value_t tmp = 0;
+                if (as_float) for (index_t j = 0; j < jend; ++j) tmp += entry_p[j] * (value_t)(float)v[jst + j];   /* :318 v_p is float */
+                else          for (index_t j = 0; j < jend; ++j) tmp += entry_p[j] * v[jst + j];                 /* :243 */
+                wl[i] += tmp;
+            }
+        }
+        free(entry);
+    }
+}

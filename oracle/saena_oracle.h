@@ -118,6 +118,12 @@ void    orc_op_free(orc_op *op);
 void orc_matvec(orc_op *op, const value_t *v, value_t *w);
 /* src/saena_matrix_matvec.cpp:448-550 */
 void orc_matvec_float(orc_op *op, const value_t *v, value_t *w);
+/* saena_matrix_dense::convert_saena_matrix + matvec_dense / matvec_dense_float (src/saena_matrix_dense.cpp:763-793,
+ * :181-260, :262-340), the reference's optional `switch_to_dense` storage of a square operator: every rank holds its
+ * rows as a dense M x Mbig block and the x blocks travel round a ring; rank r adds, block by block starting with its
+ * own, tmp = sum_j A[i][j] x_owner[j] (ascending j) and then w[i] += tmp.  as_float != 0: EVERY block of x -- the
+ * rank's own included -- is rounded to float first (matvec_dense_float copies v into float buffers). */
+void orc_matvec_dense(orc_op *op, const value_t *v, value_t *w, int as_float);
 /* include/saena_matrix.tpp:16-43 */
 void orc_residual(orc_op *op, const value_t *u, const value_t *rhs, value_t *res);
 void orc_residual_negative(orc_op *op, const value_t *u, const value_t *rhs, value_t *res);

@@ -530,6 +530,30 @@ __global__ __launch_bounds__(BLOCK) void k_dense_rows(const SpmvArgs a, const do
     if (r < nrows && l == 0) epilogue<EPI, false>(a, r, sum);
 }
 
+// K1c with a halo: the row-partitioned dense operator.  The reference passes the x blocks round a ring, one
+// send/recv per step (matvec_dense, src/saena_matrix_dense.cpp:181-260); over xGMI one neighbour exchange costs ~20 us
+// whatever its size, so here every rank receives the blocks it needs in ONE grouped exchange (the operator's ordinary
+// halo plan) and then multiplies its dense rows: `dense` holds the columns this rank owns, `dense_rem` the columns of
+// the halo buffer (receive order).  fp32 wire: like matvec_dense_float (:262-340) EVERY block of x is rounded to
+// float, the rank's own included (the sparse float form rounds the halo only).
+template <int EPI>
+__global__ __launch_bounds__(BLOCK) void k_dense_rows_halo(const SpmvArgs a, const double *__restrict__ dense, const double *__restrict__ dense_rem,
+                                                           int nrows, int ncols, int nhalo, const double *__restrict__ halo,
+                                                           const float *__restrict__ halo_f, int x_float) {
+    const int r = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    double sum = 0.0;
+    if (r < nrows) {
+        const double *row = dense + (size_t)r * ncols;
+        if (x_float) { for (int j = l; j < ncols; j += 64) sum += row[j] * (double)(float)a.x[j]; }
+        else         { for (int j = l; j < ncols; j += 64) sum += row[j] * a.x[j]; }
+        const double *rrow = dense_rem + (size_t)r * nhalo;
+        if (halo_f) { for (int j = l; j < nhalo; j += 64) sum += rrow[j] * (double)halo_f[j]; }
+        else        { for (int j = l; j < nhalo; j += 64) sum += rrow[j] * halo[j]; }
+    }
+    sum = group_sum<64>(sum);
+    if (r < nrows && l == 0) epilogue<EPI, false>(a, r, sum);
+}
+
 // ---------------------------------------------------------------------------
 // K2: boundary rows.  Rows that own remote entries are left out of the interior launch (SpmvArgs::skip)
 // and computed whole by this kernel on the halo stream, after the exchange: G lanes own one row, add its

@@ -188,18 +188,24 @@ int build_part(CsrPart &P, const std::vector<int> &rp, const std::vector<int> &c
 
 // dense form of a small, mostly full operator (saena_matrix_dense: rows <= dense_sz_thre 5000 by default)
 constexpr int DENSE_MAX_ROWS = 8192;
+// Size limits only: at most 8192 rows and 64 M entries (512 MB) per rank.  WHEN the dense form is used is the caller's
+// policy -- saena::amg applies the reference's density rule (density > dense_thre and rows <= dense_sz_thre,
+// saena_object_setup2.cpp:328), the plan-time autotune tries it from 50 % fill on.
 bool dense_candidate(int nrows, int ncols, int64_t nnz) {
-    return nrows > 0 && ncols > 0 && nrows <= DENSE_MAX_ROWS && ncols <= DENSE_MAX_ROWS && (double)nnz >= 0.1 * (double)nrows * (double)ncols;
+    return nrows > 0 && ncols > 0 && nnz > 0 && nrows <= DENSE_MAX_ROWS && (int64_t)nrows * ncols <= (int64_t)DENSE_MAX_ROWS * DENSE_MAX_ROWS;
 }
 int build_dense(CsrPart &P) {
     if (P.dense) return SGPU_OK;
-    if (P.h_val.empty() || P.h_rp.empty()) return fail(SGPU_ERR_ARG, "this operator is too large or too sparse for the dense form");
+    if (P.h_val.empty() || P.h_rp.empty()) return fail(SGPU_ERR_ARG, "this operator is too large for the dense form (more than 8192 rows or 64 M entries on this rank)");
     std::vector<double> d((size_t)P.nrows * P.ncols, 0.0);
     for (int i = 0; i < P.nrows; ++i)
         for (int k = P.h_rp[i]; k < P.h_rp[i + 1]; ++k) d[(size_t)i * P.ncols + P.h_col[k]] = P.h_val[k];
     CHK(dev_upload(&P.dense, d.data(), d.size()));
     return SGPU_OK;
 }
+
+// the remote part of the dense form: M x recvSize over the receive buffer (zero rows for the rows without remote entries)
+int build_dense_rem(sgpu_op *op);
 
 // 16-bit compressed columns of plan k: (slot << ob) | (col & (2^ob - 1)) with <= 2^(16-ob) segment bases per block.
 // ob is the largest of 12..8 for which every block's distinct segments fit its slots (fewest table entries to read);
@@ -289,12 +295,15 @@ struct sgpu_op {
     bool    local_only_ok = false; // test hook: sgpu_debug_allow_local_only
     bool    single_stream = false; // exchange and rows on the compute stream, in order (short local kernels): apply() mode S
     std::string vname;            // sgpu_op_get_variant's kernel name (owns the string it returns)
+    double *dense_rem = nullptr;  // variant 5 with a halo: row-major M x recvSize over the receive buffer
+    std::vector<int> rem_rows_h;  // host copy of rem.rows (compact boundary row -> local row)
     std::vector<double> h_val;   // host copy of the values of small local parts (coarsest-level factorisation)
     unsigned *skip = nullptr;     // bitmask over the M rows: set = boundary row (has remote entries), written by k_csr_boundary
     int     bnd_lanes = 1;        // lanes per boundary row
     hipEvent_t ev_x = nullptr, ev_halo = nullptr;   // cs -> hs: inputs ready; hs -> cs: exchange + boundary rows done
     ~sgpu_op() {                  // also runs when sgpu_op_create bails out half-way: nothing leaks
         loc.free_all(); rem.free_all();
+        hipFree(dense_rem);
         hipFree(skip); hipFree(inv_diag); hipFree(tmp); hipFree(dvec); hipFree(vIndex); hipFree(send_buf); hipFree(recv_buf); hipFree(send_f); hipFree(recv_f);
         if (ev_x) hipEventDestroy(ev_x);
         if (ev_halo) hipEventDestroy(ev_halo);
@@ -302,6 +311,18 @@ struct sgpu_op {
 };
 
 namespace {
+
+int build_dense_rem(sgpu_op *op) {
+    if (op->dense_rem || !op->has_remote) return SGPU_OK;
+    if (op->rem.h_val.empty()) return fail(SGPU_ERR_ARG, "this operator is too large for the dense form");
+    const size_t nh = (size_t)op->recvSize;
+    std::vector<double> d((size_t)op->M * nh, 0.0);
+    // rem: CSR over the boundary rows (h_rows maps compact -> local row), columns = receive-buffer positions
+    for (int i = 0; i < op->rem.nrows; ++i)
+        for (int k = op->rem.h_rp[i]; k < op->rem.h_rp[i + 1]; ++k) d[(size_t)op->rem_rows_h[(size_t)i] * nh + op->rem.h_col[k]] = op->rem.h_val[k];
+    CHK(dev_upload(&op->dense_rem, d.data(), d.size()));
+    return SGPU_OK;
+}
 
 using KernelFn = void (*)(const sk::SpmvArgs);
 using VecKernelFn = void (*)(const sk::SpmvArgs, int);
@@ -459,6 +480,26 @@ BndKernelFn pick_bnd(int epi, int lanes) {
     }
 }
 
+// dense storage with a halo: all rows in one launch after the exchange (k_dense_rows_halo)
+int launch_dense_halo(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e, bool halo_is_f32, hipStream_t stream) {
+    if (op->M == 0) return SGPU_OK;
+    if (!op->loc.dense || !op->dense_rem) return fail(SGPU_ERR_STATE, "the dense form was not built");
+    sk::SpmvArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d; a.c0 = e.c0; a.c1 = e.c1; a.cc_ob = 12;
+    void (*kd)(const sk::SpmvArgs, const double *, const double *, int, int, int, const double *, const float *, int) =
+        epi == sk::EPI_SPMV ? sk::k_dense_rows_halo<sk::EPI_SPMV> : epi == sk::EPI_RESIDUAL ? sk::k_dense_rows_halo<sk::EPI_RESIDUAL>
+        : epi == sk::EPI_JACOBI ? sk::k_dense_rows_halo<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows_halo<sk::EPI_CHEBY0>
+        : epi == sk::EPI_CHEBYK ? sk::k_dense_rows_halo<sk::EPI_CHEBYK> : sk::k_dense_rows_halo<sk::EPI_SUB>;
+    SGPU_LAUNCH(kd, dim3((op->M + 3) / 4), dim3(sk::BLOCK), 0, stream, a, (const double *)op->loc.dense, (const double *)op->dense_rem,
+                (int)op->M, op->loc.ncols, op->recvSize, (const double *)op->recv_buf, halo_is_f32 ? (const float *)op->recv_f : (const float *)nullptr,
+                op->halo_fp32 ? 1 : 0);       // (an injected halo arrives as float-rounded doubles: halo_f null, x still rounded)
+    HIPCHK(hipGetLastError());
+    return SGPU_OK;
+}
+// the rows of an operator whose halo has arrived: interior rows + boundary rows, or the dense form's single launch
+int launch_rows_after_exchange(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e, bool f32, hipStream_t stream);
+
 // The rows that own remote entries, computed whole (local + halo products, one epilogue) on `stream`.
 int launch_boundary(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e, bool halo_is_f32, hipStream_t stream) {
     if (op->rem.nrows == 0) return SGPU_OK;
@@ -492,6 +533,13 @@ int exchange_group(sgpu_op *op, bool f32, hipStream_t st) {
     return SGPU_OK;
 }
 
+int launch_rows_after_exchange(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e, bool f32, hipStream_t stream) {
+    if (op->loc.variant == 5 && op->has_remote) return launch_dense_halo(op, epi, x, y, e, f32, stream);
+    CHK(launch_part(op->loc, epi, x, y, e, op->has_remote ? op->skip : nullptr));     // (always on cs: callers pass cs)
+    if (op->has_remote) CHK(launch_boundary(op, epi, x, y, e, f32, stream));
+    return SGPU_OK;
+}
+
 // Host-routed exchange: pack -> host -> callback -> device, then the same interior / boundary kernels, all on cs.
 int apply_host_transport(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     const bool f32 = op->halo_fp32 != 0;
@@ -509,8 +557,7 @@ int apply_host_transport(sgpu_op *op, int epi, const double *x, double *y, const
                hr.data(), op->recvRank.data(), op->recvCount.data(), (int)op->recvRank.size(), (int)eb) != 0)
         return fail(SGPU_ERR_RCCL, "host transport: exchange callback failed");
     if (op->recvSize) HIPCHK(hipMemcpyAsync(f32 ? (void *)op->recv_f : (void *)op->recv_buf, hr.data(), hr.size(), hipMemcpyHostToDevice, g.cs));
-    CHK(launch_part(op->loc, epi, x, y, e, op->has_remote ? op->skip : nullptr));
-    if (op->has_remote) CHK(launch_boundary(op, epi, x, y, e, f32, g.cs));
+    CHK(launch_rows_after_exchange(op, epi, x, y, e, f32, g.cs));
     HIPCHK(hipStreamSynchronize(g.cs));                  // the staging vectors die with this frame
     return SGPU_OK;
 }
@@ -526,10 +573,8 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     if (g.xchg && !op->injected && (op->vIndexSize || op->recvSize)) return apply_host_transport(op, epi, x, y, e);
     const bool exchanged = g.comm && !op->injected && (op->vIndexSize || op->recvSize);
     if (!exchanged) {
-        if (op->has_remote && op->injected) {           // halo supplied by the caller (tests): same kernels, one stream
-            CHK(launch_part(op->loc, epi, x, y, e, op->skip));
-            return launch_boundary(op, epi, x, y, e, false, g.cs);
-        }
+        if (op->has_remote && op->injected)             // halo supplied by the caller (tests): same kernels, one stream
+            return launch_rows_after_exchange(op, epi, x, y, e, false, g.cs);
         // an operator with remote entries but no way to fetch them (no communicator, no host transport, no injected
         // halo): the local part alone would be a silently wrong product (a binding that forgot the unique id, or a
         // 1-rank context fed N-rank layouts).  sgpu_debug_allow_local_only lifts this for plan/launch tests.
@@ -540,7 +585,7 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     }
     const bool f32 = op->halo_fp32 != 0;                 // both ends of a link must agree: the flag alone decides the wire type
     const unsigned *skip = op->has_remote ? op->skip : nullptr;
-    if (op->single_stream) {
+    if (op->single_stream || (op->loc.variant == 5 && op->has_remote)) {      // (the dense form has no interior/boundary split)
         // S  one stream.  A SHORT local kernel has nothing to hide the exchange behind, and the fork/join between the
         //    two streams then costs more than it overlaps: pack -> send/recv group -> interior rows -> boundary rows,
         //    all on cs, in stream order (4 enqueues instead of 6, no flag, no event; capturable in a hipGraph).
@@ -551,9 +596,7 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
             HIPCHK(hipGetLastError());
         }
         CHK(exchange_group(op, f32, g.cs));
-        CHK(launch_part(op->loc, epi, x, y, e, skip));
-        if (op->has_remote) CHK(launch_boundary(op, epi, x, y, e, f32, g.cs));
-        return SGPU_OK;
+        return launch_rows_after_exchange(op, epi, x, y, e, f32, g.cs);
     }
     const uint64_t n = ++g.seq;
     // Three ways to express the two dependencies (fork: hs after cs's earlier work; join: cs after hs), fastest first:
@@ -942,7 +985,8 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         std::vector<double> val(d->val_local, d->val_local + d->nnz_l_local);
         CHK(build_part(op->loc, rp, col, val, nullptr));
         op->loc.ncols = d->N_local;
-        if (dense_candidate(d->M, d->N_local, d->nnz_l_local)) op->loc.h_val = val;
+        // (whole operator: local + remote entries against the columns this rank reads, owned + halo)
+        if (dense_candidate(d->M, d->N_local + d->col_remote_size, d->nnz_l_local + d->nnz_l_remote)) op->loc.h_val = val;
         if (d->M <= sk::CG_MAXN) op->h_val = val;
     }
     // remote part: CSC over the receive buffer -> CSR over the halo buffer on the rows that own remote entries
@@ -968,6 +1012,7 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
                 col[fillp[s]] = j; val[fillp[s]] = d->val_remote[k]; fillp[s]++;
             }
         CHK(build_part(op->rem, rp, col, val, &rows));
+        if (!op->loc.h_val.empty()) { op->rem.h_val = val; op->rem_rows_h = rows; }      // a dense form is still possible
         op->has_remote = true;
         // boundary rows: masked out of the interior launch, computed whole by k_csr_boundary
         std::vector<unsigned> mask(((size_t)d->M + 31) / 32, 0u);
@@ -1088,8 +1133,8 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
     if (variant < 0 || variant > 6) return fail(SGPU_ERR_ARG, "variant must be 0..6");
     if (variant == 5) {
-        if (op->has_remote) return fail(SGPU_ERR_ARG, "the dense form serves operators without a halo");
         CHK(build_dense(op->loc));
+        CHK(build_dense_rem(op));
     } else if (variant == 3 || variant == 4) {
         CHK(build_cc16(op->loc, variant - 3));
         if (!op->loc.cc_ok[variant - 3]) return fail(SGPU_ERR_ARG, "a row block of this operator touches more than 256 column segments of 256 columns");

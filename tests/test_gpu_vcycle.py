@@ -432,7 +432,9 @@ def test_distributed_hierarchy_reaches_the_device():
 
 
 # agglomeration policies of the coarse levels (host/amg_setup.h; tests/test_amg_setup.py POLICIES)
-POLICIES = {"rows4096": {"SAENA_SHRINK_CHAIN_US": "0", "SAENA_SHRINK_ROWS": "4096"}, "model": {}, "stride": {"SAENA_SHRINK_CHAIN_US": "3.5"}}
+POLICIES = {"rows4096": {"SAENA_SHRINK_CHAIN_US": "0", "SAENA_SHRINK_ROWS": "4096"}, "model": {}, "stride": {"SAENA_SHRINK_CHAIN_US": "3.5"},
+            # keep the 1420-row level (12.8 % full) row-partitioned and store it dense: the dense operator WITH a halo
+            "dense_halo": {"SAENA_SHRINK_CHAIN_US": "0", "SAENA_SHRINK_ROWS": "300", "TEST_SWITCH_TO_DENSE": "1"}}
 
 
 def _transport_worker(rank, world, port, smoother, ret, float_level=3, policy="rows4096", env=None):
@@ -450,9 +452,13 @@ def _transport_worker(rank, world, port, smoother, ret, float_level=3, policy="r
         L = host.load("gpu")
         comm = host.Comm("gpu", "dist", dist)
         A = host.Matrix(comm).laplacian3D(32).assemble()   # the reference's nnz-balanced partition
-        S = host.AmgSolver(A, host.options(L, **dict(host.OPTIONS001, smoother=smoother, float_level=float_level))).to_device()
+        kw = dict(host.OPTIONS001, smoother=smoother, float_level=float_level)
+        if os.environ.get("TEST_SWITCH_TO_DENSE"):
+            kw.update(switch_to_dense=1, dense_thre=0.1, dense_sz_thre=5000)
+        S = host.AmgSolver(A, host.options(L, **kw)).to_device()
         u, it, hist, ok = S.solve_pCG(A.laplacian3D_rhs())
         u2, it2, hist2, ok2 = S.solve(A.laplacian3D_rhs())
+        variants = [S.device_op(l, 0).variant()[0] for l in range(S.num_levels)]
         # launches of one V-cycle on this rank (kernels + graph launches; the host transport has no RCCL groups)
         M = A.num_local_rows
         du, dr = c.DeviceVector(M, np.zeros(M)), c.DeviceVector(M, A.laplacian3D_rhs())
@@ -463,7 +469,7 @@ def _transport_worker(rank, world, port, smoother, ret, float_level=3, policy="r
         owners = [[r for r in range(world) if S.level_split(l)[r + 1] > S.level_split(l)[r]] for l in range(S.num_levels)]
         ret[rank] = ("ok", it, [float(h) for h in hist], bool(ok), it2, float(hist2[-1]), bool(ok2),
                      [S.level_info(l)["rows"] for l in range(S.num_levels)], [int(x) for x in A.split], launches, owners,
-                     u.tobytes())
+                     u.tobytes(), variants)
     except BaseException as e:      # noqa
         import traceback
         ret[rank] = ("".join(traceback.format_exception(type(e), e, e.__traceback__)),)
@@ -512,8 +518,10 @@ def test_multirank_tail_of_the_vcycle_is_one_graph_launch(capi):
 
 
 @pytest.mark.parametrize("world,smoother,float_level,policy", [(3, "jacobi", 3, "rows4096"), (4, "chebyshev", 3, "rows4096"), (3, "jacobi", 0, "rows4096"),
-                                                               (4, "jacobi", 3, "model"), (4, "jacobi", 3, "stride"), (4, "chebyshev", 3, "stride")],
-                         ids=["3-jacobi", "4-chebyshev", "3-jacobi-fp32-halos", "4-jacobi-model", "4-jacobi-stride", "4-chebyshev-stride"])
+                                                               (4, "jacobi", 3, "model"), (4, "jacobi", 3, "stride"), (4, "chebyshev", 3, "stride"),
+                                                               (3, "jacobi", 3, "dense_halo")],
+                         ids=["3-jacobi", "4-chebyshev", "3-jacobi-fp32-halos", "4-jacobi-model", "4-jacobi-stride", "4-chebyshev-stride",
+                              "3-jacobi-dense-level-with-halo"])
 def test_multirank_solve_through_the_library(capi, world, smoother, float_level, policy):
     """The LIBRARY's multi-rank solve (sgpu_solve_pCG / sgpu_solve over the row-distributed hierarchy: interior and
     boundary kernels, shrunk coarse levels, dense coarsest solve on rank 0, global dots) with several processes on
@@ -525,7 +533,9 @@ def test_multirank_solve_through_the_library(capi, world, smoother, float_level,
     coarse level of this small problem on rank 0) and the k-rank agglomeration (ranks 0 and 2 of 4 stay active on the
     middle levels: operators whose halo partners are every second rank)."""
     res = _run_transport(world, smoother, float_level, policy)
-    _, it, hist, ok, it2, last2, ok2, rows, split, launches, owners, _u = res[0]
+    _, it, hist, ok, it2, last2, ok2, rows, split, launches, owners, _u, variants = res[0]
+    if policy == "dense_halo":      # level 2 (1420 rows) stays on all 3 ranks and is stored dense there: k_dense_rows_halo ran in the solve
+        assert owners[2] == [0, 1, 2] and all(res[r][12][2] == 5 for r in range(world)), (owners, [res[r][12] for r in range(world)])
     if policy == "model":
         assert all(o == [0] for o in owners[1:]), owners
     if policy == "stride":

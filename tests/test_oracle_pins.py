@@ -120,6 +120,16 @@ def test_oracle_matches_reference(fn):
     # fp32 halo: identical float rounding of the halo, fp64 accumulate
     close_spmv(A.matvec_float(v2), ref["Av2_float"], v2, "A v2 (float halo)")
 
+    # dense storage of the same operator (saena_matrix_dense: `switch_to_dense`), ring GEMV; the float form rounds every
+    # block of x -- the rank's own too -- so it differs from the double form even at one rank
+    if "Av2_dense" in ref:
+        close_spmv(A.matvec_dense(v2), ref["Av2_dense"], v2, "dense A v2")
+        bound = _abs_bound(entries, Mbig, v2)
+        err = np.abs(A.matvec_dense(v2, as_float=True) - ref["Av2_dense_float"])
+        assert np.all(err <= TOL_SPMV * bound + 1e-300), "dense A v2 (float x)"
+        assert np.any(ref["Av2_dense_float"] != ref["Av2_dense"])
+        close_spmv(ref["Av2_dense"], ref["Av2"], v2, "the reference's dense and sparse forms agree")
+
     # squared-norm pins in the SURVEY 8c format
     pins = ref["pins"]
     assert abs(np.dot(A.matvec(v), A.matvec(v)) - pins[0]) <= 1e-12 * pins[0]
