@@ -483,7 +483,7 @@ BndKernelFn pick_bnd(int epi, int lanes) {
 // dense storage with a halo: all rows in one launch after the exchange (k_dense_rows_halo)
 int launch_dense_halo(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e, bool halo_is_f32, hipStream_t stream) {
     if (op->M == 0) return SGPU_OK;
-    if (!op->loc.dense || !op->dense_rem) return fail(SGPU_ERR_STATE, "the dense form was not built");
+    if (!op->loc.dense || (!op->dense_rem && op->has_remote)) return fail(SGPU_ERR_STATE, "the dense form was not built");
     sk::SpmvArgs a;
     memset(&a, 0, sizeof a);
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d; a.c0 = e.c0; a.c1 = e.c1; a.cc_ob = 12;
@@ -492,7 +492,7 @@ int launch_dense_halo(sgpu_op *op, int epi, const double *x, double *y, const Ep
         : epi == sk::EPI_JACOBI ? sk::k_dense_rows_halo<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows_halo<sk::EPI_CHEBY0>
         : epi == sk::EPI_CHEBYK ? sk::k_dense_rows_halo<sk::EPI_CHEBYK> : sk::k_dense_rows_halo<sk::EPI_SUB>;
     SGPU_LAUNCH(kd, dim3((op->M + 3) / 4), dim3(sk::BLOCK), 0, stream, a, (const double *)op->loc.dense, (const double *)op->dense_rem,
-                (int)op->M, op->loc.ncols, op->recvSize, (const double *)op->recv_buf, halo_is_f32 ? (const float *)op->recv_f : (const float *)nullptr,
+                (int)op->M, op->loc.ncols, op->has_remote ? op->recvSize : 0, (const double *)op->recv_buf, halo_is_f32 ? (const float *)op->recv_f : (const float *)nullptr,
                 op->halo_fp32 ? 1 : 0);       // (an injected halo arrives as float-rounded doubles: halo_f null, x still rounded)
     HIPCHK(hipGetLastError());
     return SGPU_OK;
@@ -581,6 +581,8 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
         if ((op->has_remote || op->recvSize) && !g.multi() && !op->local_only_ok)
             return fail(SGPU_ERR_STATE, "operator has %d halo entries but this context has no communicator (sgpu_init was given nranks=%d, no unique id)",
                         op->recvSize, g.nranks);
+        if (op->loc.variant == 5 && op->halo_fp32)      // matvec_dense_float rounds the rank's own block of x as well
+            return launch_dense_halo(op, epi, x, y, e, false, g.cs);
         return launch_part(op->loc, epi, x, y, e);      // no halo: the local part is the whole operator
     }
     const bool f32 = op->halo_fp32 != 0;                 // both ends of a link must agree: the flag alone decides the wire type
