@@ -13,9 +13,9 @@ rows on the halo stream).  value = algorithmic bytes of all ranks' SpMVs (BASELI
 / wall time.
 Workload at N>1 (BASELINE.json configs[3]): Poisson 512^3 row-partitioned by the reference's
 nnz-balanced partitioner (src/saena_matrix_repart.cpp:43-170).  At N=8 that is the whole 512^3
-operator (132 651 000 rows, 16.6 M rows / 116 M nnz per GPU); at N=2 and 4 the grid is
-512 x 512 x (round(510 N/8) + 2), i.e. every GPU keeps its 1/8-of-512^3-sized block (weak scaling),
-neighbours exchange one 510^2 plane (2 MB) per side.
+operator (132 651 000 rows, 16.6 M rows / 116 M nnz per GPU); at N=2 and 4 it is the cube that keeps
+those 16.6 M rows per GPU (323^3 and 407^3: weak scaling, isotropic like the 512^3 problem itself),
+neighbours exchange about one plane of the cube per side.
 
 Extra objects: `roofline` (HBM bound; kernel time from HIP events recorded on the compute stream
 around the timed launches; states whether the working set is Infinity-Cache resident),
@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--grid-m", "--m", dest="m", type=int, default=None, help="grid points per side (reference laplacian3D argument); default 128 at "
-                    "--gpus 1 (BASELINE configs[1]) and 512 at --gpus N>1 (configs[3]: rank r owns its 1/8-of-512^3-sized row block)")
+                    "--gpus 1 (BASELINE configs[1]) and 512 at --gpus N>1 (configs[3] at N=8; at N=2/4 the cube with the same rows per GPU)")
     ap.add_argument("--hbm-m", "--m-hbm", dest="m_hbm", type=int, default=256, help="grid of the secondary HBM-resident SpMV figure at --gpus 1 (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
@@ -309,12 +309,13 @@ def main():
     else:
         comm = host.Comm("gpu", "rccl")
     A = host.Matrix(comm)
-    if world == 1:
-        grid = (m, m, m)
-    else:                                                # this many ranks' worth of the m^3 problem's 8 row blocks
-        grid = (m, m, int(round((m - 2) * world / 8.0)) + 2)
+    if world == 1 or world == 8:
+        mg = m
+    else:                                                # the cube that gives every GPU the rows it holds at N = 8: (N/8)^(1/3) (m - 2) interior points per side
+        mg = int(round((world / 8.0) ** (1.0 / 3.0) * (m - 2))) + 2
+    grid = (mg, mg, mg)
     A.laplacian3D(*grid).assemble()                      # reference partitioner: nnz-balanced contiguous row blocks
-    grid_s = f"{grid[0]}^3" if grid[0] == grid[1] == grid[2] else f"{grid[0]}x{grid[1]}x{grid[2]}"
+    grid_s = f"{mg}^3"
 
     def sync_all():
         capi.check(capi.lib().sgpu_barrier())
@@ -366,11 +367,12 @@ def main():
                 "workload": (f"Poisson {grid_s} (Saena laplacian3D, boundary rows removed): SpMV w=Av, "
                              f"{info['M']} rows x {info['nnz_local'] + info['nnz_remote']} nnz on rank 0, int32 indices"
                              + ("; BASELINE configs[1]" if world == 1 and m == 128 else "")
-                             + (f"; BASELINE configs[3]: this is {world}/8 of the Poisson {m}^3 operator, one 1/8-sized row block per GPU"
+                             + (f"; BASELINE configs[3] (Poisson {m}^3 over 8 GPUs)" + ("" if world == 8 else
+                                f" weak-scaled to {world} GPUs: the cube with the same {(m - 2) ** 3 // 8} rows per GPU")
                                 if world > 1 else "")),
                 "rows_per_gpu": rows_all, "nnz_per_gpu": info["nnz_local"] + info["nnz_remote"],
                 "partition": "1 rank" if world == 1 else
-                             f"{world} nnz-balanced contiguous row blocks (reference partitioner), RCCL halo of <= {grid[0] - 2}^2 doubles per side "
+                             f"{world} nnz-balanced contiguous row blocks (reference partitioner), RCCL halo of ~{grid[0] - 2}^2 doubles per side "
                              f"(remote nnz per rank {halo_all})",
                 "pct_of_hbm_peak": round(B_total / sec_per_step / 1e9 / (HBM_PEAK_GBS * world) * 100, 2),
             },

@@ -41,7 +41,8 @@ def _bench_rehearsal(nproc, extra, timeout=900):
 
 def test_bench_two_ranks_rehearsal():
     """stdout must be ONE JSON line whose SpMV self-check -- halo values included -- passes; the workload is the
-    N/8 share of the m^3 problem under the reference partitioner (configs[3] at m = 512, N = 8; m = 128 here)."""
+    cube with the per-GPU rows of the m^3 problem over 8 GPUs, under the reference partitioner (configs[3] at m = 512,
+    N = 8; m = 128 here)."""
     import json
     out = _bench_rehearsal(2, ["--grid-m", "128", "--no-vcycle"])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
@@ -49,7 +50,7 @@ def test_bench_two_ranks_rehearsal():
     assert len(lines) == 1, out.stdout[-3000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
-    assert sum(d["config"]["rows_per_gpu"]) == 126 * 126 * 32 and "128x128x34" in d["metric"]      # round(126 * 2 / 8) = 32 planes
+    assert sum(d["config"]["rows_per_gpu"]) == 79 ** 3 and "81^3" in d["metric"]      # (2/8)^(1/3) x 126 = 79.4 interior points per side
     assert d["check"]["ok"] is True, d["check"]
     assert d["roofline"]["traffic_measured_in_run"] in (None, False) and "working_set_bytes" in d["roofline"]
 
