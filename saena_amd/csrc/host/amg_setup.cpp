@@ -131,9 +131,20 @@ Csr transpose(const Csr &A) {
 // |v| <= ALMOST_ZERO are dropped unless row id == column id, the rule of the reference's SpGEMM
 // output (saena_object_setup_matmat.cpp:2423,2442).
 // row_offset: global id of row 0 (distributed setup: the "row id == column id" exemption is about GLOBAL ids)
+} // namespace
+// C = A B on the GPU when libsaena_amd.so has a device context (sgpu_spgemm.hip installs this; bit-identical result)
+spgemm_hook_fn g_spgemm_hook = nullptr;
+namespace {
+
 Csr spgemm(const Csr &A, const Csr &B, index_t row_offset = 0) {
     Csr C;
     C.nrows = A.nrows; C.ncols = B.ncols;
+    if (g_spgemm_hook && (A.col.size() + B.col.size()) >= 200000 && A.nrows > 0 && B.nrows > 0) {
+        if (g_spgemm_hook(A.nrows, B.nrows, B.ncols, A.ptr.data(), A.col.data(), A.val.data(), B.ptr.data(), B.col.data(), B.val.data(),
+                          row_offset, C.ptr, C.col, C.val) == 0)
+            return C;
+        C.ptr.clear(); C.col.clear(); C.val.clear();       // the GPU declined (memory): the host kernel below
+    }
     // work estimate per row for load balance
     std::vector<nnz_t> work((size_t)A.nrows + 1, 0);
     for (index_t i = 0; i < A.nrows; ++i) {

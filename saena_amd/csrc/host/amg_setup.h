@@ -13,6 +13,14 @@
 
 namespace saena_host {
 
+// Optional accelerator for the setup's sparse products C = A B (CSR in, CSR out, rows sorted by column, the drop rule of
+// the host kernel).  libsaena_amd.so installs its GPU kernel here when a device context exists; returns 0 on success,
+// non-zero to decline (the host kernel then runs).  nullptr in libsaena_host.so.
+typedef int (*spgemm_hook_fn)(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int *a_col, const double *a_val,
+                              const long *b_ptr, const int *b_col, const double *b_val, int row_offset,
+                              std::vector<long> &c_ptr, std::vector<int> &c_col, std::vector<double> &c_val);
+extern spgemm_hook_fn g_spgemm_hook;
+
 // saena::options (reference include/saena.hpp:127-193; defaults :151-155)
 struct amg_options {
     int         solver_max_iter = 100;

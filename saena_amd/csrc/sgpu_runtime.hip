@@ -25,6 +25,8 @@
 #include <thread>
 #include <vector>
 
+extern "C" void sgpu_install_spgemm_hook(int on);
+
 namespace {
 
 thread_local std::string g_err;
@@ -860,6 +862,7 @@ int sgpu_init(int device_id, int rank, int nranks, const void *uid) {
         NCCLCHK(ncclCommInitRank(&g.comm, nranks, id, rank));
     }
     g.live = true;
+    sgpu_install_spgemm_hook(1);         // the AMG setup's Galerkin products run on this device from now on (sgpu_spgemm.hip)
     return SGPU_OK;
 }
 
@@ -875,6 +878,7 @@ int sgpu_debug_init_host_transport(int device_id, int rank, int nranks, sgpu_hos
 
 int sgpu_finalize(void) {
     if (!g.live) return SGPU_OK;
+    sgpu_install_spgemm_hook(0);
     hipDeviceSynchronize();
     if (g.comm) { ncclCommDestroy(g.comm); g.comm = nullptr; }
     hipFree(g.partials); hipFree(g.dscalar); hipHostFree(g.hscalar); hipFree(g.dint); hipHostFree(g.hint);
