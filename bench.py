@@ -187,7 +187,7 @@ def pmc_traffic(m, world, kernel_name):
     """Memory-side bytes per launch from the COMMITTED rocprofv3 PMC passes of this same command (PMC counters cannot
     be read from inside the process, so this is never a measurement of the present run: the line says so with
     `traffic_measured_in_run: false`).  Only for the kernel those passes profiled; None for anything else."""
-    table = {"k_csr_cc16<16KiB,4+12>": "r01_pmc_spmv_128_cc16.json", "k_csr_stream<16KiB>": "r01_pmc_spmv_128.json"}
+    table = {"k_csr_cc16<16KiB,4+12>": "r02_pmc_spmv_128_cc16.json", "k_csr_stream<16KiB>": "r01_pmc_spmv_128.json"}
     name = table.get(kernel_name)
     path = os.path.join(ROOT, "profiles", name) if name else None
     if m == 128 and world == 1 and path and os.path.exists(path):

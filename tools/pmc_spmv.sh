@@ -11,7 +11,7 @@ export SAENA_BENCH_VARIANT=$V
 i=0
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum; do   # one counter per pass: pairs exceed the hardware
     i=$((i+1))
-    timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $D/pass$i -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-vcycle > $D/pass$i.log 2>&1
+    timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $D/pass$i -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-vcycle --hbm-m 0 > $D/pass$i.log 2>&1
 done
 python3 tools/pmc_summarise.py $D $V > $OUT
 cat $OUT
