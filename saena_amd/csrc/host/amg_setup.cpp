@@ -677,7 +677,20 @@ void amg_hierarchy::distribute(Comm &c, const std::vector<index_t> &split0) {
         const auto &roots = levels[l - 1].roots;                // splitNew[r] = #roots below the fine boundary
         for (int r = 1; r < np; ++r)
             sp[r] = (index_t)(std::lower_bound(roots.begin(), roots.end(), dist[l - 1].split[r]) - roots.begin());
-        level_stride[(size_t)l] = next_stride((long)levels[l].A->nnz_g, rows, np, level_stride[(size_t)l - 1]);
+        const int stride_prev = level_stride[(size_t)l - 1];
+        level_stride[(size_t)l] = next_stride((long)levels[l].A->nnz_g, rows, np, stride_prev);
+        const int active = (np + stride_prev - 1) / stride_prev;
+        if (level_stride[(size_t)l] < np && active > 1 && rows >= active && !std::getenv("SAENA_NO_COARSE_REPART")) {
+            // Ac->repart(): nnz-balanced over the active ranks (the whole operator is here: every rank counts its own rows'
+            // share so that the histogram's sum over the ranks is the global one)
+            const auto &npr = levels[l].A->L.nnzPerRow_local;
+            SelfComm self;
+            const std::vector<index_t> sa = nnz_balanced_split(self, rows, levels[l].A->nnz_g, active, [&](const std::vector<index_t> &firstSplit, std::vector<long> &H) {
+                const int nb = (int)H.size();
+                for (index_t i = 0; i < rows; ++i) H[(size_t)lower_bound2(firstSplit.data(), firstSplit.data() + nb, i)] += npr[(size_t)i];
+            });
+            for (int r = 0; r <= np; ++r) sp[(size_t)r] = sa[(size_t)std::min(active, (r + stride_prev - 1) / stride_prev)];
+        }
         dist[l].split = merge_split(sp, level_stride[(size_t)l]);
     }
     for (int l = 0; l < n; ++l) {
@@ -842,15 +855,19 @@ std::vector<cooEntry> csr_entries_colmajor(const Csr &M, index_t row_lo) {
     return e;
 }
 
-// every row of this rank's block goes to rank `dest`; returns the rows this rank receives, concatenated in source-rank
-// order (blocks are ascending row ranges held by ascending ranks, so the result is the merged block in row order)
-Csr rehome_rows(Comm &c, const Csr &X, int dest) {
+// the rows of this rank's block [row_lo, row_lo + X.nrows) go to their owners under `split_to`; returns the rows this
+// rank receives, concatenated in source-rank order (blocks are ascending row ranges held by ascending ranks and owners
+// are contiguous ranges, so the result is this rank's new block in row order)
+Csr route_rows(Comm &c, const Csr &X, index_t row_lo, const std::vector<index_t> &split_to) {
     const int np = c.nranks;
     std::vector<int> scr((size_t)np, 0), sce((size_t)np, 0);
     std::vector<nnz_t> len((size_t)X.nrows);
-    for (index_t i = 0; i < X.nrows; ++i) len[i] = X.ptr[i + 1] - X.ptr[i];
-    scr[(size_t)dest] = X.nrows;
-    sce[(size_t)dest] = (int)X.col.size();
+    for (index_t i = 0; i < X.nrows; ++i) {
+        len[i] = X.ptr[i + 1] - X.ptr[i];
+        const int d = owner_of_id(split_to, row_lo + i);
+        scr[(size_t)d]++;
+        sce[(size_t)d] += (int)len[i];
+    }
     const std::vector<nnz_t> rlen = c.alltoallv_records(len, scr);
     Csr Y;
     Y.ncols = X.ncols;
@@ -859,7 +876,7 @@ Csr rehome_rows(Comm &c, const Csr &X, int dest) {
     Y.nrows = (index_t)rlen.size();
     Y.ptr.assign((size_t)Y.nrows + 1, 0);
     for (index_t i = 0; i < Y.nrows; ++i) Y.ptr[i + 1] = Y.ptr[i] + rlen[i];
-    if ((size_t)Y.ptr[Y.nrows] != Y.col.size()) throw std::runtime_error("rehome_rows: length mismatch");
+    if ((size_t)Y.ptr[Y.nrows] != Y.col.size()) throw std::runtime_error("route_rows: length mismatch");
     return Y;
 }
 
@@ -1213,7 +1230,9 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         }
         pt.lap("filter");
 
-        // ---- agglomeration (amg_setup.h): merge the blocks of consecutive ranks, move R's and Ac's rows to the group's first rank ----
+        // ---- the coarse operator's final partition (amg_setup.h): nnz-balanced over the ranks still active (the reference's
+        //      Ac->repart(), saena_matrix_repart.cpp:728-980), then agglomerated (decide_shrinking / shrink_set_params);
+        //      R's and Ac's rows move to their owners, P's columns are laid out on the same partition ----
         {
             long nnzC = (long)AcN.col.size();
             c.allreduce_sum_i64(&nnzC, 1);
@@ -1221,16 +1240,29 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             const int stride_prev = level_stride[(size_t)l];
             const int stride = next_stride(nnzC, new_size, np, stride_prev);
             level_stride.push_back(stride);
-            if (stride > stride_prev) {
-                splitC = merge_split(splitNew, stride);
-                const int root = stride >= np ? 0 : me - me % stride;
-                R = rehome_rows(c, R, root);
-                AcN = rehome_rows(c, AcN, root);
-                clo = splitC[me]; chi = splitC[me + 1];
-                if (R.nrows != chi - clo || AcN.nrows != chi - clo) throw std::runtime_error("agglomeration: merged block has the wrong size");
-                if (std::getenv("SAENA_SETUP_TIMING") && me == 0)
-                    fprintf(stderr, "[setup L%d] level %d (%d rows, %ld nnz) agglomerated: rank stride %d -> %d\n", l, l + 1, new_size, nnzC, stride_prev, stride);
+            std::vector<index_t> splitB = splitNew;
+            const int active = (np + stride_prev - 1) / stride_prev;
+            if (stride < np && active > 1 && new_size >= active && !std::getenv("SAENA_NO_COARSE_REPART")) {
+                const std::vector<index_t> sa = nnz_balanced_split(c, new_size, nnzC, active, [&](const std::vector<index_t> &firstSplit, std::vector<long> &H) {
+                    const int nb = (int)H.size();
+                    for (index_t i = 0; i < AcN.nrows; ++i)
+                        H[(size_t)lower_bound2(firstSplit.data(), firstSplit.data() + nb, i + clo)] += (long)(AcN.ptr[i + 1] - AcN.ptr[i]);
+                });
+                // part a of the active ranks is rank a * stride_prev; the idle ranks in between keep empty blocks
+                for (int r = 0; r <= np; ++r) {
+                    const int a = std::min(active, (r + stride_prev - 1) / stride_prev);
+                    splitB[(size_t)r] = sa[(size_t)a];
+                }
             }
+            splitC = merge_split(splitB, stride);
+            if (splitC != splitNew) {
+                R = route_rows(c, R, clo, splitC);
+                AcN = route_rows(c, AcN, clo, splitC);
+                clo = splitC[me]; chi = splitC[me + 1];
+                if (R.nrows != chi - clo || AcN.nrows != chi - clo) throw std::runtime_error("coarse repartition: a block has the wrong size");
+            }
+            if (stride > stride_prev && std::getenv("SAENA_SETUP_TIMING") && me == 0)
+                fprintf(stderr, "[setup L%d] level %d (%d rows, %ld nnz) agglomerated: rank stride %d -> %d\n", l, l + 1, new_size, nnzC, stride_prev, stride);
             pt.lap("agglomeration");
         }
         // ---- this level's transfer operators in the reference's layout ----

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <fstream>
+#include <functional>
 #include <numeric>
 #include <iomanip>
 #include <sstream>
@@ -299,46 +300,55 @@ void saena_matrix::setup_initial_data() {
     nnz_g = c.sum(nnz_l);
 }
 
-// repartition_nnz_initial (saena_matrix_repart.cpp:43-170): nprocs^2 near-equal
-// row buckets, merged left to right until a rank holds ~nnz_g/nprocs entries.
+// The reference's nnz-balanced row partition (repartition_nnz_initial, saena_matrix_repart.cpp:43-170; the same
+// algorithm re-partitions every coarse operator, saena_matrix::repart, :728-980): nparts^2 near-equal row buckets, merged
+// left to right until a part holds ~nnz_g/nparts entries.  `add_local_histogram(firstSplit, H)` adds this rank's
+// entries per bucket; the histogram is summed over the ranks here.
+std::vector<index_t> nnz_balanced_split(Comm &c, index_t Mbig, nnz_t nnz_g, int nparts,
+                                        const std::function<void(const std::vector<index_t> &, std::vector<long> &)> &add_local_histogram) {
+    std::vector<index_t> split((size_t)nparts + 1, 0);
+    if (nparts == 1) { split[1] = Mbig; return split; }
+    int n_buckets;
+    if (Mbig > nparts * nparts) n_buckets = nparts < 1000 ? nparts * nparts : 1000 * nparts;
+    else if (nparts <= Mbig) n_buckets = Mbig;
+    else throw std::runtime_error("number of tasks cannot be greater than the number of rows of the matrix.");
+    std::vector<index_t> splitOffset((size_t)n_buckets, 0);
+    const index_t baseOffset = (index_t)std::floor(1.0 * Mbig / n_buckets);
+    const float offsetRes = float(1.0 * Mbig / n_buckets) - baseOffset;
+    float offsetResSum = 0;
+    for (index_t i = 1; i < n_buckets; ++i) {
+        splitOffset[i] = baseOffset;
+        offsetResSum += offsetRes;
+        if (offsetResSum >= 1) { splitOffset[i]++; offsetResSum -= 1; }
+    }
+    std::vector<index_t> firstSplit((size_t)n_buckets + 1, 0);
+    for (index_t i = 1; i < n_buckets; ++i) firstSplit[i] = firstSplit[i - 1] + splitOffset[i];
+    firstSplit[n_buckets] = Mbig;
+    std::vector<long> H((size_t)n_buckets, 0);
+    add_local_histogram(firstSplit, H);
+    c.allreduce_sum_i64(H.data(), n_buckets);
+    for (int i = 1; i < n_buckets; ++i) H[i] += H[i - 1];
+    const nnz_t NNZ_PROC = nnz_g / nparts;
+    index_t procNum = 0;
+    for (nnz_t i = 1; i < n_buckets; ++i) {
+        if (Mbig - firstSplit[i + 1] < nparts - (procNum + 1)) {
+            for (; i < n_buckets; ++i) { procNum++; split[procNum] = firstSplit[i]; }
+            break;
+        }
+        if (H[i] > (procNum + 1) * NNZ_PROC) { ++procNum; split[procNum] = firstSplit[i]; }
+    }
+    for (index_t p = procNum + 1; p < nparts; ++p) split[p] = Mbig;      // (parts the loop never reached stay empty)
+    split[nparts] = Mbig;
+    return split;
+}
+
 void saena_matrix::repartition_nnz_initial() {
     Comm &c = *comm;
     const int nprocs = c.nranks;
-    split.assign((size_t)nprocs + 1, 0);
-    if (nprocs == 1) {
-        split[1] = Mbig;
-    } else {
-        int n_buckets;
-        if (Mbig > nprocs * nprocs) n_buckets = nprocs < 1000 ? nprocs * nprocs : 1000 * nprocs;
-        else if (nprocs <= Mbig) n_buckets = Mbig;
-        else throw std::runtime_error("number of tasks cannot be greater than the number of rows of the matrix.");
-        std::vector<index_t> splitOffset((size_t)n_buckets, 0);
-        const index_t baseOffset = (index_t)std::floor(1.0 * Mbig / n_buckets);
-        const float offsetRes = float(1.0 * Mbig / n_buckets) - baseOffset;
-        float offsetResSum = 0;
-        for (index_t i = 1; i < n_buckets; ++i) {
-            splitOffset[i] = baseOffset;
-            offsetResSum += offsetRes;
-            if (offsetResSum >= 1) { splitOffset[i]++; offsetResSum -= 1; }
-        }
-        std::vector<index_t> firstSplit((size_t)n_buckets + 1, 0);
-        for (index_t i = 1; i < n_buckets; ++i) firstSplit[i] = firstSplit[i - 1] + splitOffset[i];
-        firstSplit[n_buckets] = Mbig;
-        std::vector<long> H((size_t)n_buckets, 0);
+    split = nnz_balanced_split(c, Mbig, nnz_g, nprocs, [this](const std::vector<index_t> &firstSplit, std::vector<long> &H) {
+        const int n_buckets = (int)H.size();
         for (const auto &e : entry) H[lower_bound2(firstSplit.data(), firstSplit.data() + n_buckets, e.row)]++;
-        c.allreduce_sum_i64(H.data(), n_buckets);
-        for (int i = 1; i < n_buckets; ++i) H[i] += H[i - 1];
-        const nnz_t NNZ_PROC = nnz_g / nprocs;
-        index_t procNum = 0;
-        for (nnz_t i = 1; i < n_buckets; ++i) {
-            if (Mbig - firstSplit[i + 1] < nprocs - (procNum + 1)) {
-                for (; i < n_buckets; ++i) { procNum++; split[procNum] = firstSplit[i]; }
-                break;
-            }
-            if (H[i] > (procNum + 1) * NNZ_PROC) { ++procNum; split[procNum] = firstSplit[i]; }
-        }
-        split[nprocs] = Mbig;
-    }
+    });
     // move the entries to their owners (saena_matrix_repart.cpp:293 MPI_Alltoallv) and sort column-major
     entry = route(c, std::move(entry), split, [](const cooEntry &e) { return e.row; });
     sort_col_major(entry);

@@ -9,6 +9,7 @@
 #pragma once
 #include "comm.h"
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,11 @@ inline bool row_major(const cooEntry &a, const cooEntry &b) { return a.row != b.
 
 // index of the block of `split` that holds val (aux_functions.h:39-58, lower_bound2)
 long lower_bound2(const index_t *left, const index_t *right, index_t val);
+
+// the reference's nnz-balanced contiguous row partition (saena_matrix_repart.cpp:43-170 for the fine operator, :728-980
+// for every coarse one): see saena_matrix.cpp
+std::vector<index_t> nnz_balanced_split(Comm &c, index_t Mbig, nnz_t nnz_g, int nparts,
+                                        const std::function<void(const std::vector<index_t> &, std::vector<long> &)> &add_local_histogram);
 
 // The halo plan + local/remote split shared by A, R and P.
 struct DistLayout {

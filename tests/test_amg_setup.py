@@ -141,6 +141,20 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, polic
         else:
             assert any(o == list(range(0, world, 2)) for o in owners[1:]), owners       # groups of 2 merged onto ranks 0, 2
             assert all(set(owners[l + 1]) <= set(owners[l]) for l in range(len(owners) - 1)), owners   # agglomeration is monotone
+        # the coarse operators are re-partitioned by nnz over the ranks that still own rows (the reference's Ac->repart()):
+        # every owner of a distributed coarse level holds about its share of the level's entries
+        import torch
+        for l in range(1, S.num_levels):
+            own = owners[l]
+            if len(own) < 2:
+                continue
+            d = S.level_layout(l, 0)
+            mine = torch.tensor([float(len(d["col_local"]) + len(d["row_remote"]))], dtype=torch.float64)
+            allv = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(allv, mine)
+            per = np.array([float(t[0]) for t in allv])[own]
+            assert per.max() <= 1.6 * per.mean(), (l, per)
+
         def empty_in_the_middle(sp):      # an empty block followed by a non-empty one
             ne = [sp[r + 1] > sp[r] for r in range(world)]
             return any((not ne[r]) and any(ne[r + 1:]) for r in range(world))
