@@ -22,8 +22,8 @@ around the timed launches; states whether the working set is Infinity-Cache resi
 `spmv_hbm_resident` (N=1: the same measurement on Poisson 256^3, 1.7 GB, beyond the 256 MiB cache;
 per-GPU work of configs[3]), `check` (one more SpMV, outside the timed region, against the
 host-formed product incl. halo values), `vcycle` (pCG iterations/s and V-cycles/s on the global
-128^3 problem, host-built hierarchy; strong-scaled for N>1), `vcycle_config4` (N>1: the same on
-the 512^3-share operator) and `cpu_baseline` (the compiled reference's own matvec under mpirun on
+128^3 problem, host-built hierarchy; strong-scaled for N>1), `vcycle_config4` (N>1, opt-in with
+--config4-vcycle: the same on the configs[3] operator) and `cpu_baseline` (the compiled reference's own matvec under mpirun on
 this box's cores -- oracle/_ref, test infrastructure -- or the oracle's restatement as fallback;
 rank 0, N=1 only; never part of the measured path).
 
@@ -55,7 +55,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
     ap.add_argument("--vcycle-timeout", type=float, default=420.0, help="watchdog of the multi-rank V-cycle legs, seconds")
-    ap.add_argument("--no-config4-vcycle", action="store_true", help="N>1: skip the V-cycle leg on the 512^3-share operator (host setup of 16.6 M rows per rank)")
+    ap.add_argument("--config4-vcycle", action="store_true",
+                    help="N>1: also run the V-cycle / pCG leg on the configs[3] operator itself.  Off by default: the row-distributed host "
+                         "setup of 16.6 M rows per rank takes ~4 min over the gloo setup collectives (profiles/r02_bench_n2_323_*.json), "
+                         "which would put the whole run beyond a few minutes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -460,7 +463,10 @@ def main():
             leg["partition"] = f"{world} nnz-balanced row blocks of the global Poisson {128 if m >= 128 else m}^3 operator"
             legs["vcycle"] = leg
             A2.free()
-            if not args.no_config4_vcycle:
+            if not args.config4_vcycle:
+                legs["vcycle_config4"] = {"skipped": "opt-in (--config4-vcycle): the host setup of this operator's hierarchy takes ~4 min at 16.6 M rows "
+                                                     "per rank; rehearsed at that size in profiles/r02_bench_n2_323_gpu_spgemm.json"}
+            else:
                 capi.check(fatal(line("the configs[3] V-cycle leg ended with a fatal signal").encode()))
                 # (2) configs[3]: the operator of the SpMV measurement above (16.6 M rows per GPU at m = 512); every
                 #     rank builds only its rows of the hierarchy (row-distributed setup)

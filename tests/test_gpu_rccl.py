@@ -59,7 +59,7 @@ def test_bench_four_ranks_rehearsal_with_vcycle_legs():
     """the whole --gpus 4 run (both V-cycle legs over the row-distributed hierarchies) through the host transport:
     exit status 0, the 128^3 strong leg reproduces the reference's printed line"""
     import json
-    out = _bench_rehearsal(4, ["--grid-m", "64"], timeout=1200)
+    out = _bench_rehearsal(4, ["--grid-m", "64", "--config4-vcycle"], timeout=1200)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
     assert "vcycle_error" not in d
