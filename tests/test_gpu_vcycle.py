@@ -223,6 +223,52 @@ def test_full_pipeline_poisson32_matches_reference_pins(capi):
     assert conv2 and it2 == it2_o and np.all(np.abs(hist2 - hist2_o) <= TOL_HIST * hist2_o[0])
 
 
+def test_large_coarsest_level_falls_back_to_the_host_driven_cg(capi):
+    """A hierarchy cut off early (max_level = 1: the coarsest level of Poisson 24^3 has 5 324 rows) exceeds what the
+    LDS-resident coarsest solvers hold (1 024 rows).  The reference's solve_coarsest_CG has no size limit
+    (src/saena_object_solve.cpp:14-114): the library falls back to the host-driven CG over the device kernels -- for the
+    'direct' setting too -- instead of refusing the hierarchy (round-1 advisor finding)."""
+    from saena_amd import host
+    from tests.test_amg_setup import oracle_amg_from_host
+    L = host.load("gpu")
+    A = host.Matrix(host.Comm("gpu", "rccl")).laplacian3D(24).assemble()
+    S = host.AmgSolver(A, host.options(L, **dict(host.OPTIONS001, dynamic_levels=0, max_level=1))).to_device()
+    assert S.num_levels == 2 and S.level_info(1)["rows"] > 1024
+    rhs = A.laplacian3D_rhs()
+    u, it, hist, conv = S.solve_pCG(rhs)
+    assert conv
+    amg, OA = oracle_amg_from_host(S, "jacobi", pre=3, post=3, max_iter=50, tol=1e-8)      # the oracle's coarsest solve is the reference's CG
+    u_o, it_o, hist_o = amg.solve_pCG(rhs)
+    assert it_o == it and np.all(np.abs(hist - hist_o) <= TOL_HIST * hist_o[0])
+    assert rel(u, u_o) <= 1e-9
+
+
+def test_retuning_an_operator_drops_the_captured_graphs(capi, hier):
+    """sgpu_op_autotune / set_variant free and replace plan buffers a captured V-cycle graph launches kernels on: the
+    graphs are dropped (plan generation) and recaptured, never replayed on freed memory (round-1 advisor finding)"""
+    O, G, _, (GA, GP, GR) = build(capi, hier, "jacobi")
+    n = GA[0].M
+    rhs = inputs.rhs2(n)
+    dr = capi.DeviceVector(n, rhs)
+    du = capi.DeviceVector(n, np.zeros(n))
+    G.vcycle(du, dr)                                    # captures the graph
+    first = du.download()
+    for op in GA:
+        for v in (1, 3, 4, 0):                          # builds and frees compressed-column plans
+            try:
+                op.set_variant(v)
+            except capi.SgpuError:
+                pass
+        op.set_lanes_per_row(1)
+    GA[1].autotune()
+    for op in GA:
+        op.set_variant(0)
+        op.set_lanes_per_row(0)
+    du.upload(np.zeros(n))
+    G.vcycle(du, dr)                                    # must recapture
+    assert rel(du.download(), first) <= 1e-12
+
+
 def test_cpp_surface_poisson_driver(capi, tmp_path):
     """examples/poisson.cpp drives include/saena.hpp (saena::matrix / vector / options / amg) exactly like the
     reference's experiments/Poisson.cpp; its printed residuals must be the reference's."""
