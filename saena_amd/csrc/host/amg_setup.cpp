@@ -844,17 +844,6 @@ Csr relabel_cols(const Csr &M, index_t lo, index_t hi, const FetchPlan &plan, in
     return R;
 }
 
-// the local rows of M as global-id entries in column-major order (counting sort by column: rows stay ascending)
-std::vector<cooEntry> csr_entries_colmajor(const Csr &M, index_t row_lo) {
-    std::vector<nnz_t> cnt((size_t)M.ncols + 1, 0);
-    for (index_t cidx : M.col) cnt[(size_t)cidx + 1]++;
-    for (index_t j = 0; j < M.ncols; ++j) cnt[j + 1] += cnt[j];
-    std::vector<cooEntry> e(M.col.size());
-    for (index_t i = 0; i < M.nrows; ++i)
-        for (nnz_t k = M.ptr[i]; k < M.ptr[i + 1]; ++k) e[(size_t)cnt[M.col[k]]++] = cooEntry(i + row_lo, M.col[k], M.val[k]);
-    return e;
-}
-
 // the rows of this rank's block [row_lo, row_lo + X.nrows) go to their owners under `split_to`; returns the rows this
 // rank receives, concatenated in source-rank order (blocks are ascending row ranges held by ascending ranks and owners
 // are contiguous ranges, so the result is this rank's new block in row order)
@@ -1003,7 +992,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             long nn = (long)A.col.size();
             c.allreduce_sum_i64(&nn, 1);
             d.nnzA = nn;
-            d.A.build(c, csr_entries_colmajor(A, lo), split, split);
+            d.A.build_from_csr(c, A.ptr, A.col, A.val, split, split);
         }
         pt.lap("layout of A");
         if (l == max_level) break;
@@ -1271,8 +1260,8 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             long nn = (long)P.col.size();
             c.allreduce_sum_i64(&nn, 1);
             d.nnzP = nn;
-            d.P.build(c, csr_entries_colmajor(P, lo), split, splitC);
-            d.R.build(c, csr_entries_colmajor(R, clo), splitC, split);
+            d.P.build_from_csr(c, P.ptr, P.col, P.val, split, splitC);
+            d.R.build_from_csr(c, R.ptr, R.col, R.val, splitC, split);
         }
         // ---- next level ----
         std::vector<value_t> invd((size_t)(chi - clo), 1.0);

@@ -498,6 +498,12 @@ void DistLayout::build(Comm &c, const std::vector<cooEntry> &entry, const std::v
                 col_local[k] = entry[k2].col; val_local[k] = entry[k2].val;
             }
     }
+    finish_plan(c, split_col);
+}
+
+// the halo plan from what the classification left: recvCount, nnzPerProcScan (per rank), vElement_remote
+void DistLayout::finish_plan(Comm &c, const std::vector<index_t> &split_col) {
+    const int nprocs = c.nranks, rank = c.rank;
     for (int p = 1; p < nprocs + 1; ++p) nnzPerProcScan[p] += nnzPerProcScan[p - 1];   // :948-950
 
     sendCount = c.alltoall_one(recvCount);                               // :953 MPI_Alltoall
@@ -516,6 +522,63 @@ void DistLayout::build(Comm &c, const std::vector<cooEntry> &entry, const std::v
     recvSize   = rdispls[nprocs - 1] + recvCount[nprocs - 1];
     vIndex = c.alltoallv_records(vElement_remote, recvCount);            // :1030 MPI_Alltoallv
     for (auto &x : vIndex) x -= split_col[rank];                         // :1044-1046
+}
+
+// The same layout straight from this rank's rows as CSR (global columns, ascending inside a row) -- what the
+// row-distributed AMG setup holds.  build() wants the entries column-major and counting-sorts the local ones back to
+// row-major: two passes over 16 B per entry that this form skips (the local part IS the CSR minus the remote entries;
+// only the remote entries, a thin halo, are sorted by column).  Same arrays as build(), bit for bit.
+void DistLayout::build_from_csr(Comm &c, const std::vector<nnz_t> &ptr, const std::vector<index_t> &col, const std::vector<value_t> &val,
+                                const std::vector<index_t> &split_row, const std::vector<index_t> &split_col) {
+    const int nprocs = c.nranks, rank = c.rank;
+    *this = DistLayout();
+    M = split_row[rank + 1] - split_row[rank];
+    N_local = split_col[rank + 1] - split_col[rank];
+    col_offset = split_col[rank];
+    if ((index_t)ptr.size() != M + 1) throw std::runtime_error("build_from_csr: row count does not match the partition");
+    const index_t lo = split_col[rank], hi = split_col[rank + 1];
+    nnzPerRow_local.assign((size_t)M, 0);
+    recvCount.assign((size_t)nprocs, 0);
+    nnzPerProcScan.assign((size_t)nprocs + 1, 0);
+    struct Rem { index_t col, row; value_t val; };
+    std::vector<Rem> rem;
+    nnz_t nloc = 0;
+    for (index_t i = 0; i < M; ++i)
+        for (nnz_t k = ptr[i]; k < ptr[i + 1]; ++k) {
+            if (col[k] >= lo && col[k] < hi) { ++nnzPerRow_local[i]; ++nloc; }
+            else rem.push_back({col[k], i, val[k]});
+        }
+    nnz_l_local = nloc;
+    col_local.resize((size_t)nloc); val_local.resize((size_t)nloc);
+    {
+        nnz_t q = 0;
+        for (index_t i = 0; i < M; ++i)
+            for (nnz_t k = ptr[i]; k < ptr[i + 1]; ++k)
+                if (col[k] >= lo && col[k] < hi) { col_local[(size_t)q] = col[k]; val_local[(size_t)q] = val[k]; ++q; }
+    }
+    std::sort(rem.begin(), rem.end(), [](const Rem &a, const Rem &b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
+    size_t i = 0;
+    while (i < rem.size()) {                                             // the remote half of :828-859
+        const long procNum = owner_of(split_col, rem[i].col);
+        const size_t tmp = i;
+        while (i < rem.size() && rem[i].col < split_col[procNum + 1]) {
+            vElement_remote.push_back(rem[i].col);
+            ++recvCount[procNum];
+            nnzPerCol_remote.push_back(0);
+            do {
+                col_remote.push_back((index_t)vElement_remote.size() - 1);
+                col_remote2.push_back(rem[i].col);
+                row_remote.push_back(rem[i].row);
+                val_remote.push_back(rem[i].val);
+                ++nnzPerCol_remote.back();
+            } while (++i < rem.size() && rem[i].col == rem[i - 1].col);
+        }
+        nnzPerProcScan[procNum + 1] = (nnz_t)(i - tmp);
+    }
+    nnz_l_remote = (nnz_t)row_remote.size();
+    col_remote_size = (index_t)vElement_remote.size();
+    recvCount[rank] = 0;
+    finish_plan(c, split_col);
 }
 
 void DistLayout::build_single_rank(index_t M_, index_t N_, const std::vector<nnz_t> &ptr, std::vector<index_t> &&col,

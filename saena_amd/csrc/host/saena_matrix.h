@@ -62,6 +62,10 @@ struct DistLayout {
     // entry: this rank's rows, column-major sorted, GLOBAL row and column ids.
     void build(Comm &comm, const std::vector<cooEntry> &entry, const std::vector<index_t> &split_row,
                const std::vector<index_t> &split_col);
+    // the same from this rank's rows as CSR (global columns ascending inside a row): no column-major detour
+    void build_from_csr(Comm &comm, const std::vector<nnz_t> &ptr, const std::vector<index_t> &col, const std::vector<value_t> &val,
+                        const std::vector<index_t> &split_row, const std::vector<index_t> &split_col);
+    void finish_plan(Comm &comm, const std::vector<index_t> &split_col);
     // one rank: everything is local, so the layout IS the row-major CSR (no exchange, no sort)
     void build_single_rank(index_t M_, index_t N_, const std::vector<nnz_t> &ptr, std::vector<index_t> &&col,
                            std::vector<value_t> &&val);
