@@ -1015,15 +1015,29 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         { const std::vector<value_t> h = planA.values(c, maxPerRow); maxExt.insert(maxExt.end(), h.begin(), h.end()); }
         std::vector<nnz_t> sptr((size_t)nloc + 1, 0);
         std::vector<index_t> scol;                       // ext positions
-        for (index_t i = 0; i < nloc; ++i) {
-            for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+        {   // two passes over the rows on threads: count the strong connections per row, then fill
+            auto strong = [&](index_t i, nnz_t k) {
                 const index_t j = A.col[k];
                 value_t s_, st;
                 if (i + lo == j) { s_ = 1; st = 1; }
                 else { s_ = -A.val[k] / maxPerRow[i]; st = -A.val[k] / maxExt[(size_t)aext[(size_t)k]]; }
-                if (s_ > opts.connStrength || st > opts.connStrength) scol.push_back(aext[(size_t)k]);
-            }
-            sptr[i + 1] = (nnz_t)scol.size();
+                return s_ > opts.connStrength || st > opts.connStrength;
+            };
+            parallel_rows(nloc, &A.ptr, [&](int, index_t r0, index_t r1) {
+                for (index_t i = r0; i < r1; ++i) {
+                    nnz_t cnt = 0;
+                    for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) cnt += strong(i, k) ? 1 : 0;
+                    sptr[(size_t)i + 1] = cnt;
+                }
+            });
+            for (index_t i = 0; i < nloc; ++i) sptr[(size_t)i + 1] += sptr[(size_t)i];
+            scol.resize((size_t)sptr[(size_t)nloc]);
+            parallel_rows(nloc, &A.ptr, [&](int, index_t r0, index_t r1) {
+                for (index_t i = r0; i < r1; ++i) {
+                    nnz_t q = sptr[(size_t)i];
+                    for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) if (strong(i, k)) scol[(size_t)q++] = aext[(size_t)k];
+                }
+            });
         }
         pt.lap("strength graph");
 
@@ -1145,22 +1159,40 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         { const std::vector<index_t> h = planA.values(c, aggc); aggcExt.insert(aggcExt.end(), h.begin(), h.end()); }
         Csr P;
         P.nrows = nloc; P.ncols = new_size; P.ptr.assign((size_t)nloc + 1, 0);
-        {
-            std::vector<std::pair<index_t, value_t>> row;
-            for (index_t i = 0; i < nloc; ++i) {
-                row.clear();
-                for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
-                    value_t vtmp = -om * inv_diag[i] * A.val[k];
-                    if (i + lo == A.col[k]) vtmp += 1;
-                    row.emplace_back(aggcExt[(size_t)aext[(size_t)k]], vtmp);
+        {   // rows are independent: chunks of rows on threads (per-thread output, concatenated in row order)
+            const int T = n_threads();
+            std::vector<std::vector<index_t>> tcol((size_t)T);
+            std::vector<std::vector<value_t>> tval((size_t)T);
+            std::vector<index_t> tlo((size_t)T, 0), thi((size_t)T, 0);
+            std::vector<nnz_t> rowlen((size_t)nloc, 0);
+            parallel_rows(nloc, &A.ptr, [&](int t, index_t r0, index_t r1) {
+                tlo[(size_t)t] = r0; thi[(size_t)t] = r1;
+                std::vector<std::pair<index_t, value_t>> row;
+                auto &oc = tcol[(size_t)t];
+                auto &ov = tval[(size_t)t];
+                for (index_t i = r0; i < r1; ++i) {
+                    row.clear();
+                    for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+                        value_t vtmp = -om * inv_diag[i] * A.val[k];
+                        if (i + lo == A.col[k]) vtmp += 1;
+                        row.emplace_back(aggcExt[(size_t)aext[(size_t)k]], vtmp);
+                    }
+                    std::stable_sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+                    nnz_t cnt = 0;
+                    for (size_t q = 0; q < row.size(); ++q) {
+                        value_t v = row[q].second;
+                        while (q + 1 < row.size() && row[q + 1].first == row[q].first) v += row[++q].second;
+                        if (std::fabs(v) > SAENA_ALMOST_ZERO) { oc.push_back(row[q].first); ov.push_back(v); ++cnt; }
+                    }
+                    rowlen[(size_t)i] = cnt;
                 }
-                std::stable_sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-                for (size_t q = 0; q < row.size(); ++q) {
-                    value_t v = row[q].second;
-                    while (q + 1 < row.size() && row[q + 1].first == row[q].first) v += row[++q].second;
-                    if (std::fabs(v) > SAENA_ALMOST_ZERO) { P.col.push_back(row[q].first); P.val.push_back(v); }
-                }
-                P.ptr[i + 1] = (nnz_t)P.col.size();
+            });
+            for (index_t i = 0; i < nloc; ++i) P.ptr[i + 1] = P.ptr[i] + rowlen[(size_t)i];
+            P.col.resize((size_t)P.ptr[nloc]); P.val.resize((size_t)P.ptr[nloc]);
+            for (int t = 0; t < T; ++t) {
+                if (thi[(size_t)t] <= tlo[(size_t)t]) continue;
+                std::copy(tcol[(size_t)t].begin(), tcol[(size_t)t].end(), P.col.begin() + P.ptr[tlo[(size_t)t]]);
+                std::copy(tval[(size_t)t].begin(), tval[(size_t)t].end(), P.val.begin() + P.ptr[tlo[(size_t)t]]);
             }
         }
         pt.lap("smoothed P");
