@@ -60,6 +60,7 @@ def parse():
                          "setup of 16.6 M rows per rank takes ~4 min over the gloo setup collectives (profiles/r02_bench_n2_323_*.json), "
                          "which would put the whole run beyond a few minutes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
+    ap.add_argument("--spmv-timeout", type=float, default=300.0, help="N>1: watchdog of the SpMV measurement itself, seconds")
     return ap.parse_args()
 
 
@@ -326,7 +327,22 @@ def main():
             dist.barrier()
 
     # ---- warm-up, then EXACTLY K timed steps between barriers ----
+    # (N > 1: the first exchange between two DEVICES happens in here -- it has only ever run through a 1-rank communicator
+    #  and the host transport.  A hang must not look like a long run: a watchdog ends the process non-zero with a reason.)
+    spmv_dog = None
+    if world > 1:
+        import threading
+
+        def spmv_bail():
+            print(f"bench.py rank {rank}: the multi-GPU SpMV measurement did not finish within {args.spmv_timeout:.0f} s "
+                  "(halo exchange over RCCL hung?)", file=sys.stderr, flush=True)
+            os._exit(4)
+        spmv_dog = threading.Timer(args.spmv_timeout, spmv_bail)
+        spmv_dog.daemon = True
+        spmv_dog.start()
     R = measure_spmv(capi, host, np, A, rank, args.steps, args.warmup, sync_all)
+    if spmv_dog is not None:
+        spmv_dog.cancel()
     op, info, kernel_name, ms_kernel, wall, B_local = R["op"], R["info"], R["kernel_name"], R["ms_kernel"], R["wall"], R["B_local"]
 
     err, _ = verify_spmv(np, host, A, op, R["x"], R["y"], R["g0"])        # outside the timed region

@@ -296,6 +296,7 @@ struct sgpu_op {
     bool    injected = false;     // test hook: halo supplied by sgpu_debug_inject_halo
     bool    local_only_ok = false; // test hook: sgpu_debug_allow_local_only
     bool    single_stream = false; // exchange and rows on the compute stream, in order (short local kernels): apply() mode S
+    bool    events_only = false;   // long interior kernel: the two streams are ordered by plain events (apply() mode E)
     std::string vname;            // sgpu_op_get_variant's kernel name (owns the string it returns)
     double *dense_rem = nullptr;  // variant 5 with a halo: row-major M x recvSize over the receive buffer
     std::vector<int> rem_rows_h;  // host copy of rem.rows (compact boundary row -> local row)
@@ -620,8 +621,12 @@ int apply(sgpu_op *op, int epi, const double *x, double *y, const EpiArgs &e) {
     if (g.peer_seen.size() != (size_t)g.nranks) g.peer_seen.assign((size_t)g.nranks, 0);
     for (int r : op->sendRank) if (!(g.peer_seen[(size_t)r] & 1)) { fresh_peer = true; g.peer_seen[(size_t)r] |= 1; }
     for (int r : op->recvRank) if (!(g.peer_seen[(size_t)r] & 2)) { fresh_peer = true; g.peer_seen[(size_t)r] |= 2; }
-    const bool K = g.inkernel_sync && op->loc.nblk > 0 && !fresh_peer;
-    const bool V = g.value_ops && !fresh_peer;
+    // A LONG interior kernel hides the whole exchange chain whichever way the streams are ordered (16.6 M rows per GPU,
+    // configs[3]: ~290 us of interior work against a 48 us chain in the plainest mode), so such operators take plain
+    // events: nothing polls, nothing depends on co-residency.  The polling forms earn their keep in between.
+    const bool plain = fresh_peer || op->events_only;
+    const bool K = g.inkernel_sync && op->loc.nblk > 0 && !plain;
+    const bool V = g.value_ops && !plain;
     if (K) {
         CHK(launch_part(op->loc, epi, x, y, e, skip, n));
     } else {
@@ -1081,6 +1086,9 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         long thr = 1000 * 1000;
         if (const char *e = std::getenv("SAENA_SINGLE_STREAM_NNZ")) thr = std::atol(e);
         op->single_stream = (long)d->nnz_l_local < thr;
+        long ev = 30L * 1000 * 1000;       // 12 B x 30 M nnz / 5 TB/s = 72 us of interior work: the event-ordered chain (~48 us) hides behind it
+        if (const char *e2 = std::getenv("SAENA_EVENT_SYNC_NNZ")) ev = std::atol(e2);
+        op->events_only = (long)d->nnz_l_local >= ev;
     }
     // same-device dependencies only: no system-scope fence needed (saves ~2 us per hop, tools/hop_bench.hip)
     HIPCHK(hipEventCreateWithFlags(&op->ev_x, hipEventDisableTiming | hipEventDisableSystemFence));
