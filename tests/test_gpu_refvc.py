@@ -74,3 +74,78 @@ def test_gpu_transfers_at_the_reference_partitions(capi, fn, fp32):
             WP.g[r].spmv(es[r], fs[r])
         bound = refvc.abs_product(hier, "P", l, e)
         assert np.all(np.abs(WP.gather(fs) - ref[f"P{l}_ec{sfx}"]) <= TOL_TRANSFER * bound + 1e-300), f"P{l}{sfx}"
+
+
+def _refvc_worker(rank, world, port, fn, ret):
+    import os
+    import sys
+    import torch.distributed as dist                      # torch first (its HIP runtime), like bench.py --gpus N
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["SAENA_NO_AUTOTUNE"] = "1"
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        import torch
+        from saena_amd import capi as c
+        from tests import refvc as rv, util as ut
+        c.init_host_transport(0, dist)                     # this process is rank `rank` of `world`; halos and dots through gloo
+        hier, ref = rv.load(fn)
+        nl = int(hier["nlevels"])
+        splits = [ref[f"split{l}"] for l in range(nl)]
+        OA, OP, OR = rv.oracle_hierarchy(hier, splits)     # every rank's layout; this process takes rank `rank`'s share
+        GA = [ut.gpu_operator(a, rank) for a in OA]
+        GP = [ut.gpu_operator(p, rank) for p in OP]
+        GR = [ut.gpu_operator(r_, rank) for r_ in OR]
+        lo, hi = int(splits[0][rank]), int(splits[0][rank + 1])
+        n0 = OA[0].Mbig
+        u0, rhs = 0.01 * rv.v2(n0), rv.rhs2(n0)
+        errs = {}
+        for name, (smoother, pre, post) in rv.VCYCLE_CASES.items():
+            G = c.Amg(GA, GP, GR, eig_max=hier["eig"], pre=pre, post=post, smoother=smoother, coarse_solver="cg")
+            for key, start in ((f"vcycle_{name}", u0), (f"vcycle0_{name}", np.zeros(n0))):
+                du, dr = c.DeviceVector(hi - lo, start[lo:hi]), c.DeviceVector(hi - lo, rhs[lo:hi])
+                G.vcycle(du, dr)
+                mine = du.download()
+                want = ref[key][lo:hi]
+                t = torch.tensor([float(np.sum((mine - want) ** 2)), float(np.sum(want ** 2))], dtype=torch.float64)
+                dist.all_reduce(t)
+                errs[key] = float(np.sqrt(t[0] / t[1]))
+            G.destroy()
+        ret[rank] = ("ok", errs)
+    except BaseException as e:      # noqa
+        import traceback
+        ret[rank] = ("".join(traceback.format_exception(type(e), e, e.__traceback__)),)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fn", [f for f in refvc.FIXTURES if ".np1." not in f], ids=os.path.basename)
+def test_library_multirank_vcycle_matches_the_reference_multirank_vectors(capi, fn):
+    """The LIBRARY's multi-rank V-cycle (one process per rank on this one card, halos and the coarsest level's CG dots
+    through the host transport; operators laid out at the partitions the REFERENCE chose for 2 and 4 ranks, coarsest
+    level row-partitioned like the reference's) against the V-cycle vectors the compiled reference computed at that rank
+    count: Jacobi (3,3)/(2,1), Chebyshev (3,3)/(1,2), from a non-zero and from the zero iterate."""
+    import multiprocessing as mp      # not torch's: this process already runs the system HIP runtime
+    import socket
+    world = int(os.path.basename(fn).split(".np")[1].split(".")[0])
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_refvc_worker, args=(r, world, port, fn, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        res = dict(ret)
+    for r in range(world):
+        assert res.get(r) and res[r][0] == "ok", f"rank {r}: {res.get(r)}"
+    errs = res[0][1]
+    assert len(errs) == 8
+    for key, e in errs.items():
+        assert e <= TOL_VCYCLE, (key, e)
