@@ -12,8 +12,10 @@
 // Three accumulators by the row's upper bound ub = min(products, columns of B):
 //   light  (ub <= 256)   one wave per row, 512-slot hash table in LDS (4 rows per workgroup);
 //   medium (ub <= 2048)  one workgroup per row, 4096-slot hash table in LDS;
-//   heavy                persistent workgroups with a dense accumulator of their own in HBM (the coarse levels'
-//                        rows reach 10^4-10^5 products; an MI355X has the memory: 12 B x columns per workgroup).
+//   heavy                first the same LDS table, abandoned when more than 3072 distinct columns turn up (a row of R A
+//                        on the second level has 13 700 products and 760 entries); the rows that overflow go to
+//                        persistent workgroups with a dense accumulator of their own in HBM (the coarse levels' rows
+//                        reach 10^5-10^6 products; an MI355X has the memory: 12 B x columns per workgroup).
 // Each row leaves its touched (column, value) pairs unsorted in a scratch segment; dropped entries (|v| <= 1e-14 off
 // the diagonal, saena_object_setup_matmat.cpp:2423,2442) get the key INT_MAX; one segmented radix sort per chunk of rows
 // orders every segment by column, and the kept prefix of each segment is copied out.
@@ -23,6 +25,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -97,16 +100,21 @@ __global__ __launch_bounds__(256) void k_spgemm_light(Mats m, const int *__restr
 }
 
 // ---- medium rows: one workgroup per row ----
+// TRY = true serves rows whose upper bound exceeds the table but whose DISTINCT output columns usually do not (a row of
+// R A on the second level: 13 700 products, 760 entries): the row is abandoned -- n_touched = -1 -- as soon as more than
+// MEDIUM_FILL keys are in the table, and the host hands it to the dense-accumulator kernel.
+constexpr int MEDIUM_FILL = 3072;
+template <bool TRY>
 __global__ __launch_bounds__(256) void k_spgemm_medium(Mats m, const int *__restrict__ rows, int r0, const int *__restrict__ ubptr,
                                                        int *__restrict__ tcol, double *__restrict__ tval, int *__restrict__ n_touched,
                                                        int *__restrict__ n_kept, int row_offset) {
     __shared__ int K[MEDIUM_SLOTS];
     __shared__ double V[MEDIUM_SLOTS];
-    __shared__ int counter[2];
+    __shared__ int counter[4];                              // [0] written out, [1] dropped, [2] keys in the table, [3] overflow
     const int tid = threadIdx.x;
     const int i = rows[blockIdx.x], loc = i - r0;
     for (int s = tid; s < MEDIUM_SLOTS; s += 256) K[s] = -1;
-    if (tid < 2) counter[tid] = 0;
+    if (tid < 4) counter[tid] = 0;
     __syncthreads();
     for (long long ka = m.a_ptr[i]; ka < m.a_ptr[i + 1]; ++ka) {
         const int k = m.a_col[ka];
@@ -116,14 +124,20 @@ __global__ __launch_bounds__(256) void k_spgemm_medium(Mats m, const int *__rest
             const int j = m.b_col[kb];
             const double v = a * m.b_val[kb];
             unsigned h = hash_col(j) & (MEDIUM_SLOTS - 1);
+            int steps = 0;
             while (true) {
                 const int prev = atomicCAS(&K[h], -1, j);
-                if (prev == -1) { V[h] = v; break; }
+                if (prev == -1) { V[h] = v; if (TRY) atomicAdd(&counter[2], 1); break; }
                 if (prev == j) { V[h] += v; break; }
                 h = (h + 1) & (MEDIUM_SLOTS - 1);
+                if (TRY && ++steps >= MEDIUM_SLOTS) { counter[3] = 1; break; }      // table full: give the row up
             }
         }
         __syncthreads();                                    // entry ka+1 of A's row adds after entry ka everywhere
+        if (TRY) {
+            const bool over = counter[3] != 0 || counter[2] > MEDIUM_FILL;          // the same answer in every thread
+            if (over) { if (tid == 0) { n_touched[loc] = -1; n_kept[loc] = 0; } return; }
+        }
     }
     const long long u0 = ubptr[loc];
     for (int s = tid; s < MEDIUM_SLOTS; s += 256) {
@@ -227,6 +241,11 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
         products_total += w;
         ub[(size_t)i] = std::min<long long>(w, b_cols);
     }
+    const bool timing = std::getenv("SAENA_SETUP_TIMING") != nullptr;
+    double t_up = 0, t_kern = 0, t_sort = 0, t_down = 0, t_host = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    auto T0 = now();
     Dev D;
     Mats m;
     long long *dap = D.alloc<long long>((size_t)a_rows + 1), *dbp = D.alloc<long long>((size_t)b_rows + 1);
@@ -240,6 +259,7 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
     SP_CHK(hipMemcpy(dav, a_val, (size_t)a_nnz * 8, hipMemcpyHostToDevice));
     SP_CHK(hipMemcpy(dbv, b_val, (size_t)b_nnz * 8, hipMemcpyHostToDevice));
     m.a_ptr = dap; m.a_col = dac; m.a_val = dav; m.b_ptr = dbp; m.b_col = dbc; m.b_val = dbv;
+    t_up = secs(T0, now());
 
     // chunks of consecutive rows whose scratch segments fit CH entries (2 x 12 B each: unsorted + sorted)
     const long long CH = 384LL << 20;                                           // < 2^31: in-chunk offsets are ints
@@ -279,6 +299,7 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
     std::vector<int> h_kept, light, medium, heavy, h_rows;
     for (size_t c = 0; c + 1 < chunk_start.size(); ++c) {
         const int r0 = chunk_start[c], r1 = chunk_start[c + 1], n = r1 - r0;
+        auto Tc = now();
         h_ubptr.assign((size_t)n + 1, 0);
         light.clear(); medium.clear(); heavy.clear();
         for (int i = r0; i < r1; ++i) {
@@ -286,6 +307,7 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
             if (ub[(size_t)i] == 0) continue;
             (ub[(size_t)i] <= LIGHT_UB ? light : ub[(size_t)i] <= MEDIUM_UB ? medium : heavy).push_back(i);
         }
+        t_host += secs(Tc, now()); Tc = now();
         SP_CHK(hipMemcpy(d_ubptr, h_ubptr.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
         SP_CHK(hipMemset(d_touched, 0, (size_t)n * 4));
         SP_CHK(hipMemset(d_kept, 0, (size_t)n * 4));
@@ -295,8 +317,22 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
             hipLaunchKernelGGL(k_spgemm_light, dim3(((unsigned)light.size() + 3) / 4), dim3(256), 0, 0, m, (const int *)d_rows, (int)light.size(), r0,
                                (const int *)d_ubptr, tcol, tval, d_touched, d_kept, row_offset);
         if (!medium.empty())
-            hipLaunchKernelGGL(k_spgemm_medium, dim3((unsigned)medium.size()), dim3(256), 0, 0, m, (const int *)(d_rows + light.size()), r0,
+            hipLaunchKernelGGL(k_spgemm_medium<false>, dim3((unsigned)medium.size()), dim3(256), 0, 0, m, (const int *)(d_rows + light.size()), r0,
                                (const int *)d_ubptr, tcol, tval, d_touched, d_kept, row_offset);
+        if (!heavy.empty()) {
+            // rows with many products but (usually) few distinct columns: try the LDS table first, keep the dense
+            // accumulator for the rows that overflow it
+            const int *d_heavy = d_rows + light.size() + medium.size();
+            hipLaunchKernelGGL(k_spgemm_medium<true>, dim3((unsigned)heavy.size()), dim3(256), 0, 0, m, d_heavy, r0,
+                               (const int *)d_ubptr, tcol, tval, d_touched, d_kept, row_offset);
+            SP_CHK(hipGetLastError());
+            h_kept.resize((size_t)n);                                            // (scratch: the touched counts)
+            SP_CHK(hipMemcpy(h_kept.data(), d_touched, (size_t)n * 4, hipMemcpyDeviceToHost));
+            std::vector<int> over;
+            for (int i : heavy) if (h_kept[(size_t)(i - r0)] < 0) over.push_back(i);
+            heavy.swap(over);
+            if (!heavy.empty()) SP_CHK(hipMemcpy(d_rows + light.size() + medium.size(), heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice));
+        }
         if (!heavy.empty()) {
             if (!acc) {
                 const long long per = 12LL * b_cols;                            // 8 B sum + 4 B mark per column and workgroup
@@ -312,6 +348,7 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
                                d_touched, d_kept, row_offset, acc, mark, (long long)b_cols);
         }
         SP_CHK(hipGetLastError());
+        if (timing) { SP_CHK(hipDeviceSynchronize()); t_kern += secs(Tc, now()); Tc = now(); }
         hipLaunchKernelGGL(k_seg_ends, dim3((n + 255) / 256), dim3(256), 0, 0, (const int *)d_ubptr, (const int *)d_touched, d_ends, n);
         // every segment by column (dropped entries carry INT_MAX and end up behind the kept ones)
         const long long items = h_ubptr[(size_t)n];
@@ -329,6 +366,7 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
         if (se != hipSuccess) { if (d_temp) hipFree(d_temp); return 1; }
         h_kept.resize((size_t)n);
         SP_CHK(hipMemcpy(h_kept.data(), d_kept, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (timing) { t_sort += secs(Tc, now()); Tc = now(); }
         h_outptr.assign((size_t)n + 1, 0);
         for (int i = 0; i < n; ++i) h_outptr[(size_t)i + 1] = h_outptr[(size_t)i] + h_kept[(size_t)i];
         const long long out_n = h_outptr[(size_t)n];
@@ -345,10 +383,12 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
             SP_CHK(hipMemcpy(c_val.data() + base, tval, (size_t)out_n * 8, hipMemcpyDeviceToHost));
         }
         for (int i = 0; i < n; ++i) c_ptr.push_back((long)(base + (size_t)h_outptr[(size_t)i + 1]));
+        t_down += secs(Tc, now());
     }
     if (d_temp) hipFree(d_temp);
     if (std::getenv("SAENA_SETUP_TIMING"))
-        fprintf(stderr, "[spgemm gpu] %d x %d, %lld products -> %zu entries, %zu chunk(s)\n", a_rows, b_cols, products_total, c_col.size(), chunk_start.size() - 1);
+        fprintf(stderr, "[spgemm gpu] %d x %d, %lld products -> %zu entries, %zu chunk(s): upload %.2f, row kernels %.2f, sort %.2f, copy-out+download %.2f, host %.2f, total %.2f s\n",
+                a_rows, b_cols, products_total, c_col.size(), chunk_start.size() - 1, t_up, t_kern, t_sort, t_down, t_host, secs(T0, now()));
     return 0;
 }
 
