@@ -10,15 +10,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # how the two streams of a multi-rank apply depend on each other: flags polled by kernels (default),
 # stream value operations, events
+# ... and which applies take which form: the loopback operator is small (< 1 M nnz), which by default means ONE stream
+# (mode S); SAENA_SINGLE_STREAM_NNZ=0 forces the two-stream forms onto it, SAENA_EVENT_SYNC_NNZ=1 the plain-event form
+# that operators with a long interior kernel use
+TWO = {"SAENA_SINGLE_STREAM_NNZ": "0"}
 SYNC_MODES = {
-    "kernel-flags": {},
-    "stream-value-ops": {"SAENA_NO_INKERNEL_SYNC": "1"},
-    "events": {"SAENA_NO_INKERNEL_SYNC": "1", "SAENA_NO_STREAM_VALUE_OPS": "1"},
+    "kernel-flags": dict(TWO),
+    "stream-value-ops": dict(TWO, SAENA_NO_INKERNEL_SYNC="1"),
+    "events": dict(TWO, SAENA_NO_INKERNEL_SYNC="1", SAENA_NO_STREAM_VALUE_OPS="1"),
+    "events-for-long-kernels": dict(TWO, SAENA_EVENT_SYNC_NNZ="1"),
+    "single-stream": {},
 }
 
 
-@pytest.mark.parametrize("torch_first,mode", [(False, "kernel-flags"), (True, "kernel-flags"), (True, "stream-value-ops"), (True, "events")],
-                         ids=["system-rocm", "torch-runtime", "torch-runtime-value-ops", "torch-runtime-events"])
+@pytest.mark.parametrize("torch_first,mode", [(False, "kernel-flags"), (True, "kernel-flags"), (True, "stream-value-ops"), (True, "events"),
+                                              (True, "events-for-long-kernels"), (True, "single-stream"), (False, "single-stream")],
+                         ids=["system-rocm", "torch-runtime", "torch-runtime-value-ops", "torch-runtime-events", "torch-runtime-long-kernel-events",
+                              "torch-runtime-single-stream", "system-rocm-single-stream"])
 def test_rccl_loopback(torch_first, mode):
     cmd = [sys.executable, "-m", "tests.rccl_loopback"] + (["--torch"] if torch_first else [])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **SYNC_MODES[mode])
