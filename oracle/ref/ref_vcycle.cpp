@@ -11,7 +11,8 @@
 //     uCorrCoarse = 0; vcycle(coarse)
 //     uCorr = P uCorrCoarse (prolong_matrix::matvec, src/prolong_matrix.cpp:489-624);  u -= uCorr (:1360-1361)
 //     smooth
-// with the coarsest level solved by the loop of solve_coarsest_CG (:14-114) over the reference's matvec.
+// with the coarsest level solved by the loop of solve_coarsest_CG (:14-114) over the reference's matvec, and the outer
+// loops of solve_pCG (:2389-2801) and solve (:1883-2014) composed the same way (residual histories and solutions).
 // The hierarchy (A_l, P_l as coordinate lists) is an INPUT, written by oracle/ref/make_golden_vcycle.py from the
 // product's host setup; R_l is built by the reference itself (restrict_matrix::transposeP, src/restrict_matrix.cpp:10-494)
 // from the reference's own layout of P_l (prolong_matrix::findLocalRemote, src/prolong_matrix.cpp:18-378).
@@ -203,6 +204,69 @@ int main(int argc, char **argv) {
         std::fill(u.begin(), u.end(), 0.0);
         vcycle(0, u.data(), rhs.data());
         write_raw(pfx + "vcycle0_" + cs.name, "f64", gather_d(u.data(), M0));
+    }
+    // ---- the outer loops around it: solve_pCG (:2389-2801) and solve (:1883-2014), options001 (Jacobi 3+3, tol 1e-8) ----
+    {
+        smoother = 0; pre = 3; post = 3;
+        const double tol = 1e-8;
+        const int max_iter = 50;
+        std::vector<double> rhs(std::max(M0, 1)), u(std::max(M0, 1), 0.0), r(std::max(M0, 1)), rho(std::max(M0, 1)), p(std::max(M0, 1)), h(std::max(M0, 1));
+        for (int i = 0; i < M0; ++i) rhs[i] = f_rhs2(o0 + i);
+        auto ldot = [&](const std::vector<double> &a, const std::vector<double> &b) {
+            double s = 0, g = 0;
+            for (int i = 0; i < M0; ++i) s += a[i] * b[i];
+            MPI_Allreduce(&s, &g, 1, MPI_DOUBLE, MPI_SUM, comm);
+            return g;
+        };
+        // solve_pCG
+        std::vector<double> hist;
+        {
+            double *rp = r.data();
+            A[0]->residual(u.data(), rhs.data(), rp);                        // :2497
+            const double init_dot = ldot(r, r);
+            hist.push_back(sqrt(init_dot));
+            std::fill(rho.begin(), rho.end(), 0.0);
+            vcycle(0, rho.data(), r.data());                                  // :2536-2537
+            p = rho;
+            const double THRSHLD = init_dot * tol * tol;
+            double current_dot = init_dot;
+            int i = 0;
+            for (i = 0; i < max_iter; ++i) {                                  // :2565
+                A[0]->matvec(p.data(), h.data());
+                const double rho_res = ldot(r, rho), pdoth = ldot(p, h);
+                const double alpha = rho_res / pdoth;
+                for (int j = 0; j < M0; ++j) { u[j] -= alpha * p[j]; r[j] -= alpha * h[j]; }
+                current_dot = ldot(r, r);
+                hist.push_back(sqrt(current_dot));
+                if (current_dot < THRSHLD) break;
+                std::fill(rho.begin(), rho.end(), 0.0);
+                vcycle(0, rho.data(), r.data());
+                double beta = ldot(r, rho);
+                beta /= rho_res;
+                for (int j = 0; j < M0; ++j) p[j] = rho[j] + beta * p[j];
+            }
+        }
+        write_raw(pfx + "pcg_hist", "f64", hist);
+        write_raw(pfx + "pcg_u", "f64", gather_d(u.data(), M0));
+        // solve: u = 0; repeat vcycle until ||r||^2 < ||r0||^2 tol^2
+        std::fill(u.begin(), u.end(), 0.0);
+        hist.clear();
+        {
+            double *rp = r.data();
+            A[0]->residual(u.data(), rhs.data(), rp);
+            const double init_dot = ldot(r, r);
+            hist.push_back(sqrt(init_dot));
+            const double THRSHLD = init_dot * tol * tol;
+            for (int i = 0; i < max_iter; ++i) {                              // :1957-1970
+                vcycle(0, u.data(), rhs.data());
+                A[0]->residual(u.data(), rhs.data(), rp);
+                const double d = ldot(r, r);
+                hist.push_back(sqrt(d));
+                if (d < THRSHLD) break;
+            }
+        }
+        write_raw(pfx + "solve_hist", "f64", hist);
+        write_raw(pfx + "solve_u", "f64", gather_d(u.data(), M0));
     }
     std::vector<long> meta = {(long)nl, (long)g_np};
     write_raw(pfx + "meta", "i64", meta);

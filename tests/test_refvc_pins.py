@@ -44,6 +44,24 @@ def test_oracle_transfers_and_vcycle_match_the_compiled_reference(fn):
             assert np.linalg.norm(got - want) <= TOL_VCYCLE * np.linalg.norm(want), (key, np.linalg.norm(got - want) / np.linalg.norm(want))
 
 
+@pytest.mark.parametrize("fn", [f for f in refvc.FIXTURES if "poisson16" in f], ids=os.path.basename)
+def test_oracle_pcg_and_solve_histories_match_the_composed_reference_loops(fn):
+    """solve_pCG (src/saena_object_solve.cpp:2389-2801) and solve (:1883-2014) composed over the reference's operators
+    (ref_vcycle.cpp): same iteration counts, every ||r_k|| within 1e-10 ||r_0|| (north_star's tolerance), same solution"""
+    hier, ref = refvc.load(fn)
+    nl = int(hier["nlevels"])
+    OA, OP, OR = refvc.oracle_hierarchy(hier, [ref[f"split{l}"] for l in range(nl)])
+    O = orc.OracleAmg(OA, OP, OR, pre=3, post=3, smoother="jacobi", max_iter=50, tol=1e-8)
+    rhs = refvc.rhs2(OA[0].Mbig)
+    for fn_, key in ((O.solve_pCG, "pcg"), (O.solve, "solve")):
+        u, it, hist = fn_(rhs)
+        want_h, want_u = ref[f"{key}_hist"], ref[f"{key}_u"]
+        assert it == len(want_h) - 1 and len(hist) == len(want_h), (key, it, len(want_h) - 1)
+        assert np.all(np.abs(hist - want_h) <= 1e-10 * want_h[0]), (key, np.max(np.abs(hist - want_h)) / want_h[0])
+        assert want_h[-1] < 1e-8 * want_h[0]
+        assert np.linalg.norm(u - want_u) <= 1e-9 * np.linalg.norm(want_u), key
+
+
 def test_reference_vcycle_is_rank_count_invariant_to_rounding():
     """the reference's own outputs at 1, 2 and 4 ranks agree to ~1e-13: what 'the same V-cycle' means numerically"""
     base = refvc.load(os.path.join(refvc.GOLDEN, "refvc_poisson16.np1.npz"))[1]
