@@ -117,10 +117,13 @@ int sgpu_op_info(const sgpu_op *op, index_t *M, index_t *N_local, nnz_t *nnz_loc
 /* kernel variant override (tuning/tests): lanes_per_row in {0=auto,1,2,4,...,64} */
 int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
 /* kernel variant of the local part: 0 k_csr_stream with 16 KiB tiles, 1 with 32 KiB tiles, 2 k_csr_vector
- * (no LDS staging), 3 / 4 k_csr_cc16 (16-bit compressed column ids, 10 B/nnz) on the 16 / 32 KiB plan;
- * 3 and 4 are refused when a block touches more than 16 column segments or holds a row longer than the tile;
- * 5 k_dense_rows: dense row-major storage (saena_matrix_dense, the reference's `switch_to_dense`), for operators
- * without a halo, at most 8192 x 8192 and at least 10 % full */
+ * (no LDS staging), 3 / 4 k_csr_cc16 (16-bit compressed column ids, 10 B/nnz; the slot/offset split is chosen per
+ * operator) on the 16 / 32 KiB plan, refused when a block touches more than 256 column segments of 256 columns;
+ * 5 k_dense_rows: dense row-major storage (saena_matrix_dense, the reference's `switch_to_dense`; with a halo:
+ * k_dense_rows_halo), at most 8192 rows and 64 M entries per rank; 6 k_csr_wave (long rows streamed by a wave);
+ * 7 / 8 k_csr_cm: compressed columns with the entries of a row block in column order (12 B/nnz, fewer L1 requests on
+ * rows of a few hundred entries) on the 16 / 32 KiB plan, built from a host copy of the values that the library keeps
+ * only until the plan-time autotune */
 int sgpu_op_set_variant(sgpu_op *op, int variant);
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name);
 /* time a few (variant, lanes) candidates on this operator and keep the fastest (plan-time autotune) */

@@ -64,6 +64,10 @@ struct SpmvArgs {
     const int            *segptr;   // [nblk+1]
     const unsigned short *ccol;     // [nnz] (padded)
     int                   cc_ob;    // offset bits
+    // column-major-in-block form (k_csr_cm): the block's entries re-sorted by column, each with the tile slot its product
+    // belongs to; val / ccol then point at the re-sorted copies, cmptr[b] is the block's (quad-aligned) start in them
+    const unsigned short *dst;
+    const int            *cmptr;
     // in-kernel fork to the halo stream (multi-rank interior launch only, else nullptr): block 0 stores
     // *flag_x = seq when it starts -- stream order: everything earlier on the compute stream is complete, so
     // the halo stream's pack, which polls the flag, may read x.
@@ -418,6 +422,82 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
     }
     __syncthreads();
 
+    constexpr int ROWS_PER_PASS = BLOCK / G;
+    const int g = tid / G, l = tid % G;
+    for (int r = r0 + g; r < r1; r += ROWS_PER_PASS) {
+        const int s = a.row_ptr[r] - a0, e = a.row_ptr[r + 1] - a0;
+        double sum = 0.0;
+        for (int k = s + l; k < e; k += G) sum += lds[k];
+        sum = group_sum<G>(sum);
+        if (l == 0) {
+            epilogue<EPI, HALO>(a, r, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1h: k_csr_cc16 with the block's entries streamed in COLUMN order.  The smoothed-aggregation levels are bound by
+// vector-L1 miss requests, 4-5 per distinct x line a block touches (profiles/r02_pmc_l1_*.txt): the rows of a block share
+// most of their columns, but in row-major order the entries that want one line sit hundreds of nnz apart, in different
+// wave instructions, and each asks for the line again while it is in flight.  Here the block's entries are stored
+// sorted by (column, row): the entries that share a line are neighbours in the stream -- the same lane, adjacent lanes,
+// one instruction -- and every entry carries the tile slot its product belongs to (16 bit), so the products still land in
+// row-major order and phase 2 adds each row's products in column order: bit-identical results.  12 B/nnz (8 value +
+// 2 column + 2 slot) instead of 10.
+template <int EPI, int G, int CAPV, bool HALO>
+__global__ __launch_bounds__(BLOCK) void k_csr_cm(const SpmvArgs a) {
+    constexpr int LDSN = CAPV + 8;
+    __shared__ __attribute__((aligned(16))) double lds[LDSN];
+    __shared__ int seg[CC_MAXSEG];
+    const int tid = threadIdx.x;
+    if constexpr (HALO) fork_signal(a);
+    const int b   = xcd_remap(blockIdx.x, a.nblk);
+    const int r0 = a.blk_row[b], r1 = a.blk_row[b + 1];
+    const int p0 = a.row_ptr[r0];
+    {
+        const int s0 = a.segptr[b], ns = a.segptr[b + 1] - s0;
+        if (tid < ns) seg[tid] = a.segtab[s0 + tid];
+    }
+    __syncthreads();
+    const int ob = a.cc_ob;
+    const unsigned om = (1u << ob) - 1u;
+    const int c0 = a.cmptr[b], nq = (a.cmptr[b + 1] - c0) >> 2;     // the block's quads in the re-sorted arrays (padded to whole quads)
+    constexpr int ITER = (LDSN / 4 + BLOCK - 1) / BLOCK;
+    double2 v01[ITER], v23[ITER];
+    uint2   c[ITER], d[ITER];
+    const int qlast = nq > 0 ? nq - 1 : 0;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        int q = tid + it * BLOCK;
+        q = q < qlast ? q : qlast;
+        const int idx = c0 + 4 * q;
+        v01[it] = ld_stream_d2(a.val + idx);
+        v23[it] = ld_stream_d2(a.val + idx + 2);
+        c[it]   = ld_stream_u2(a.ccol + idx);
+        d[it]   = ld_stream_u2(a.dst + idx);
+    }
+    double2 o01[ITER], o23[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const unsigned c0_ = c[it].x & 0xffffu, c1 = c[it].x >> 16, c2 = c[it].y & 0xffffu, c3 = c[it].y >> 16;
+        o01[it].x = a.x[seg[c0_ >> ob] + (int)(c0_ & om)];
+        o01[it].y = a.x[seg[c1 >> ob] + (int)(c1 & om)];
+        o23[it].x = a.x[seg[c2 >> ob] + (int)(c2 & om)];
+        o23[it].y = a.x[seg[c3 >> ob] + (int)(c3 & om)];
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int q = tid + it * BLOCK;
+        if (q < nq) {                                  // padding entries carry value 0 and the spare slot CAPV + 4
+            lds[d[it].x & 0xffffu] = v01[it].x * o01[it].x;
+            lds[d[it].x >> 16]     = v01[it].y * o01[it].y;
+            lds[d[it].y & 0xffffu] = v23[it].x * o23[it].x;
+            lds[d[it].y >> 16]     = v23[it].y * o23[it].y;
+        }
+    }
+    __syncthreads();
+
+    const int a0 = p0 & ~3;
     constexpr int ROWS_PER_PASS = BLOCK / G;
     const int g = tid / G, l = tid % G;
     for (int r = r0 + g; r < r1; r += ROWS_PER_PASS) {

@@ -133,6 +133,12 @@ struct CsrPart {
     int            *segtab[2] = {nullptr, nullptr}, *segptr[2] = {nullptr, nullptr};
     unsigned short *ccol[2] = {nullptr, nullptr};
     bool            cc_ok[2] = {false, false};
+    // column-major-in-block form (variants 7/8, on top of the compressed columns of the same plan)
+    double         *cm_val[2] = {nullptr, nullptr};
+    unsigned short *cm_col[2] = {nullptr, nullptr}, *cm_dst[2] = {nullptr, nullptr};
+    int            *cm_ptr[2] = {nullptr, nullptr};
+    bool            cm_ok[2] = {false, false};
+    char            cm_tried[2] = {0, 0};
     int             cc_ob[2] = {12, 12};   // offset bits of the slot/offset split (12: 16 segments of 4096 columns ... 8: 256 of 256)
     char            cc_tried[2] = {0, 0};  // build_cc16 ran and found no split that fits (do not try again)
     std::vector<int> h_rp, h_col, h_blk, h_blk_big;   // host copies kept for build_cc16 / the coarsest factorisation
@@ -140,6 +146,7 @@ struct CsrPart {
         hipFree(row_ptr); hipFree(col); hipFree(blk_row); hipFree(blk_row_big); hipFree(rows); hipFree(val); hipFree(dense);
         dense = nullptr;
         for (int k = 0; k < 2; ++k) { hipFree(segtab[k]); hipFree(segptr[k]); hipFree(ccol[k]); segtab[k] = segptr[k] = nullptr; ccol[k] = nullptr; }
+        for (int k = 0; k < 2; ++k) { hipFree(cm_val[k]); hipFree(cm_col[k]); hipFree(cm_dst[k]); hipFree(cm_ptr[k]); cm_val[k] = nullptr; cm_col[k] = cm_dst[k] = nullptr; cm_ptr[k] = nullptr; }
         row_ptr = col = blk_row = blk_row_big = rows = nullptr; val = nullptr;
     }
 };
@@ -277,6 +284,65 @@ int build_cc16(CsrPart &P, int k) {
     return SGPU_OK;                                              // a block touches more than 256 segments of 256 columns
 }
 
+// column-major-in-block form of plan k (needs the compressed columns of the same plan and the host copy of the values)
+int build_cm(CsrPart &P, int k, const std::vector<double> &h_val_all) {
+    if (P.cm_ok[k] || P.cm_tried[k] || P.h_rp.empty()) return SGPU_OK;
+    P.cm_tried[k] = 1;
+    CHK(build_cc16(P, k));
+    if (!P.cc_ok[k] || h_val_all.size() != P.h_col.size()) return SGPU_OK;
+    const std::vector<int> &blk = k ? P.h_blk_big : P.h_blk;
+    const int cap = k ? sk::CAP_BIG : sk::CAP;
+    const int nblk = (int)blk.size() - 1;
+    if (nblk == 0) return SGPU_OK;
+    std::vector<int> cmptr((size_t)nblk + 1, 0);
+    for (int b = 0; b < nblk; ++b) {
+        const int n = P.h_rp[blk[b + 1]] - P.h_rp[blk[b]];
+        if (n > cap) return SGPU_OK;                               // long rows: not in this form
+        cmptr[(size_t)b + 1] = cmptr[(size_t)b] + ((n + 3) & ~3);
+    }
+    const size_t tot = (size_t)cmptr[(size_t)nblk];
+    // the 16-bit column codes of plan k live on the device only: re-encode on the host with the block's (sorted) table
+    const int ob = P.cc_ob[k], om = (1 << ob) - 1;
+    std::vector<double> val(tot + 8, 0.0);
+    std::vector<unsigned short> col(tot + 8, 0), dst(tot + 8, (unsigned short)(cap + 4));
+    const int nt = std::min(host_threads(), std::max(1, nblk / 64));
+    auto work = [&](int t) {
+        const int b0 = (int)((long)nblk * t / nt), b1 = (int)((long)nblk * (t + 1) / nt);
+        std::vector<int> order, uniq;
+        for (int b = b0; b < b1; ++b) {
+            const int p0 = P.h_rp[blk[b]], p1 = P.h_rp[blk[b + 1]], n = p1 - p0, a0 = p0 & ~3;
+            uniq.clear();
+            for (int p = p0; p < p1; ++p) uniq.push_back(P.h_col[p] >> ob);
+            std::sort(uniq.begin(), uniq.end());
+            uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());      // the block's segment table (ascending, as build_cc16 made it)
+            order.resize((size_t)n);
+            for (int i = 0; i < n; ++i) order[(size_t)i] = p0 + i;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return P.h_col[x] < P.h_col[y]; });   // (column, then row: CSR order is row-major)
+            const size_t o = (size_t)cmptr[(size_t)b];
+            for (int i = 0; i < n; ++i) {
+                const int p = order[(size_t)i];
+                const int slot = (int)(std::lower_bound(uniq.begin(), uniq.end(), P.h_col[p] >> ob) - uniq.begin());
+                val[o + i] = h_val_all[(size_t)p];
+                col[o + i] = (unsigned short)((slot << ob) | (P.h_col[p] & om));
+                dst[o + i] = (unsigned short)(p - a0);
+            }
+            for (int i = n; i < ((n + 3) & ~3); ++i) col[o + i] = n ? col[o] : 0;    // padding: a valid column, value 0, the spare slot
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    CHK(dev_upload(&P.cm_val[k], val.data(), val.size()));
+    CHK(dev_upload(&P.cm_col[k], col.data(), col.size()));
+    CHK(dev_upload(&P.cm_dst[k], dst.data(), dst.size()));
+    CHK(dev_upload(&P.cm_ptr[k], cmptr.data(), cmptr.size()));
+    P.cm_ok[k] = true;
+    return SGPU_OK;
+}
+
 } // namespace
 
 struct sgpu_op {
@@ -301,6 +367,7 @@ struct sgpu_op {
     double *dense_rem = nullptr;  // variant 5 with a halo: row-major M x recvSize over the receive buffer
     std::vector<int> rem_rows_h;  // host copy of rem.rows (compact boundary row -> local row)
     std::vector<double> h_val;   // host copy of the values of small local parts (coarsest-level factorisation)
+    std::vector<double> h_val_all;   // host copy of all local values (kept while the column-major form may still be built)
     unsigned *skip = nullptr;     // bitmask over the M rows: set = boundary row (has remote entries), written by k_csr_boundary
     int     bnd_lanes = 1;        // lanes per boundary row
     hipEvent_t ev_x = nullptr, ev_halo = nullptr;   // cs -> hs: inputs ready; hs -> cs: exchange + boundary rows done
@@ -334,6 +401,7 @@ using VecKernelFn = void (*)(const sk::SpmvArgs, int);
 template <int F, int EPI, int CAPV, int G, bool H>
 constexpr KernelFn kernel_of() {
     if constexpr (F == 0) return sk::k_csr_stream<EPI, G, CAPV, H>;
+    else if constexpr (F == 2) return sk::k_csr_cm<EPI, G, CAPV, H>;
     else return sk::k_csr_cc16<EPI, G, CAPV, H>;
 }
 template <int F, int EPI, int CAPV, bool H>
@@ -423,7 +491,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.row_ptr = P.row_ptr; a.col = P.col; a.val = P.val;
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
-    a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12;
+    a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12; a.dst = nullptr; a.cmptr = nullptr;
     const bool halo = skip != nullptr || seq != 0;
     if (P.variant == 5) {                                         // dense rows, one wave per row
         if (!P.dense) return fail(SGPU_ERR_STATE, "the dense form was not built");
@@ -434,6 +502,14 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
             : epi == sk::EPI_JACOBI ? sk::k_dense_rows<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows<sk::EPI_CHEBY0>
             : epi == sk::EPI_CHEBYK ? sk::k_dense_rows<sk::EPI_CHEBYK> : sk::k_dense_rows<sk::EPI_SUB>;
         SGPU_LAUNCH(kd, dim3((P.nrows + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, (const double *)P.dense, P.nrows, P.ncols);
+    } else if (P.variant == 7 || P.variant == 8) {                       // compressed columns, entries in column order inside a block
+        const int k = P.variant - 7;
+        if (!P.cm_ok[k]) return fail(SGPU_ERR_STATE, "the column-major form of plan %d was not built", k);
+        a.blk_row = k ? P.blk_row_big : P.blk_row;
+        a.nblk = k ? P.nblk_big : P.nblk;
+        a.segtab = P.segtab[k]; a.segptr = P.segptr[k]; a.cc_ob = P.cc_ob[k];
+        a.val = P.cm_val[k]; a.ccol = P.cm_col[k]; a.dst = P.cm_dst[k]; a.cmptr = P.cm_ptr[k];
+        SGPU_LAUNCH(pick<2>(epi, P.lanes, k == 1, halo), dim3(a.nblk), dim3(sk::BLOCK), 0, g.cs, a);
     } else if (P.variant == 3 || P.variant == 4) {                       // 16-bit compressed columns
         const int k = P.variant - 3;
         if (!P.cc_ok[k]) return fail(SGPU_ERR_STATE, "compressed columns of plan %d were not built", k);
@@ -510,7 +586,7 @@ int launch_boundary(sgpu_op *op, int epi, const double *x, double *y, const EpiA
     b.s.flag_x = nullptr; b.s.seq = 0;
     b.s.row_ptr = op->loc.row_ptr; b.s.col = op->loc.col; b.s.val = op->loc.val; b.s.blk_row = nullptr; b.s.nblk = 0;
     b.s.x = x; b.s.y = y; b.s.rhs = e.rhs; b.s.inv_diag = e.inv_diag; b.s.u = e.u; b.s.d = e.d; b.s.c0 = e.c0; b.s.c1 = e.c1;
-    b.s.skip = nullptr; b.s.segtab = nullptr; b.s.segptr = nullptr; b.s.ccol = nullptr; b.s.cc_ob = 12;
+    b.s.skip = nullptr; b.s.segtab = nullptr; b.s.segptr = nullptr; b.s.ccol = nullptr; b.s.cc_ob = 12; b.s.dst = nullptr; b.s.cmptr = nullptr;
     b.rows = op->rem.rows; b.nrows = op->rem.nrows;
     b.h_ptr = op->rem.row_ptr; b.h_col = op->rem.col; b.h_val = op->rem.val;
     b.halo = op->recv_buf; b.halo_f = halo_is_f32 ? op->recv_f : nullptr;
@@ -999,6 +1075,10 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         // (whole operator: local + remote entries against the columns this rank reads, owned + halo)
         if (dense_candidate(d->M, d->N_local + d->col_remote_size, d->nnz_l_local + d->nnz_l_remote)) op->loc.h_val = val;
         if (d->M <= sk::CG_MAXN) op->h_val = val;
+        // the column-major-in-block form (k_csr_cm) is built from a host copy of the values; it pays on rows of a few
+        // hundred entries (the autotune tries it there and drops the copy afterwards); SAENA_KEEP_HOST_VALUES=1: always keep
+        const double avg_row = d->M > 0 ? (double)d->nnz_l_local / d->M : 0.0;
+        if (std::getenv("SAENA_KEEP_HOST_VALUES") || (avg_row >= 96.0 && avg_row <= 768.0 && !std::getenv("SAENA_NO_CM"))) op->h_val_all = val;
     }
     // remote part: CSC over the receive buffer -> CSR over the halo buffer on the rows that own remote entries
     if (d->nnz_l_remote > 0) {
@@ -1127,13 +1207,14 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave"};
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>"};   // (3, 4, 7, 8 are named with their slot/offset split below)
     if (variant) *variant = op->loc.variant;
     if (kernel_name) {
         const int v = op->loc.variant;
-        if (v == 3 || v == 4) {      // name the slot/offset split of the compressed columns: "k_csr_cc16<32KiB,5+11>"
+        if (v == 3 || v == 4 || v == 7 || v == 8) {      // name the slot/offset split of the compressed columns: "k_csr_cc16<32KiB,5+11>"
             char buf[64];
-            snprintf(buf, sizeof buf, "k_csr_cc16<%s,%d+%d>", v == 3 ? "16KiB" : "32KiB", 16 - op->loc.cc_ob[v - 3], op->loc.cc_ob[v - 3]);
+            const int k = (v == 3 || v == 7) ? 0 : 1;
+            snprintf(buf, sizeof buf, "%s<%s,%d+%d>", v >= 7 ? "k_csr_cm" : "k_csr_cc16", k == 0 ? "16KiB" : "32KiB", 16 - op->loc.cc_ob[k], op->loc.cc_ob[k]);
             const_cast<sgpu_op *>(op)->vname = buf;
             *kernel_name = op->vname.c_str();
         } else {
@@ -1145,10 +1226,15 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 6) return fail(SGPU_ERR_ARG, "variant must be 0..6");
+    if (variant < 0 || variant > 8) return fail(SGPU_ERR_ARG, "variant must be 0..8");
     if (variant == 5) {
         CHK(build_dense(op->loc));
         CHK(build_dense_rem(op));
+    } else if (variant == 7 || variant == 8) {
+        CHK(build_cm(op->loc, variant - 7, op->h_val_all));
+        if (!op->loc.cm_ok[variant - 7])
+            return fail(SGPU_ERR_ARG, "the column-major form needs compressed columns, no row longer than the tile and the host copy of the values "
+                                      "(kept until the autotune for rows of 96-768 entries, or with SAENA_KEEP_HOST_VALUES=1)");
     } else if (variant == 3 || variant == 4) {
         CHK(build_cc16(op->loc, variant - 3));
         if (!op->loc.cc_ok[variant - 3]) return fail(SGPU_ERR_ARG, "a row block of this operator touches more than 256 column segments of 256 columns");
@@ -1172,11 +1258,15 @@ int sgpu_op_autotune(sgpu_op *op) {
     CHK(x.alloc(op->N_local)); CHK(y.alloc(op->M)); CHK(r.alloc(op->M));
     CHK(sgpu_vec_fill(x.p, 1.0, op->N_local)); CHK(sgpu_vec_fill(r.p, 1.0, op->M));
     const int kind = op->inv_diag ? 1 : 0;
-    float best = 1e30f;
-    int bv = 0, bg = g0;
+    float best = 1e30f, best_cm = 1e30f;
+    int bv = 0, bg = g0, cmv = 8, cmg = g0;
     std::vector<int> variants = {0, 1, 2};
     for (int k = 0; k < 2; ++k) { CHK(build_cc16(op->loc, k)); if (op->loc.cc_ok[k]) variants.push_back(3 + k); }
     if (op->loc.nnz >= 256 * (int64_t)std::max(1, op->loc.nrows)) variants.push_back(6);   // long rows: the wave-streamed kernel
+    if (!op->h_val_all.empty()) {                                                          // rows of a few hundred entries: column order inside the block
+        CHK(build_cm(op->loc, 1, op->h_val_all));
+        if (op->loc.cm_ok[1]) variants.push_back(8);
+    }
     if (!op->has_remote && !op->loc.h_val.empty() && (double)op->loc.nnz >= 0.5 * (double)op->loc.nrows * op->loc.ncols && build_dense(op->loc) == SGPU_OK)
         variants.push_back(5);                         // at least half full: the dense form moves fewer bytes
     // Only the LOCAL part is timed, without the halo exchange: ranks may end up with different candidate
@@ -1202,13 +1292,22 @@ int sgpu_op_autotune(sgpu_op *op) {
                 float ms = 0;
                 HIPCHK(hipEventElapsedTime(&ms, e0, e1));
                 ms /= reps;
-                if (round == 1 && ms < best) { best = ms; bv = v; bg = gl; }
+                if (round == 1 && v >= 7) { if (ms < best_cm) { best_cm = ms; cmv = v; cmg = gl; } }
+                else if (round == 1 && ms < best) { best = ms; bv = v; bg = gl; }
             }
+    if (best_cm < 0.95f * best) { bv = cmv; bg = cmg; }    // the column-major copy costs 2 B/nnz more: it has to win clearly
     guard.armed = false;
     op->loc.variant = bv; op->loc.lanes = bg;
     if (bv != 5 && op->loc.dense) { hipFree(op->loc.dense); op->loc.dense = nullptr; }
+    for (int k = 0; k < 2; ++k)                       // the column-major copies of the plans that lost
+        if (op->loc.cm_ok[k] && bv != 7 + k) {
+            hipFree(op->loc.cm_val[k]); hipFree(op->loc.cm_col[k]); hipFree(op->loc.cm_dst[k]); hipFree(op->loc.cm_ptr[k]);
+            op->loc.cm_val[k] = nullptr; op->loc.cm_col[k] = op->loc.cm_dst[k] = nullptr; op->loc.cm_ptr[k] = nullptr;
+            op->loc.cm_ok[k] = false; op->loc.cm_tried[k] = 0;
+        }
+    std::vector<double>().swap(op->h_val_all);       // (a later set_variant(7/8) on this operator is refused: the values are gone)
     for (int k = 0; k < 2; ++k)                       // free the compressed arrays of the plans that lost
-        if (op->loc.cc_ok[k] && bv != 3 + k) {
+        if (op->loc.cc_ok[k] && bv != 3 + k && bv != 7 + k) {
             hipFree(op->loc.segtab[k]); hipFree(op->loc.segptr[k]); hipFree(op->loc.ccol[k]);
             op->loc.segtab[k] = op->loc.segptr[k] = nullptr; op->loc.ccol[k] = nullptr; op->loc.cc_ok[k] = false; op->loc.cc_tried[k] = 0;
         }
