@@ -240,16 +240,18 @@ int amg::set_matrix(saena::matrix *A, saena::options *opts) {
             d.halo_fp32 = f32;
             gchk(sgpu_op_create(&d, &op), "sgpu_op_create(A)");
         }
+        // plan-time autotune right after each create: the operator's host copy of the values lives only until then
+        const bool tune = !std::getenv("SAENA_NO_AUTOTUNE");
+        if (tune) gchk(sgpu_op_autotune(op), "sgpu_op_autotune");
         dA_.push_back(op);
         eig.push_back(H_->level_eig(l));
         if (l < n - 1) {
             fill_desc(multi ? H_->dist[l].P : gp->P.L, nullptr, &d); d.halo_fp32 = f32; gchk(sgpu_op_create(&d, &op), "sgpu_op_create(P)"); dP_.push_back(op);
+            if (tune) gchk(sgpu_op_autotune(op), "sgpu_op_autotune");
             fill_desc(multi ? H_->dist[l].R : gp->R.L, nullptr, &d); d.halo_fp32 = f32; gchk(sgpu_op_create(&d, &op), "sgpu_op_create(R)"); dR_.push_back(op);
+            if (tune) gchk(sgpu_op_autotune(op), "sgpu_op_autotune");
         }
     }
-    if (!std::getenv("SAENA_NO_AUTOTUNE"))
-        for (auto *v : {&dA_, &dP_, &dR_})
-            for (sgpu_op *op : *v) gchk(sgpu_op_autotune(op), "sgpu_op_autotune");
     if (o.switch_to_dense)                    // saena_object_setup2.cpp:328
         for (int l = 1; l < n; ++l) {
             const double rows = (double)H_->level_rows(l), dens = (double)H_->level_nnzA(l) / (rows * rows);

@@ -287,18 +287,18 @@ int saena_amg_to_device(saena_amg_h *S) {
         d.halo_fp32 = l >= fl ? 1 : 0;
         if (gchk(sgpu_op_create(&d, &o))) return -2;
         S->dA.push_back(o);
+        const bool tune = !std::getenv("SAENA_NO_AUTOTUNE");     // right after each create: the host copy of the values lives only until then
+        if (tune && gchk(sgpu_op_autotune(o))) return -2;
         eig.push_back(S->H.level_eig(l));
         if (l < n - 1) {
             if (saena_amg_level_desc(S, l, 1, &d)) return -1;
             d.halo_fp32 = l >= fl ? 1 : 0; if (gchk(sgpu_op_create(&d, &o))) return -2; S->dP.push_back(o);
+            if (tune && gchk(sgpu_op_autotune(o))) return -2;
             if (saena_amg_level_desc(S, l, 2, &d)) return -1;
             d.halo_fp32 = l >= fl ? 1 : 0; if (gchk(sgpu_op_create(&d, &o))) return -2; S->dR.push_back(o);
+            if (tune && gchk(sgpu_op_autotune(o))) return -2;
         }
     }
-    if (!std::getenv("SAENA_NO_AUTOTUNE"))
-        for (auto *v : {&S->dA, &S->dP, &S->dR})
-            for (sgpu_op *o : *v)
-                if (gchk(sgpu_op_autotune(o))) return -2;
     if (S->H.opts.switch_to_dense)            // saena_object_setup2.cpp:328: switch_to_dense && density > dense_thre && Mbig <= dense_sz_thre
         for (int l = 1; l < n; ++l) {
             const double rows = (double)S->H.level_rows(l), dens = (double)S->H.level_nnzA(l) / (rows * rows);

@@ -512,6 +512,57 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cm(const SpmvArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// K1s: sliced ELLPACK for even rows (the stencil levels and the first smoothed-aggregation level).  A slice is 64
+// consecutive rows = one wave; its entries are stored position-major -- entry j of the slice's rows side by side -- padded
+// to the slice's longest row.  A lane owns a row: it adds the row's products in column order in a register (the
+// reference's sequential sum, whatever the launch shape), there is no product tile, no phase 2 and no row pointer, every
+// stream load of the wave is one contiguous 512-byte (values) or 128-byte (columns) piece, on a stencil the 64 gathers
+// of an instruction are 64 consecutive doubles of x, and elsewhere a lane walks along its own row, whose neighbouring
+// columns share lines that are still in L1.  Columns are the 16-bit codes of k_csr_cc16 against a segment table per
+// workgroup (4 slices): 10 B per stored entry.  Operators whose padding exceeds 12 % keep the CSR kernels.
+// a.val / a.ccol: the padded arrays, a.segtab / a.segptr / a.cc_ob: the tables, a.cmptr: slice starts (multiples of 64),
+// a.dst: row lengths, a.nblk: slices.
+template <int EPI, bool HALO>
+__global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
+    __shared__ int seg[CC_MAXSEG];
+    if constexpr (HALO) fork_signal(a);
+    constexpr int SPB = BLOCK / 64;
+    const int b = xcd_remap(blockIdx.x, (a.nblk + SPB - 1) / SPB);
+    {
+        const int s0 = a.segptr[b], ns = a.segptr[b + 1] - s0;      // ns <= CC_MAXSEG = BLOCK
+        if ((int)threadIdx.x < ns) seg[threadIdx.x] = a.segtab[s0 + threadIdx.x];
+    }
+    __syncthreads();
+    const int s = __builtin_amdgcn_readfirstlane(b * SPB + ((int)threadIdx.x >> 6));
+    if (s >= a.nblk) return;
+    const int lane = threadIdx.x & 63;
+    const int r = s * 64 + lane;
+    const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 6;
+    const int len = r < nrows ? (int)a.dst[r] : 0;
+    const int ob = a.cc_ob;
+    const unsigned om = (1u << ob) - 1u;
+    const double         *v = a.val + p + lane;
+    const unsigned short *c = a.ccol + p + lane;
+    double sum = 0.0;
+    for (int j = 0; j < w; j += 8) {
+        double   vv[8], xx[8];
+        unsigned cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                 // all stream loads first; positions past the slice's width re-read its last one
+            const int jj = j + u < w ? j + u : w - 1;
+            vv[u] = v[jj * 64];
+            cc[u] = c[jj * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xx[u] = a.x[seg[cc[u] >> ob] + (int)(cc[u] & om)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j + u < len) sum += vv[u] * xx[u];    // padding (value 0) is never added: a NaN or inf in x stays in the rows that own it
+    }
+    if (r < nrows) epilogue<EPI, HALO>(a, r, sum);
+}
+
+// ---------------------------------------------------------------------------
 // K1b: vector CSR (no LDS staging): G lanes own one row and stream it straight from
 // global memory, 256/G rows per workgroup.  Rows are contiguous in val/col, so a
 // wave still reads whole 128-B lines; there is no barrier and no LDS round trip.

@@ -108,12 +108,19 @@ def test_spmv_lane_variants(capi, name, lanes):
     assert np.all(np.abs(got - want) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
 
 
+def _sell_eligible(entries, M):
+    """the library's rule for the sliced-ELLPACK form: slices of 64 rows padded to their longest row, <= 12 % padding"""
+    n = np.bincount(np.asarray(entries["row"]), minlength=M)
+    padded = sum(64 * int(n[s:s + 64].max()) for s in range(0, M, 64))
+    return padded <= 1.12 * len(entries)
+
+
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9])
 def test_kernel_variants(capi, name, variant, monkeypatch):
     """32 KiB tiles / vector CSR / 16-bit compressed columns (16 and 32 KiB tiles; long rows included) / wave-streamed
-    long rows / compressed columns with the block's entries in column order (16 and 32 KiB tiles): same results as the
-    default kernel"""
+    long rows / compressed columns with the block's entries in column order (16 and 32 KiB tiles) / sliced ELLPACK:
+    same results as the default kernel"""
     monkeypatch.setenv("SAENA_KEEP_HOST_VALUES", "1")      # the column-major form is built from a host copy of the values
     entries, M = get_problem(name)
     A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
@@ -122,11 +129,17 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         with pytest.raises(capi.SgpuError, match="column-major"):      # rows longer than the 16 KiB tile: refused, not mis-computed
             G.set_variant(variant)
         return
+    if variant == 9 and not _sell_eligible(entries, M):
+        with pytest.raises(capi.SgpuError, match="sliced-ELLPACK"):    # uneven rows: more than 12 % padding, refused
+            G.set_variant(variant)
+        return
     G.set_variant(variant)                # the compressed-column forms serve every one of these operators
     if variant in (3, 4):
         assert "k_csr_cc16" in G.variant()[1]
     if variant in (7, 8):
         assert "k_csr_cm" in G.variant()[1]
+    if variant == 9:
+        assert G.variant()[1] == "k_sell"
     x, rhs = inputs.v2(M), inputs.rhs2(M)
     bound = abs_bound(entries, M, x)
     dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
@@ -134,7 +147,7 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         G.set_lanes_per_row(lanes)
         G.spmv(dx, dy)
         got, want = dy.download(), A.matvec(x)
-        if lanes == 1 and variant not in (2, 6) and (name != "band3000_1400" or variant in (1, 4, 8)):
+        if (lanes == 1 or variant == 9) and variant not in (2, 6) and (name != "band3000_1400" or variant in (1, 4, 8)):
             np.testing.assert_array_equal(got, want)          # stream variants keep the sequential row sum
         else:
             assert np.all(np.abs(got - want) <= TOL_SPMV * bound + 1e-300)
@@ -339,7 +352,7 @@ def test_halo_path_emulated_ranks(capi, name, nprocs, fp32):
 
 @pytest.mark.parametrize("name,nprocs", [("poisson20", 3), ("band64_63", 2), ("irregular5000", 5)])
 def test_halo_path_column_ordered_kernel(capi, name, nprocs, monkeypatch):
-    """k_csr_cm with a halo in play (boundary rows masked out of the local launch, computed by k_csr_boundary): the
+    """k_csr_cm (and k_sell) with a halo in play (boundary rows masked out of the local launch, computed by k_csr_boundary): the
     same bits as k_csr_cc16 on every simulated rank, for the product and for a Jacobi sweep."""
     monkeypatch.setenv("SAENA_KEEP_HOST_VALUES", "1")
     entries, M = get_problem(name)
@@ -348,7 +361,7 @@ def test_halo_path_column_ordered_kernel(capi, name, nprocs, monkeypatch):
     W = util.EmulatedWorld(A)
     x, rhs = inputs.v2(M), inputs.rhs2(M)
     out = {}
-    for variant in (4, 8):
+    for variant in (4, 8) + ((9,) if name == "poisson20" else ()):
         xs, ys, rs, us = W.slices(x, split), W.slices(np.zeros(M), split), W.slices(rhs, split), W.slices(x, split)
         W.exchange(xs); W.exchange(us)
         for r in range(nprocs):
@@ -358,6 +371,9 @@ def test_halo_path_column_ordered_kernel(capi, name, nprocs, monkeypatch):
         out[variant] = (W.gather(ys), W.gather(us))
     np.testing.assert_array_equal(out[8][0], out[4][0])
     np.testing.assert_array_equal(out[8][1], out[4][1])
+    if 9 in out:                                              # sliced ELLPACK: the sequential row sum as well
+        np.testing.assert_array_equal(out[9][0], out[4][0])
+        np.testing.assert_array_equal(out[9][1], out[4][1])
     assert np.all(np.abs(out[8][0] - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
     assert rel(out[8][1], A.jacobi(1, x, rhs)) <= TOL_SMOOTH
 

@@ -10,7 +10,7 @@ import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-want = sys.argv[2] if len(sys.argv) > 2 else "k_csr"
+want = sys.argv[2] if len(sys.argv) > 2 else "sk::k_"
 g = collections.defaultdict(list)
 for r in rows:
     if want in r["Kernel_Name"]:

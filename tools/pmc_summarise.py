@@ -6,12 +6,13 @@ import sys
 from collections import defaultdict
 
 d, variant = sys.argv[1], int(sys.argv[2])
-want = {3: "k_csr_cc16", 0: "k_csr_stream"}[variant]
+want = {3: "k_csr_cc16", 0: "k_csr_stream", 9: "k_sell"}[variant]
+inst = {3: "<0, 1, 2048", 0: "<0, 1, 2048", 9: "k_sell<0, "}[variant]     # the SpMV instantiation of the 128^3 fine level
 vals = defaultdict(list)
 kernel = None
 for f in sorted(glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        if want in row["Kernel_Name"] and "<0, 1, 2048" in row["Kernel_Name"]:
+        if want in row["Kernel_Name"] and inst in row["Kernel_Name"]:
             kernel = row["Kernel_Name"]
             vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
 # the 5 warm-up launches come first: keep the last 40 (the timed steps)
