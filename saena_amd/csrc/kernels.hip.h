@@ -646,6 +646,64 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wave(const SpmvArgs a, int nrows)
 }
 
 // ---------------------------------------------------------------------------
+// K1x: the whole input vector in LDS, for operators with at most XL_MAX local columns (the coarse levels of thousands of
+// entries per row, and the transfers into them: 256^3 L4, 20 K rows x 2 800 entries).  On those levels the k_csr_cc16 /
+// k_csr_wave gathers go out to the L2 two to three times per line of stream data and the kernels sit at 45-50 % of the
+// roofline; here one 1024-thread workgroup per CU copies x into LDS once (<= 158 KB, read from the L2), then its 16 waves
+// stream rows like k_csr_wave -- 16-byte value loads, 8-byte loads of four 16-bit ABSOLUTE column ids (10 B/nnz, no
+// segment table), four quads in flight per lane -- and every gather is an LDS read.  The workgroup owns an nnz-balanced
+// chunk of consecutive rows (a.blk_row); its waves take the chunk's rows from a shared counter.
+constexpr int XL_MAX   = 20224;            // doubles of x in LDS: 161 792 B of the CU's 163 840
+constexpr int XL_BLOCK = 1024;
+template <int EPI, bool HALO>
+__global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, int ncols) {
+    __shared__ __attribute__((aligned(16))) double xs[XL_MAX];
+    __shared__ int next_row;
+    if constexpr (HALO) fork_signal(a);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < ncols; i += XL_BLOCK) xs[i] = a.x[i];
+    if (tid == 0) next_row = XL_BLOCK / 64;                       // the first 16 rows go to the 16 waves in order
+    __syncthreads();
+    const int r0 = a.blk_row[blockIdx.x], r1 = a.blk_row[blockIdx.x + 1];
+    int r = r0 + wv;
+    while (r < r1) {                                              // (wave-uniform)
+        const int p0 = a.row_ptr[r], p1 = a.row_ptr[r + 1];
+        const int a0 = p0 & ~3;
+        const int nq = (p1 - a0 + 3) >> 2;
+        double sum = 0.0;
+        for (int q = lane; q < nq; q += 4 * 64) {
+            double2 v01[4], v23[4];
+            uint2   c[4];
+            int     i[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                         // a lane without a k-th quad re-reads its first and drops it
+                i[k] = q + 64 * k < nq ? a0 + 4 * (q + 64 * k) : a0 + 4 * q;
+                v01[k] = ld_stream_d2(a.val + i[k]);
+                v23[k] = ld_stream_d2(a.val + i[k] + 2);
+                c[k]   = ld_stream_u2(a.ccol + i[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double x0 = xs[c[k].x & 0xffffu], x1 = xs[c[k].x >> 16], x2 = xs[c[k].y & 0xffffu], x3 = xs[c[k].y >> 16];
+                if (k > 0 && q + 64 * k >= nq) { v01[k].x = v01[k].y = v23[k].x = v23[k].y = 0.0; }
+                else if (i[k] < p0 || i[k] + 4 > p1) {            // first / last quad of the row: drop the neighbours' entries
+                    v01[k].x = stray(i[k], p0, p1) ? 0.0 : v01[k].x;     v01[k].y = stray(i[k] + 1, p0, p1) ? 0.0 : v01[k].y;
+                    v23[k].x = stray(i[k] + 2, p0, p1) ? 0.0 : v23[k].x; v23[k].y = stray(i[k] + 3, p0, p1) ? 0.0 : v23[k].y;
+                }
+                sum += v01[k].x * x0; sum += v01[k].y * x1; sum += v23[k].x * x2; sum += v23[k].y * x3;
+            }
+        }
+        sum = group_sum<64>(sum);
+        int nr = 0;
+        if (lane == 0) {
+            epilogue<EPI, HALO>(a, r, sum);
+            nr = atomicAdd(&next_row, 1);
+        }
+        r = r0 + __shfl(nr, 0, 64);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K1c: dense row-major operator (saena_matrix_dense::matvec_dense, src/saena_matrix_dense.cpp:181-260,
 // the reference's optional `switch_to_dense` storage for coarse levels that are mostly full).  One wave per row streams
 // the row with coalesced 8-byte loads (no column ids: 8 B per entry instead of 12), the fused epilogues are the sparse ones.

@@ -65,6 +65,7 @@ int fail(int code, const char *fmt, ...) {
 struct Ctx {
     bool        live = false;
     int         device = 0, rank = 0, nranks = 1;
+    int         ncu = 256;            // compute units of the device (k_csr_xlds launches one workgroup per CU)
     hipStream_t cs = nullptr, hs = nullptr;
     ncclComm_t  comm = nullptr;
     double     *partials = nullptr;   // dot partial sums
@@ -152,6 +153,13 @@ struct CsrPart {
         hipFree(sl_val); hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr); hipFree(sl_ptr);
         sl_val = nullptr; sl_col = sl_len = nullptr; sl_base = sl_segptr = sl_ptr = nullptr; sl_ok = false; sl_tried = 0;
     }
+    // x in LDS (variant 10): absolute 16-bit column ids and nnz-balanced row chunks, one per CU
+    unsigned short *xl_col = nullptr;
+    int            *xl_blk = nullptr;
+    int             xl_nblk = 0;
+    bool            xl_ok = false;
+    char            xl_tried = 0;
+    void free_xlds() { hipFree(xl_col); hipFree(xl_blk); xl_col = nullptr; xl_blk = nullptr; xl_ok = false; xl_tried = 0; }
     int             cc_ob[2] = {12, 12};   // offset bits of the slot/offset split (12: 16 segments of 4096 columns ... 8: 256 of 256)
     char            cc_tried[2] = {0, 0};  // build_cc16 ran and found no split that fits (do not try again)
     std::vector<int> h_rp, h_col, h_blk, h_blk_big;   // host copies kept for build_cc16 / the coarsest factorisation
@@ -162,6 +170,7 @@ struct CsrPart {
         for (int k = 0; k < 2; ++k) { hipFree(cm_val[k]); hipFree(cm_col[k]); hipFree(cm_dst[k]); hipFree(cm_ptr[k]); cm_val[k] = nullptr; cm_col[k] = cm_dst[k] = nullptr; cm_ptr[k] = nullptr; }
         row_ptr = col = blk_row = blk_row_big = rows = nullptr; val = nullptr;
         free_sell();
+        free_xlds();
     }
 };
 
@@ -368,6 +377,30 @@ int build_cm(CsrPart &P, int k, const std::vector<double> &h_val_all) {
     CHK(dev_upload(&P.cm_dst[k], dst.data(), dst.size()));
     CHK(dev_upload(&P.cm_ptr[k], cmptr.data(), cmptr.size()));
     P.cm_ok[k] = true;
+    return SGPU_OK;
+}
+
+// x-in-LDS form of the local part (k_csr_xlds): at most XL_MAX columns; 16-bit absolute column ids, the rows cut into one
+// nnz-balanced chunk per CU.
+int build_xlds(CsrPart &P) {
+    if (P.xl_ok || P.xl_tried || P.h_rp.empty()) return SGPU_OK;
+    P.xl_tried = 1;
+    const int M = P.nrows;
+    if (M == 0 || P.ncols > sk::XL_MAX || P.nnz == 0) return SGPU_OK;
+    std::vector<unsigned short> col(P.h_col.size() + 8, 0);
+    for (size_t i = 0; i < P.h_col.size(); ++i) col[i] = (unsigned short)P.h_col[i];
+    const int nb = std::min(std::max(1, g.ncu), M);
+    std::vector<int> blk((size_t)nb + 1, 0);
+    for (int b = 1; b < nb; ++b) {                                 // row whose prefix reaches b/nb of the entries
+        const int64_t target = (int64_t)P.nnz * b / nb;
+        int r = (int)(std::lower_bound(P.h_rp.begin(), P.h_rp.end(), (int)target) - P.h_rp.begin());
+        blk[(size_t)b] = std::min(M, std::max(r, blk[(size_t)b - 1]));
+    }
+    blk[(size_t)nb] = M;
+    CHK(dev_upload(&P.xl_col, col.data(), col.size()));
+    CHK(dev_upload(&P.xl_blk, blk.data(), blk.size()));
+    P.xl_nblk = nb;
+    P.xl_ok = true;
     return SGPU_OK;
 }
 
@@ -591,6 +624,18 @@ SellKernelFn pick_sell_h(int epi) {
     }
 }
 SellKernelFn pick_sell(int epi, bool halo) { return halo ? pick_sell_h<true>(epi) : pick_sell_h<false>(epi); }
+template <bool HALO>
+SellKernelFn pick_xlds_h(int epi) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return sk::k_csr_xlds<sk::EPI_SPMV, HALO>;
+        case sk::EPI_RESIDUAL: return sk::k_csr_xlds<sk::EPI_RESIDUAL, HALO>;
+        case sk::EPI_JACOBI:   return sk::k_csr_xlds<sk::EPI_JACOBI, HALO>;
+        case sk::EPI_CHEBY0:   return sk::k_csr_xlds<sk::EPI_CHEBY0, HALO>;
+        case sk::EPI_CHEBYK:   return sk::k_csr_xlds<sk::EPI_CHEBYK, HALO>;
+        default:               return sk::k_csr_xlds<sk::EPI_SUB, HALO>;
+    }
+}
+SellKernelFn pick_xlds(int epi, bool halo) { return halo ? pick_xlds_h<true>(epi) : pick_xlds_h<false>(epi); }
 
 int launch_part(const CsrPart &P, int epi, const double *x, double *y, const EpiArgs &e, const unsigned *skip = nullptr, uint64_t seq = 0) {
     if (P.nblk == 0) return SGPU_OK;
@@ -610,6 +655,10 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
             : epi == sk::EPI_JACOBI ? sk::k_dense_rows<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows<sk::EPI_CHEBY0>
             : epi == sk::EPI_CHEBYK ? sk::k_dense_rows<sk::EPI_CHEBYK> : sk::k_dense_rows<sk::EPI_SUB>;
         SGPU_LAUNCH(kd, dim3((P.nrows + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, (const double *)P.dense, P.nrows, P.ncols);
+    } else if (P.variant == 10) {                                 // x in LDS, a workgroup per CU
+        if (!P.xl_ok) return fail(SGPU_ERR_STATE, "the x-in-LDS form was not built");
+        a.blk_row = P.xl_blk; a.nblk = P.xl_nblk; a.ccol = P.xl_col;
+        SGPU_LAUNCH(pick_xlds(epi, halo), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, P.ncols);
     } else if (P.variant == 9) {                                  // sliced ELLPACK, a lane per row
         if (!P.sl_ok) return fail(SGPU_ERR_STATE, "the sliced-ELLPACK form was not built");
         a.blk_row = nullptr; a.nblk = P.nslices;
@@ -1018,6 +1067,7 @@ int sgpu_init(int device_id, int rank, int nranks, const void *uid) {
     if (ndev == 0) return fail(SGPU_ERR_HIP, "no HIP device visible: libsaena_amd needs an MI355X (there is no CPU fallback)");
     if (device_id < 0 || device_id >= ndev) return fail(SGPU_ERR_ARG, "device %d not in [0,%d)", device_id, ndev);
     HIPCHK(hipSetDevice(device_id));
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && n > 0) g.ncu = n; }
     g.device = device_id; g.rank = rank; g.nranks = nranks;
     HIPCHK(hipStreamCreateWithFlags(&g.cs, hipStreamNonBlocking));
     {   // the halo stream's small kernels (pack, RCCL, boundary rows) must not queue behind the interior launch
@@ -1320,7 +1370,7 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell"};   // (3, 4, 7, 8 are named with their slot/offset split below)
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds"};   // (3, 4, 7, 8 are named with their slot/offset split below)
     if (variant) *variant = op->loc.variant;
     if (kernel_name) {
         const int v = op->loc.variant;
@@ -1339,7 +1389,11 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 9) return fail(SGPU_ERR_ARG, "variant must be 0..9");
+    if (variant < 0 || variant > 10) return fail(SGPU_ERR_ARG, "variant must be 0..10");
+    if (variant == 10) {
+        CHK(build_xlds(op->loc));
+        if (!op->loc.xl_ok) return fail(SGPU_ERR_ARG, "the x-in-LDS form serves operators with at most %d local columns", sk::XL_MAX);
+    }
     if (variant == 9) {
         CHK(build_sell(op->loc, op->h_val_all));
         if (!op->loc.sl_ok)
@@ -1381,6 +1435,10 @@ int sgpu_op_autotune(sgpu_op *op) {
     std::vector<int> variants = {0, 1, 2};
     for (int k = 0; k < 2; ++k) { CHK(build_cc16(op->loc, k)); if (op->loc.cc_ok[k]) variants.push_back(3 + k); }
     if (op->loc.nnz >= 256 * (int64_t)std::max(1, op->loc.nrows)) variants.push_back(6);   // long rows: the wave-streamed kernel
+    if (op->loc.ncols <= sk::XL_MAX && op->loc.nnz >= 128 * (int64_t)std::max(1, op->loc.nrows) && !std::getenv("SAENA_NO_XLDS")) {
+        CHK(build_xlds(op->loc));                                                           // long rows over few columns: x in LDS
+        if (op->loc.xl_ok) variants.push_back(10);
+    }
     if (!op->h_val_all.empty()) {
         const double avg_row = (double)op->loc.nnz / std::max(1, op->loc.nrows);
         if (avg_row >= 96.0 && avg_row <= 768.0 && !std::getenv("SAENA_NO_CM")) {         // rows of a few hundred entries: column order inside the block
@@ -1411,7 +1469,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     for (int round = 0; round < 3; ++round)
         for (int v : variants)
             for (int gl : lanes) {
-                if (v == 9 && gl != lanes.front()) continue;      // a lane per row whatever the setting
+                if ((v == 9 || v == 10) && gl != lanes.front()) continue;      // a lane / a wave per row whatever the setting
                 op->loc.variant = v; op->loc.lanes = gl;
                 const int reps = round == 0 ? 3 : 6;
                 HIPCHK(hipEventRecord(e0, g.cs));
@@ -1442,6 +1500,7 @@ int sgpu_op_autotune(sgpu_op *op) {
             op->loc.cm_ok[k] = false; op->loc.cm_tried[k] = 0;
         }
     if (bv != 9 && !keep) op->loc.free_sell();
+    if (bv != 10 && !keep) op->loc.free_xlds();
     if (!keep) std::vector<double>().swap(op->h_val_all);       // (a later set_variant(7/8/9) on this operator is refused: the values are gone)
     for (int k = 0; k < 2; ++k)                       // free the compressed arrays of the plans that lost
         if (op->loc.cc_ok[k] && bv != 3 + k && bv != 7 + k) {

@@ -12,7 +12,7 @@ import numpy as np
 
 from saena_amd import capi
 
-VARIANTS = {0: "s16K", 1: "s32K", 2: "vec", 3: "cc16K", 4: "cc32K", 6: "wave", 7: "cm16K", 8: "cm32K", 9: "sell"}
+VARIANTS = {0: "s16K", 1: "s32K", 2: "vec", 3: "cc16K", 4: "cc32K", 6: "wave", 7: "cm16K", 8: "cm32K", 9: "sell", 10: "xlds"}
 
 
 def box_csr(n, r):

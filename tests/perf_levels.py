@@ -10,7 +10,7 @@ import numpy as np
 
 from saena_amd import capi, host
 
-VARIANTS = {0: "s16K", 1: "s32K", 2: "vec", 3: "cc16K", 4: "cc32K", 6: "wave", 7: "cm16K", 8: "cm32K", 9: "sell"}
+VARIANTS = {0: "s16K", 1: "s32K", 2: "vec", 3: "cc16K", 4: "cc32K", 6: "wave", 7: "cm16K", 8: "cm32K", 9: "sell", 10: "xlds"}
 
 
 def sweep(name, op, kind, x, rhs, y, lanes_list, reps):

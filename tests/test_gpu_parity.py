@@ -116,11 +116,11 @@ def _sell_eligible(entries, M):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10])
 def test_kernel_variants(capi, name, variant, monkeypatch):
     """32 KiB tiles / vector CSR / 16-bit compressed columns (16 and 32 KiB tiles; long rows included) / wave-streamed
-    long rows / compressed columns with the block's entries in column order (16 and 32 KiB tiles) / sliced ELLPACK:
-    same results as the default kernel"""
+    long rows / compressed columns with the block's entries in column order (16 and 32 KiB tiles) / sliced ELLPACK /
+    x in LDS: same results as the default kernel"""
     monkeypatch.setenv("SAENA_KEEP_HOST_VALUES", "1")      # the column-major form is built from a host copy of the values
     entries, M = get_problem(name)
     A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
@@ -140,6 +140,8 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         assert "k_csr_cm" in G.variant()[1]
     if variant == 9:
         assert G.variant()[1] == "k_sell"
+    if variant == 10:
+        assert G.variant()[1] == "k_csr_xlds"
     x, rhs = inputs.v2(M), inputs.rhs2(M)
     bound = abs_bound(entries, M, x)
     dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
@@ -147,7 +149,7 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         G.set_lanes_per_row(lanes)
         G.spmv(dx, dy)
         got, want = dy.download(), A.matvec(x)
-        if (lanes == 1 or variant == 9) and variant not in (2, 6) and (name != "band3000_1400" or variant in (1, 4, 8)):
+        if (lanes == 1 or variant == 9) and variant not in (2, 6, 10) and (name != "band3000_1400" or variant in (1, 4, 8)):
             np.testing.assert_array_equal(got, want)          # stream variants keep the sequential row sum
         else:
             assert np.all(np.abs(got - want) <= TOL_SPMV * bound + 1e-300)
@@ -371,6 +373,15 @@ def test_halo_path_column_ordered_kernel(capi, name, nprocs, monkeypatch):
         out[variant] = (W.gather(ys), W.gather(us))
     np.testing.assert_array_equal(out[8][0], out[4][0])
     np.testing.assert_array_equal(out[8][1], out[4][1])
+    for r in range(nprocs):                                   # x in LDS (a wave per row: its own summation order)
+        W.g[r].set_variant(10)
+    xs, ys, rs, us = W.slices(x, split), W.slices(np.zeros(M), split), W.slices(rhs, split), W.slices(x, split)
+    W.exchange(xs); W.exchange(us)
+    for r in range(nprocs):
+        W.g[r].spmv(xs[r], ys[r])
+        W.g[r].jacobi(1, us[r], rs[r])
+    assert np.all(np.abs(W.gather(ys) - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
+    assert rel(W.gather(us), A.jacobi(1, x, rhs)) <= TOL_SMOOTH
     if 9 in out:                                              # sliced ELLPACK: the sequential row sum as well
         np.testing.assert_array_equal(out[9][0], out[4][0])
         np.testing.assert_array_equal(out[9][1], out[4][1])
