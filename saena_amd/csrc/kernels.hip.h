@@ -646,60 +646,83 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wave(const SpmvArgs a, int nrows)
 }
 
 // ---------------------------------------------------------------------------
-// K1x: the whole input vector in LDS, for operators with at most XL_MAX local columns (the coarse levels of thousands of
-// entries per row, and the transfers into them: 256^3 L4, 20 K rows x 2 800 entries).  On those levels the k_csr_cc16 /
-// k_csr_wave gathers go out to the L2 two to three times per line of stream data and the kernels sit at 45-50 % of the
-// roofline; here one 1024-thread workgroup per CU copies x into LDS once (<= 158 KB, read from the L2), then its 16 waves
-// stream rows like k_csr_wave -- 16-byte value loads, 8-byte loads of four 16-bit ABSOLUTE column ids (10 B/nnz, no
-// segment table), four quads in flight per lane -- and every gather is an LDS read.  The workgroup owns an nnz-balanced
-// chunk of consecutive rows (a.blk_row); its waves take the chunk's rows from a shared counter.
+// K1x: the input vector in LDS, for the coarse levels of hundreds to thousands of entries per row and the transfers
+// into them.  There the k_csr_cc16 / k_csr_wave gathers go out to the L2 two to three times per line of stream data and
+// the kernels sit at 45-60 % of the roofline.  Here one 1024-thread workgroup per CU owns an nnz-balanced chunk of
+// consecutive rows (a.blk_row); the columns the chunk touches are cut into windows of XL_MAX columns (one window when
+// the operator has no more columns than that: 256^3 L4, 20 K x 20 K; two for L3, whose rows reach over 26 K columns;
+// at most XL_MAXT).  Per window the workgroup copies that piece of x into LDS (<= 158 KB, read from the L2), then G-lane
+// groups take the chunk's rows from a shared counter and stream each row's entries of this window like k_csr_wave --
+// 16-byte value loads, 8-byte loads of four 16-bit column ids RELATIVE TO THE WINDOW (10 B/nnz, no segment table), four
+// quads in flight per lane -- and every gather is an LDS read.  A row's partial sums are added window by window in
+// ascending column order (through `acc` in global memory when there is more than one window); the epilogue runs after
+// the last.  tab: per workgroup (T+1) x rows entry offsets, window t of row k = [tab[t*rows + k], tab[(t+1)*rows + k]).
 constexpr int XL_MAX   = 20224;            // doubles of x in LDS: 161 792 B of the CU's 163 840
+constexpr int XL_MAXT  = 8;
 constexpr int XL_BLOCK = 1024;
-template <int EPI, bool HALO>
-__global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, int ncols) {
+struct XldsArgs {
+    const int4 *info;      // per workgroup: first column, windows, offset of its table in `tab`, -
+    const int  *tab;
+    double     *acc;       // [M] partial row sums between windows (nullptr when every workgroup has one window)
+    int         ncols;
+};
+template <int EPI, int G, bool HALO>
+__global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const XldsArgs w) {
     __shared__ __attribute__((aligned(16))) double xs[XL_MAX];
     __shared__ int next_row;
     if constexpr (HALO) fork_signal(a);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < ncols; i += XL_BLOCK) xs[i] = a.x[i];
-    if (tid == 0) next_row = XL_BLOCK / 64;                       // the first 16 rows go to the 16 waves in order
-    __syncthreads();
-    const int r0 = a.blk_row[blockIdx.x], r1 = a.blk_row[blockIdx.x + 1];
-    int r = r0 + wv;
-    while (r < r1) {                                              // (wave-uniform)
-        const int p0 = a.row_ptr[r], p1 = a.row_ptr[r + 1];
-        const int a0 = p0 & ~3;
-        const int nq = (p1 - a0 + 3) >> 2;
-        double sum = 0.0;
-        for (int q = lane; q < nq; q += 4 * 64) {
-            double2 v01[4], v23[4];
-            uint2   c[4];
-            int     i[4];
+    const int tid = threadIdx.x, lane = tid & 63, l = tid % G;
+    constexpr int NG = XL_BLOCK / G;
+    const int r0 = a.blk_row[blockIdx.x], nr = a.blk_row[blockIdx.x + 1] - r0;
+    const int4 inf = w.info[blockIdx.x];
+    const int T = inf.y;
+    for (int t = 0; t < T; ++t) {
+        if (t > 0) __syncthreads();                               // everyone is done with the previous window
+        const int base = inf.x + t * XL_MAX;
+        const int n = w.ncols - base < XL_MAX ? w.ncols - base : XL_MAX;
+        for (int i = tid; i < n; i += XL_BLOCK) xs[i] = a.x[base + i];
+        if (tid == 0) next_row = NG;                              // the first NG rows go to the groups in order
+        __syncthreads();
+        const int *ts = w.tab + inf.z + t * nr, *te = ts + nr;
+        int k = tid / G;
+        while (k < nr) {
+            const int p0 = ts[k], p1 = te[k];
+            const int a0 = p0 & ~3;
+            const int nq = (p1 - a0 + 3) >> 2;
+            double sum = 0.0;
+            for (int q = l; q < nq; q += 4 * G) {
+                double2 v01[4], v23[4];
+                uint2   c[4];
+                int     i[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {                         // a lane without a k-th quad re-reads its first and drops it
-                i[k] = q + 64 * k < nq ? a0 + 4 * (q + 64 * k) : a0 + 4 * q;
-                v01[k] = ld_stream_d2(a.val + i[k]);
-                v23[k] = ld_stream_d2(a.val + i[k] + 2);
-                c[k]   = ld_stream_u2(a.ccol + i[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double x0 = xs[c[k].x & 0xffffu], x1 = xs[c[k].x >> 16], x2 = xs[c[k].y & 0xffffu], x3 = xs[c[k].y >> 16];
-                if (k > 0 && q + 64 * k >= nq) { v01[k].x = v01[k].y = v23[k].x = v23[k].y = 0.0; }
-                else if (i[k] < p0 || i[k] + 4 > p1) {            // first / last quad of the row: drop the neighbours' entries
-                    v01[k].x = stray(i[k], p0, p1) ? 0.0 : v01[k].x;     v01[k].y = stray(i[k] + 1, p0, p1) ? 0.0 : v01[k].y;
-                    v23[k].x = stray(i[k] + 2, p0, p1) ? 0.0 : v23[k].x; v23[k].y = stray(i[k] + 3, p0, p1) ? 0.0 : v23[k].y;
+                for (int u = 0; u < 4; ++u) {                     // a lane without a u-th quad re-reads its first and drops it
+                    i[u] = q + G * u < nq ? a0 + 4 * (q + G * u) : a0 + 4 * q;
+                    v01[u] = ld_stream_d2(a.val + i[u]);
+                    v23[u] = ld_stream_d2(a.val + i[u] + 2);
+                    c[u]   = ld_stream_u2(a.ccol + i[u]);
                 }
-                sum += v01[k].x * x0; sum += v01[k].y * x1; sum += v23[k].x * x2; sum += v23[k].y * x3;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double x0 = xs[c[u].x & 0xffffu], x1 = xs[c[u].x >> 16], x2 = xs[c[u].y & 0xffffu], x3 = xs[c[u].y >> 16];
+                    if (u > 0 && q + G * u >= nq) x0 = x1 = x2 = x3 = 0.0;
+                    else if (i[u] < p0 || i[u] + 4 > p1) {        // first / last quad: the neighbours' entries (other rows, other windows) count as zero
+                        x0 = stray(i[u], p0, p1) ? 0.0 : x0;     x1 = stray(i[u] + 1, p0, p1) ? 0.0 : x1;
+                        x2 = stray(i[u] + 2, p0, p1) ? 0.0 : x2; x3 = stray(i[u] + 3, p0, p1) ? 0.0 : x3;
+                    }
+                    sum += v01[u].x * x0; sum += v01[u].y * x1; sum += v23[u].x * x2; sum += v23[u].y * x3;
+                }
             }
+            sum = group_sum<G>(sum);
+            int nk = 0;
+            if (l == 0) {
+                const int r = r0 + k;
+                if (t > 0) sum = w.acc[r] + sum;
+                if (t < T - 1) w.acc[r] = sum;
+                else epilogue<EPI, HALO>(a, r, sum);
+                nk = atomicAdd(&next_row, 1);
+            }
+            k = __shfl(nk, lane & ~(G - 1), 64);
         }
-        sum = group_sum<64>(sum);
-        int nr = 0;
-        if (lane == 0) {
-            epilogue<EPI, HALO>(a, r, sum);
-            nr = atomicAdd(&next_row, 1);
-        }
-        r = r0 + __shfl(nr, 0, 64);
     }
 }
 

@@ -155,11 +155,17 @@ struct CsrPart {
     }
     // x in LDS (variant 10): absolute 16-bit column ids and nnz-balanced row chunks, one per CU
     unsigned short *xl_col = nullptr;
-    int            *xl_blk = nullptr;
-    int             xl_nblk = 0;
+    int            *xl_blk = nullptr, *xl_tab = nullptr;
+    int4           *xl_info = nullptr;
+    double         *xl_acc = nullptr;
+    int             xl_nblk = 0, xl_maxt = 1;
+    double          xl_piece = 0.0;
     bool            xl_ok = false;
     char            xl_tried = 0;
-    void free_xlds() { hipFree(xl_col); hipFree(xl_blk); xl_col = nullptr; xl_blk = nullptr; xl_ok = false; xl_tried = 0; }
+    void free_xlds() {
+        hipFree(xl_col); hipFree(xl_blk); hipFree(xl_tab); hipFree(xl_info); hipFree(xl_acc);
+        xl_col = nullptr; xl_blk = xl_tab = nullptr; xl_info = nullptr; xl_acc = nullptr; xl_ok = false; xl_tried = 0;
+    }
     int             cc_ob[2] = {12, 12};   // offset bits of the slot/offset split (12: 16 segments of 4096 columns ... 8: 256 of 256)
     char            cc_tried[2] = {0, 0};  // build_cc16 ran and found no split that fits (do not try again)
     std::vector<int> h_rp, h_col, h_blk, h_blk_big;   // host copies kept for build_cc16 / the coarsest factorisation
@@ -380,15 +386,14 @@ int build_cm(CsrPart &P, int k, const std::vector<double> &h_val_all) {
     return SGPU_OK;
 }
 
-// x-in-LDS form of the local part (k_csr_xlds): at most XL_MAX columns; 16-bit absolute column ids, the rows cut into one
-// nnz-balanced chunk per CU.
+// x-in-LDS form of the local part (k_csr_xlds): the rows cut into one nnz-balanced chunk per CU, the columns a chunk
+// touches into windows of XL_MAX; 16-bit column ids relative to the window, per chunk a table of each row's entry offsets
+// per window.  Refused when a chunk needs more than XL_MAXT windows.
 int build_xlds(CsrPart &P) {
     if (P.xl_ok || P.xl_tried || P.h_rp.empty()) return SGPU_OK;
     P.xl_tried = 1;
     const int M = P.nrows;
-    if (M == 0 || P.ncols > sk::XL_MAX || P.nnz == 0) return SGPU_OK;
-    std::vector<unsigned short> col(P.h_col.size() + 8, 0);
-    for (size_t i = 0; i < P.h_col.size(); ++i) col[i] = (unsigned short)P.h_col[i];
+    if (M == 0 || P.nnz == 0) return SGPU_OK;
     const int nb = std::min(std::max(1, g.ncu), M);
     std::vector<int> blk((size_t)nb + 1, 0);
     for (int b = 1; b < nb; ++b) {                                 // row whose prefix reaches b/nb of the entries
@@ -397,9 +402,57 @@ int build_xlds(CsrPart &P) {
         blk[(size_t)b] = std::min(M, std::max(r, blk[(size_t)b - 1]));
     }
     blk[(size_t)nb] = M;
+    std::vector<int4> info((size_t)nb);
+    int64_t tabsz = 0, pieces = 0;
+    int maxt = 1;
+    for (int b = 0; b < nb; ++b) {
+        int cmin = INT32_MAX, cmax = -1;
+        for (int r = blk[b]; r < blk[b + 1]; ++r)
+            if (P.h_rp[r + 1] > P.h_rp[r]) { cmin = std::min(cmin, P.h_col[(size_t)P.h_rp[r]]); cmax = std::max(cmax, P.h_col[(size_t)P.h_rp[r + 1] - 1]); }
+        if (cmax < 0) { cmin = 0; cmax = 0; }
+        const int T = (cmax - cmin) / sk::XL_MAX + 1, rows = blk[b + 1] - blk[b];
+        if (T > sk::XL_MAXT) return SGPU_OK;
+        maxt = std::max(maxt, T);
+        info[(size_t)b] = make_int4(cmin, T, (int)tabsz, 0);
+        tabsz += (int64_t)rows * (T + 1);
+        pieces += (int64_t)rows * T;
+        if (tabsz > INT32_MAX / 2) return SGPU_OK;
+    }
+    P.xl_piece = (double)P.nnz / (double)std::max<int64_t>(1, pieces);    // mean entries per (row, window): the autotune wants >= 24
+    std::vector<unsigned short> col(P.h_col.size() + 8, 0);
+    std::vector<int> tab((size_t)tabsz + 1, 0);
+    const int nt = std::min(host_threads(), std::max(1, nb / 8));
+    auto work = [&](int t) {
+        for (int b = (int)((long)nb * t / nt); b < (int)((long)nb * (t + 1) / nt); ++b) {
+            const int r0 = blk[b], rows = blk[b + 1] - r0, cmin = info[(size_t)b].x, T = info[(size_t)b].y;
+            int *tb = tab.data() + info[(size_t)b].z;
+            for (int k = 0; k < rows; ++k) {
+                const int p0 = P.h_rp[r0 + k], p1 = P.h_rp[r0 + k + 1];
+                int p = p0;
+                for (int w = 0; w <= T; ++w) {                     // columns ascend along a row: the windows cut it into consecutive pieces
+                    const int lim = w == T ? INT32_MAX : cmin + w * sk::XL_MAX;
+                    while (p < p1 && P.h_col[(size_t)p] < lim) {
+                        col[(size_t)p] = (unsigned short)(P.h_col[(size_t)p] - (cmin + (w - 1) * sk::XL_MAX));
+                        ++p;
+                    }
+                    tb[(size_t)w * rows + k] = w == T ? p1 : p;
+                }
+            }
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
     CHK(dev_upload(&P.xl_col, col.data(), col.size()));
     CHK(dev_upload(&P.xl_blk, blk.data(), blk.size()));
+    CHK(dev_upload(&P.xl_tab, tab.data(), tab.size()));
+    CHK(dev_upload(&P.xl_info, info.data(), info.size()));
+    if (maxt > 1) HIPCHK(hipMalloc(&P.xl_acc, (size_t)M * sizeof(double)));
     P.xl_nblk = nb;
+    P.xl_maxt = maxt;
     P.xl_ok = true;
     return SGPU_OK;
 }
@@ -624,18 +677,24 @@ SellKernelFn pick_sell_h(int epi) {
     }
 }
 SellKernelFn pick_sell(int epi, bool halo) { return halo ? pick_sell_h<true>(epi) : pick_sell_h<false>(epi); }
+using XldsKernelFn = void (*)(const sk::SpmvArgs, const sk::XldsArgs);
+template <int EPI, bool HALO>
+XldsKernelFn pick_xlds_g(int lanes) {
+    return lanes <= 4 ? sk::k_csr_xlds<EPI, 4, HALO> : lanes <= 8 ? sk::k_csr_xlds<EPI, 8, HALO> : lanes <= 16 ? sk::k_csr_xlds<EPI, 16, HALO> : lanes <= 32 ? sk::k_csr_xlds<EPI, 32, HALO>
+                                                                                                         : sk::k_csr_xlds<EPI, 64, HALO>;
+}
 template <bool HALO>
-SellKernelFn pick_xlds_h(int epi) {
+XldsKernelFn pick_xlds_h(int epi, int lanes) {
     switch (epi) {
-        case sk::EPI_SPMV:     return sk::k_csr_xlds<sk::EPI_SPMV, HALO>;
-        case sk::EPI_RESIDUAL: return sk::k_csr_xlds<sk::EPI_RESIDUAL, HALO>;
-        case sk::EPI_JACOBI:   return sk::k_csr_xlds<sk::EPI_JACOBI, HALO>;
-        case sk::EPI_CHEBY0:   return sk::k_csr_xlds<sk::EPI_CHEBY0, HALO>;
-        case sk::EPI_CHEBYK:   return sk::k_csr_xlds<sk::EPI_CHEBYK, HALO>;
-        default:               return sk::k_csr_xlds<sk::EPI_SUB, HALO>;
+        case sk::EPI_SPMV:     return pick_xlds_g<sk::EPI_SPMV, HALO>(lanes);
+        case sk::EPI_RESIDUAL: return pick_xlds_g<sk::EPI_RESIDUAL, HALO>(lanes);
+        case sk::EPI_JACOBI:   return pick_xlds_g<sk::EPI_JACOBI, HALO>(lanes);
+        case sk::EPI_CHEBY0:   return pick_xlds_g<sk::EPI_CHEBY0, HALO>(lanes);
+        case sk::EPI_CHEBYK:   return pick_xlds_g<sk::EPI_CHEBYK, HALO>(lanes);
+        default:               return pick_xlds_g<sk::EPI_SUB, HALO>(lanes);
     }
 }
-SellKernelFn pick_xlds(int epi, bool halo) { return halo ? pick_xlds_h<true>(epi) : pick_xlds_h<false>(epi); }
+XldsKernelFn pick_xlds(int epi, int lanes, bool halo) { return halo ? pick_xlds_h<true>(epi, lanes) : pick_xlds_h<false>(epi, lanes); }
 
 int launch_part(const CsrPart &P, int epi, const double *x, double *y, const EpiArgs &e, const unsigned *skip = nullptr, uint64_t seq = 0) {
     if (P.nblk == 0) return SGPU_OK;
@@ -658,7 +717,9 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     } else if (P.variant == 10) {                                 // x in LDS, a workgroup per CU
         if (!P.xl_ok) return fail(SGPU_ERR_STATE, "the x-in-LDS form was not built");
         a.blk_row = P.xl_blk; a.nblk = P.xl_nblk; a.ccol = P.xl_col;
-        SGPU_LAUNCH(pick_xlds(epi, halo), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, P.ncols);
+        sk::XldsArgs w;
+        w.info = P.xl_info; w.tab = P.xl_tab; w.acc = P.xl_acc; w.ncols = P.ncols;
+        SGPU_LAUNCH(pick_xlds(epi, P.lanes, halo), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, w);
     } else if (P.variant == 9) {                                  // sliced ELLPACK, a lane per row
         if (!P.sl_ok) return fail(SGPU_ERR_STATE, "the sliced-ELLPACK form was not built");
         a.blk_row = nullptr; a.nblk = P.nslices;
@@ -1392,7 +1453,9 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (variant < 0 || variant > 10) return fail(SGPU_ERR_ARG, "variant must be 0..10");
     if (variant == 10) {
         CHK(build_xlds(op->loc));
-        if (!op->loc.xl_ok) return fail(SGPU_ERR_ARG, "the x-in-LDS form serves operators with at most %d local columns", sk::XL_MAX);
+        if (!op->loc.xl_ok)
+            return fail(SGPU_ERR_ARG, "the x-in-LDS form needs row chunks (one per CU) that reach over at most %d columns",
+                        sk::XL_MAXT * sk::XL_MAX);
     }
     if (variant == 9) {
         CHK(build_sell(op->loc, op->h_val_all));
@@ -1435,9 +1498,9 @@ int sgpu_op_autotune(sgpu_op *op) {
     std::vector<int> variants = {0, 1, 2};
     for (int k = 0; k < 2; ++k) { CHK(build_cc16(op->loc, k)); if (op->loc.cc_ok[k]) variants.push_back(3 + k); }
     if (op->loc.nnz >= 256 * (int64_t)std::max(1, op->loc.nrows)) variants.push_back(6);   // long rows: the wave-streamed kernel
-    if (op->loc.ncols <= sk::XL_MAX && op->loc.nnz >= 128 * (int64_t)std::max(1, op->loc.nrows) && !std::getenv("SAENA_NO_XLDS")) {
+    if (op->loc.nnz >= 48 * (int64_t)std::max(1, op->loc.nrows) && !std::getenv("SAENA_NO_XLDS")) {
         CHK(build_xlds(op->loc));                                                           // long rows over few columns: x in LDS
-        if (op->loc.xl_ok) variants.push_back(10);
+        if (op->loc.xl_ok && op->loc.xl_piece >= 24.0) variants.push_back(10);
     }
     if (!op->h_val_all.empty()) {
         const double avg_row = (double)op->loc.nnz / std::max(1, op->loc.nrows);
@@ -1466,10 +1529,15 @@ int sgpu_op_autotune(sgpu_op *op) {
     // round 0 warms up (clocks, caches, code objects); rounds 1 and 2 measure and a candidate keeps its better time: the
     // first kernels after an idle spell run at ramping clocks, and one 1 ms sample per candidate picked losers now and then
     std::map<std::pair<int, int>, float> seen;
+    std::vector<int> lanes_x;                            // k_csr_xlds: lanes per (row, window) piece, about a 64th of its length
+    {
+        const int gx = std::min(64, std::max(4, pow2floor((int)std::max(1.0, op->loc.xl_piece / 64.0))));
+        for (int g : {gx / 2, gx, gx * 2}) if (g >= 4 && g <= 64) lanes_x.push_back(g);
+    }
     for (int round = 0; round < 3; ++round)
         for (int v : variants)
-            for (int gl : lanes) {
-                if ((v == 9 || v == 10) && gl != lanes.front()) continue;      // a lane / a wave per row whatever the setting
+            for (int gl : (v == 10 ? lanes_x : lanes)) {
+                if (v == 9 && gl != lanes.front()) continue;      // a lane per row whatever the setting
                 op->loc.variant = v; op->loc.lanes = gl;
                 const int reps = round == 0 ? 3 : 6;
                 HIPCHK(hipEventRecord(e0, g.cs));

@@ -1,5 +1,6 @@
-"""Run-to-run spread of one operator's kernels (development aid): python -m tests.perf_repeat m level v1,v2,... trials
-Times each variant `trials` times, interleaved, with fresh input/output vectors every second trial."""
+"""Run-to-run spread of an operator's kernels (development aid): python -m tests.perf_repeat m level[,level...] v1,v2,... trials [lanes,...]
+Times each variant `trials` times, interleaved, with fresh input/output vectors every second trial (A of each level;
+Jacobi sweep)."""
 import os
 import sys
 
@@ -10,26 +11,34 @@ from saena_amd import capi, host
 
 
 def main():
-    m, level = int(sys.argv[1]), int(sys.argv[2])
+    m, levels = int(sys.argv[1]), [int(v) for v in sys.argv[2].split(",")]
     variants = [int(v) for v in sys.argv[3].split(",")]
     trials = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+    lanes_list = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
     capi.init(0)
     L = host.load("gpu")
     A = host.Matrix(host.Comm("gpu", "rccl")).laplacian3D(m).assemble()
     S = host.AmgSolver(A, host.options(L, **host.OPTIONS001)).to_device()
-    op = S.device_op(level, 0)
-    print(f"L{level}: autotune chose {op.variant()} lanes {op.info()['lanes_per_row']}", flush=True)
-    lanes = op.info()["lanes_per_row"]
-    x = y = rhs = None
-    for t in range(trials):
-        if t % 2 == 0:
-            x, y, rhs = capi.DeviceVector(op.N_local, np.ones(op.N_local)), capi.DeviceVector(op.M), capi.DeviceVector(op.M, np.ones(op.M))
-        cells = []
-        for v in variants:
-            op.set_variant(v); op.set_lanes_per_row(lanes)
-            op.time_kernel(1, x, rhs, y, 3)
-            cells.append(f"v{v} {op.time_kernel(1, x, rhs, y, 30) * 1e3:7.1f} us")
-        print(f"trial {t}: " + " | ".join(cells), flush=True)
+    for level in levels:
+        op = S.device_op(level, 0)
+        print(f"L{level}: autotune chose {op.variant()} lanes {op.info()['lanes_per_row']}", flush=True)
+        tuned = op.info()["lanes_per_row"]
+        x = y = rhs = None
+        for t in range(trials):
+            if t % 2 == 0:
+                x, y, rhs = capi.DeviceVector(op.N_local, np.ones(op.N_local)), capi.DeviceVector(op.M), capi.DeviceVector(op.M, np.ones(op.M))
+            cells = []
+            for v in variants:
+                for lanes in lanes_list:
+                    try:
+                        op.set_variant(v)
+                    except capi.SgpuError:
+                        cells.append(f"v{v} refused")
+                        break
+                    op.set_lanes_per_row(lanes or tuned)
+                    op.time_kernel(1, x, rhs, y, 3)
+                    cells.append(f"v{v} G{lanes or tuned} {op.time_kernel(1, x, rhs, y, 30) * 1e3:7.1f} us")
+            print(f"trial {t}: " + " | ".join(cells), flush=True)
 
 
 if __name__ == "__main__":

@@ -211,6 +211,39 @@ def test_compressed_columns_slot_offset_split(capi, clusters, split_expected):
     assert np.all(np.abs(dy.download() - A2.matvec(x)) <= TOL_SPMV * 24 * np.max(np.abs(x)))
 
 
+def test_x_in_lds_column_windows(capi):
+    """k_csr_xlds on rows that reach over more columns than one LDS window holds: three clusters of 40 entries 25 000
+    columns apart (three windows per row chunk, partial sums carried between them), against the oracle; an operator whose
+    rows scatter over 2^20 columns is refused, not mis-computed."""
+    M = N = 80000
+    r = np.repeat(np.arange(M), 120)
+    c = (r + np.tile(np.concatenate([k * 25000 + np.arange(40) for k in range(3)]), M)) % N
+    key = np.unique(r.astype(np.int64) * N + c)
+    rows, cols = (key // N).astype(np.int32), (key % N).astype(np.int32)
+    entries = orc.coo_from_arrays(rows, cols, np.sin(0.37 * rows + 0.11 * cols) + (rows == cols) * 150.0)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    G.set_variant(10)
+    assert G.variant()[1] == "k_csr_xlds"
+    x, rhs = inputs.v2(M), inputs.rhs2(M)
+    dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
+    bound = abs_bound(entries, M, x)
+    for lanes in (8, 16, 64):
+        G.set_lanes_per_row(lanes)
+        G.spmv(dx, dy)
+        assert np.all(np.abs(dy.download() - A.matvec(x)) <= TOL_SPMV * bound + 1e-300)
+        du = capi.DeviceVector(M, x)
+        G.jacobi(2, du, dr)
+        assert rel(du.download(), A.jacobi(2, x, rhs)) <= TOL_SMOOTH
+    rng = np.random.default_rng(5)
+    rr = np.repeat(np.arange(2048), 24)
+    key = np.unique(rr.astype(np.int64) * (1 << 20) + rng.integers(0, 1 << 20, size=rr.size))
+    e2 = orc.coo_from_arrays((key >> 20).astype(np.int32), (key & ((1 << 20) - 1)).astype(np.int32), np.ones(key.size))
+    A2 = orc.OracleOp(e2, 2048, 1 << 20, orc.split_even(2048, 1), orc.split_even(1 << 20, 1), square=False)
+    with pytest.raises(capi.SgpuError, match="x-in-LDS"):
+        util.gpu_operator(A2).set_variant(10)
+
+
 @pytest.mark.parametrize("name", ["poisson12", "poisson20", "band300_7", "irregular5000"])
 def test_residual_jacobi_chebyshev(capi, name):
     entries, M = get_problem(name)
