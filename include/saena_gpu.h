@@ -123,7 +123,9 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
  * k_dense_rows_halo), at most 8192 rows and 64 M entries per rank; 6 k_csr_wave (long rows streamed by a wave);
  * 7 / 8 k_csr_cm: compressed columns with the entries of a row block in column order (12 B/nnz, fewer L1 requests on
  * rows of a few hundred entries) on the 16 / 32 KiB plan; 9 k_sell: sliced ELLPACK, a lane per row, 16-bit column codes
- * (operators whose slices of 64 rows pad to at most 12 % more entries).  7, 8 and 9 are built from a host copy of the
+ * (operators whose slices of 64 rows pad to at most 12 % more entries); 10 k_csr_xlds: the input vector staged in LDS
+ * in windows of 20224 columns, one workgroup per CU (row chunks that reach over at most 8 windows; 4-64 lanes per row
+ * piece, sgpu_op_set_lanes_per_row).  7, 8 and 9 are built from a host copy of the
  * values that the library keeps only until the plan-time autotune (SGPU_ERR_ARG afterwards, and where the form does
  * not apply) */
 int sgpu_op_set_variant(sgpu_op *op, int variant);
