@@ -248,8 +248,7 @@ def measure_spmv(capi, host, np, A, rank, steps, warmup, sync_all):
     sync_all()
     t0 = time.perf_counter()
     ms_kernel = op.time_kernel(0, x, None, y, steps)     # K launches, HIP events on the compute stream
-    capi.check(capi.lib().sgpu_device_sync())
-    sync_all()
+    sync_all()                                           # device synchronize + barrier
     wall = time.perf_counter() - t0
     return dict(op=op, info=info, kernel_name=kernel_name, ms_kernel=ms_kernel, wall=wall, B_local=op.algorithmic_bytes(0),
                 x=x, y=y, g0=g0)
