@@ -521,8 +521,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cm(const SpmvArgs a) {
 // columns share lines that are still in L1.  Columns are the 16-bit codes of k_csr_cc16 against a segment table per
 // workgroup (4 slices): 10 B per stored entry.  Operators whose padding exceeds 12 % keep the CSR kernels.
 // a.val / a.ccol: the padded arrays, a.segtab / a.segptr / a.cc_ob: the tables, a.cmptr: slice starts (multiples of 64),
-// a.dst: row lengths, a.nblk: slices.
-template <int EPI, bool HALO>
+// a.dst: row lengths, a.nblk: slices.  U positions are in flight per lane: 8 measured best (256^3 Jacobi sweeps, L0 / L1:
+// U=4 353 / 1081 us, U=8 351 / 1068, U=12 395 / 1061, U=16 456 / 1132; profiles/r02_sell_unroll.log).
+template <int EPI, bool HALO, int U = 8>
 __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
     __shared__ int seg[CC_MAXSEG];
     if constexpr (HALO) fork_signal(a);
@@ -544,19 +545,19 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
     const double         *v = a.val + p + lane;
     const unsigned short *c = a.ccol + p + lane;
     double sum = 0.0;
-    for (int j = 0; j < w; j += 8) {
-        double   vv[8], xx[8];
-        unsigned cc[8];
+    for (int j = 0; j < w; j += U) {
+        double   vv[U], xx[U];
+        unsigned cc[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                 // all stream loads first; positions past the slice's width re-read its last one
+        for (int u = 0; u < U; ++u) {                 // all stream loads first; positions past the slice's width re-read its last one
             const int jj = j + u < w ? j + u : w - 1;
             vv[u] = v[jj * 64];
             cc[u] = c[jj * 64];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xx[u] = a.x[seg[cc[u] >> ob] + (int)(cc[u] & om)];
+        for (int u = 0; u < U; ++u) xx[u] = a.x[seg[cc[u] >> ob] + (int)(cc[u] & om)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < U; ++u)
             if (j + u < len) sum += vv[u] * xx[u];    // padding (value 0) is never added: a NaN or inf in x stays in the rows that own it
     }
     if (r < nrows) epilogue<EPI, HALO>(a, r, sum);
