@@ -396,6 +396,10 @@ def main():
                              f"{world} nnz-balanced contiguous row blocks (reference partitioner), RCCL halo of ~{grid[0] - 2}^2 doubles per side "
                              f"(remote nnz per rank {halo_all})",
                 "pct_of_hbm_peak": round(B_total / sec_per_step / 1e9 / (HBM_PEAK_GBS * world) * 100, 2),
+                **({"weak_scaling_reference": "the 1-GPU figure at THIS per-GPU size is `spmv_hbm_resident` of the N=1 line (Poisson 256^3, "
+                                              "16.4 M rows, HBM-resident: 5.8-5.9 TB/s, profiles/r02_bench_n1.json); the N=1 `value` is the "
+                                              "Infinity-Cache-resident configs[1] operator (8.1 TB/s) and not the denominator of a weak-scaling ratio"}
+                   if world > 1 else {}),
             },
             "check": {"what": "y = A x of one more SpMV against the host-formed product from the layout arrays, halo values included; "
                               "max over all ranks of max_i |y_gpu - y_host| / max_i sum_j |a_ij x_j|",
