@@ -6,7 +6,7 @@ set -e
 M=${1:-128}; LV=${2:-2}; WH=${3:-0}; KIND=${4:-1}; V=${5:-4}; G=${6:-16}; OUT=${7:-gpurun_out/pmc_l1.txt}
 D=gpurun_out/pmc_l1_L$LV; rm -rf $D; mkdir -p $D
 cd /tmp; export TMPDIR=/tmp; cd "$OLDPWD"
-export SAENA_NO_AUTOTUNE=1
+export SAENA_NO_AUTOTUNE=1 SAENA_KEEP_HOST_VALUES=1     # (the re-ordered forms are built from the host copy of the values)
 i=0
 for C in ${PMC_L1_COUNTERS:-TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum FETCH_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_LATENCY_sum}; do
     i=$((i+1))
@@ -21,7 +21,7 @@ for f in sorted(glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=Tru
     rows += list(csv.DictReader(open(f)))
 names = defaultdict(int)
 for r in rows:
-    if "k_csr" in r["Kernel_Name"]: names[r["Kernel_Name"]] += 1
+    if "sk::k_csr" in r["Kernel_Name"] or "sk::k_sell" in r["Kernel_Name"]: names[r["Kernel_Name"]] += 1
 kernel = max(names, key=names.get)
 vals = defaultdict(list)
 for r in rows:
