@@ -156,6 +156,16 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         du = capi.DeviceVector(M, x)
         G.jacobi(2, du, dr)
         assert rel(du.download(), A.jacobi(2, x, rhs)) <= TOL_SMOOTH
+    # every fused epilogue of the variant: residual, Chebyshev (first and later step), u -= A e
+    G.residual(dx, dr, dy)
+    assert rel(dy.download(), A.residual(x, rhs)) <= TOL_SMOOTH
+    A.set_eig(1.9371)
+    du = capi.DeviceVector(M, x)
+    G.chebyshev(3, 1.9371, du, dr)
+    assert rel(du.download(), A.chebyshev(3, x, rhs)) <= TOL_SMOOTH
+    du = capi.DeviceVector(M, rhs)
+    G.prolong_correct(dx, du)
+    assert rel(du.download(), rhs - A.matvec(x)) <= TOL_SMOOTH
 
 
 def _clustered_operator(M, N, clusters, seed):
