@@ -696,11 +696,15 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
                 uint2   c[4];
                 int     i[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {                     // a lane without a u-th quad re-reads its first and drops it
-                    i[u] = q + G * u < nq ? a0 + 4 * (q + G * u) : a0 + 4 * q;
-                    v01[u] = ld_stream_d2(a.val + i[u]);
-                    v23[u] = ld_stream_d2(a.val + i[u] + 2);
-                    c[u]   = ld_stream_u2(a.ccol + i[u]);
+                for (int u = 0; u < 4; ++u) {                     // a lane without a u-th quad loads nothing (short row pieces: most of them)
+                    i[u] = a0 + 4 * (q + G * u);
+                    v01[u].x = v01[u].y = v23[u].x = v23[u].y = 0.0;
+                    c[u].x = c[u].y = 0u;
+                    if (q + G * u < nq) {
+                        v01[u] = ld_stream_d2(a.val + i[u]);
+                        v23[u] = ld_stream_d2(a.val + i[u] + 2);
+                        c[u]   = ld_stream_u2(a.ccol + i[u]);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
