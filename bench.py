@@ -434,6 +434,12 @@ def main():
             "cache_resident": bool(ws3 <= INFINITY_CACHE_BYTES), "achieved": round(a3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(a3 / HBM_PEAK_GBS, 4), "check_max_rel_err": e3,
         }
+        # bytes leaving the L2 per launch from the COMMITTED PMC passes of this leg (tools/pmc_spmv_hbm.sh), same kernel only
+        pmc3 = os.path.join(ROOT, "profiles", "r02_pmc_spmv_256_cc16.json")
+        if args.m_hbm == 256 and "k_csr_cc16" in R3["kernel_name"] and os.path.exists(pmc3):
+            with open(pmc3) as f:
+                out["spmv_hbm_resident"].update(traffic=json.load(f)["traffic_bytes_per_launch"], traffic_source="profiles/r02_pmc_spmv_256_cc16.json",
+                                                traffic_measured_in_run=False)
         R3["op"].destroy()
         for k in ("x", "y"):
             R3[k].free()
