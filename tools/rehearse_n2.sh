@@ -1,3 +1,6 @@
+#!/bin/bash
+# `bench.py --gpus 2` exactly as the driver launches it, both ranks on ONE card (host transport: RCCL refuses two ranks per
+# device), at the full per-GPU size of configs[3] (16.5 M rows per rank).  bash tools/rehearse_n2.sh
 O=gpurun_out/r02z; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0 SAENA_BENCH_NO_RCCL=1 SAENA_BENCH_DEVICE=0
 S=$(date +%s)

@@ -1,3 +1,6 @@
+#!/bin/bash
+# rocprofv3 kernel trace of a whole 256^3 run (setup, autotune, per-level timing loops, pCG, raw V-cycles): every kernel's
+# duration inside the V-cycle, split by (kernel, grid).  bash tools/trace_vcycle.sh  ->  gpurun_out/r02x/split.csv
 set -o pipefail
 O=gpurun_out/r02x; mkdir -p $O
 R=$PWD; cd /tmp && export TMPDIR=/tmp && cd $R
