@@ -383,6 +383,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
+            "device": capi.device_info(),
             "data": "synthetic",
             "config": {
                 "workload": (f"Poisson {grid_s} (Saena laplacian3D, boundary rows removed): SpMV w=Av, "

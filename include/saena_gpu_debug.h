@@ -49,6 +49,11 @@ int sgpu_debug_on_fatal_print(const char *line);
  * (tests: "fewer launches per V-cycle"); counts host-side enqueues, not GPU work */
 int sgpu_debug_launch_count(long *launches);
 
+/* one line describing the device of the context (name, architecture, compute units, clocks, L2, memory), for bench
+ * lines and logs: the same kernel ran 1 055-1 213 us on different boxes of one pool.  `buf` receives at most len-1
+ * characters and a terminator. */
+int sgpu_debug_device_info(char *buf, int len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,7 @@ SYMBOLS = {
     "sgpu_coarsest_solve": (C.c_int, [_VP, _VP, _VP, _PI]),
     "sgpu_debug_on_fatal_print": (C.c_int, [C.c_char_p]),
     "sgpu_debug_launch_count": (C.c_int, [C.POINTER(C.c_long)]),
+    "sgpu_debug_device_info": (C.c_int, [C.c_char_p, C.c_int]),
     "sgpu_debug_allow_local_only": (C.c_int, [_VP, C.c_int]),
     "sgpu_debug_init_host_transport": (C.c_int, [C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
     "sgpu_time_kernel": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int, C.POINTER(C.c_float)]),
@@ -448,6 +449,24 @@ class Amg:
                 self.destroy()
         except Exception:
             pass
+
+
+def device_info():
+    """one line about the context's device, plus the amdgpu partition modes where sysfs shows them"""
+    buf = C.create_string_buffer(512)
+    check(lib().sgpu_debug_device_info(buf, 512))
+    line = buf.value.decode()
+    import glob
+    for key in ("current_compute_partition", "current_memory_partition"):
+        vals = set()
+        for f in glob.glob(f"/sys/class/drm/card*/device/{key}"):
+            try:
+                vals.add(open(f).read().strip())
+            except OSError:
+                pass
+        if vals:
+            line += f", {key.replace('current_', '')} {'/'.join(sorted(vals))}"
+    return line
 
 
 def launch_count():

@@ -2228,6 +2228,16 @@ int sgpu_debug_on_fatal_print(const char *line) {
     return SGPU_OK;
 }
 
+int sgpu_debug_device_info(char *buf, int len) {
+    CHK(need_ctx());
+    if (!buf || len < 2) return fail(SGPU_ERR_ARG, "bad argument");
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, g.device));
+    snprintf(buf, (size_t)len, "%s (%s), %d CUs, %d MHz core, %d MHz memory x %d bit, L2 %d KiB, %.1f GiB", p.name, p.gcnArchName, p.multiProcessorCount,
+             p.clockRate / 1000, p.memoryClockRate / 1000, p.memoryBusWidth, p.l2CacheSize / 1024, (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    return SGPU_OK;
+}
+
 int sgpu_debug_launch_count(long *launches) {
     if (!launches) return fail(SGPU_ERR_ARG, "null argument");
     *launches = g_launches;

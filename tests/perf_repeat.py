@@ -16,6 +16,7 @@ def main():
     trials = int(sys.argv[4]) if len(sys.argv) > 4 else 8
     lanes_list = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
     capi.init(0)
+    print("device:", capi.device_info(), flush=True)
     L = host.load("gpu")
     A = host.Matrix(host.Comm("gpu", "rccl")).laplacian3D(m).assemble()
     S = host.AmgSolver(A, host.options(L, **host.OPTIONS001)).to_device()

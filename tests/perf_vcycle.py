@@ -15,6 +15,7 @@ def main():
     m = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     smoother = sys.argv[2] if len(sys.argv) > 2 else "jacobi"
     capi.init(0)
+    print("device:", capi.device_info(), flush=True)
     L = host.load("gpu")
     t0 = time.time()
     A = host.Matrix(host.Comm("gpu", "rccl")).laplacian3D(m).assemble()
