@@ -6,7 +6,8 @@ import sys
 
 import numpy as np
 
-os.environ.setdefault("SAENA_KEEP_HOST_VALUES", "1")
+if not os.environ.get("PERF_REPEAT_NOKEEP"):          # (NOKEEP: the library frees the losing plans after its autotune, as in production)
+    os.environ.setdefault("SAENA_KEEP_HOST_VALUES", "1")
 from saena_amd import capi, host
 
 
