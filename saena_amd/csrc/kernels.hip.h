@@ -513,17 +513,22 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cm(const SpmvArgs a) {
 
 // ---------------------------------------------------------------------------
 // K1s: sliced ELLPACK for even rows (the stencil levels and the first smoothed-aggregation level).  A slice is 64
-// consecutive rows = one wave; its entries are stored position-major -- entry j of the slice's rows side by side -- padded
-// to the slice's longest row.  A lane owns a row: it adds the row's products in column order in a register (the
-// reference's sequential sum, whatever the launch shape), there is no product tile, no phase 2 and no row pointer, every
-// stream load of the wave is one contiguous 512-byte (values) or 128-byte (columns) piece, on a stencil the 64 gathers
-// of an instruction are 64 consecutive doubles of x, and elsewhere a lane walks along its own row, whose neighbouring
-// columns share lines that are still in L1.  Columns are the 16-bit codes of k_csr_cc16 against a segment table per
-// workgroup (4 slices): 10 B per stored entry.  Operators whose padding exceeds 12 % keep the CSR kernels.
+// consecutive rows = one wave; its entries are stored position-major -- entries 2q and 2q+1 of the slice's rows side by
+// side, lane by lane (an odd last position alone; operators of fewer than 16 entries per row: one position at a time,
+// PAIR = false) -- padded to the slice's longest row.  A lane owns a row: it adds the
+// row's products in column order in a register (the reference's sequential sum, whatever the launch shape), there is no
+// product tile, no phase 2 and no row pointer, every stream load of the wave is one contiguous 1 KiB (two values per
+// lane) or 256-byte (two 16-bit column codes per lane) piece, on a stencil the gathers of an instruction are 64
+// consecutive doubles of x, and elsewhere a lane walks along its own row, whose neighbouring columns share lines that
+// are still in L1.  Columns are the 16-bit codes of k_csr_cc16 against a segment table per workgroup (4 slices): 10 B
+// per stored entry.  Operators whose padding exceeds 12 % keep the CSR kernels.
+// Two positions per load matter: with one (8-byte value loads) the kernel ran 1 055-1 210 us on 256^3 L1 depending on
+// the box, with two 1 003-1 018 us on the slowest of them (profiles/r02_sell_pairs.log) -- it was short of issue slots, not
+// bytes.  On the 7-entry rows of the cache-resident 128^3 fine level single positions are the faster form (25.4 vs ~26.5 us).
+// Four pairs are in flight per lane (2 / 6 / 8 measured equal or worse as single positions, profiles/r02_sell_unroll.log).
 // a.val / a.ccol: the padded arrays, a.segtab / a.segptr / a.cc_ob: the tables, a.cmptr: slice starts (multiples of 64),
-// a.dst: row lengths, a.nblk: slices.  U positions are in flight per lane: 8 measured best (256^3 Jacobi sweeps, L0 / L1:
-// U=4 353 / 1081 us, U=8 351 / 1068, U=12 395 / 1061, U=16 456 / 1132; profiles/r02_sell_unroll.log).
-template <int EPI, bool HALO, int U = 8>
+// a.dst: row lengths, a.nblk: slices.
+template <int EPI, bool HALO, bool PAIR>
 __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
     __shared__ int seg[CC_MAXSEG];
     if constexpr (HALO) fork_signal(a);
@@ -542,24 +547,64 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
     const int len = r < nrows ? (int)a.dst[r] : 0;
     const int ob = a.cc_ob;
     const unsigned om = (1u << ob) - 1u;
-    const double         *v = a.val + p + lane;
-    const unsigned short *c = a.ccol + p + lane;
-    double sum = 0.0;
-    for (int j = 0; j < w; j += U) {
-        double   vv[U], xx[U];
-        unsigned cc[U];
+    if constexpr (!PAIR) {                             // rows of a handful of entries (the stencil level, its transfers): one position per load
+        const double         *v = a.val + p + lane;
+        const unsigned short *c = a.ccol + p + lane;
+        double sum = 0.0;
+        for (int j = 0; j < w; j += 8) {
+            double   vv[8], xx[8];
+            unsigned cc[8];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {                 // all stream loads first; positions past the slice's width re-read its last one
-            const int jj = j + u < w ? j + u : w - 1;
-            vv[u] = v[jj * 64];
-            cc[u] = c[jj * 64];
+            for (int u = 0; u < 8; ++u) {             // all stream loads first; positions past the slice's width re-read its last one
+                const int jj = j + u < w ? j + u : w - 1;
+                vv[u] = v[jj * 64];
+                cc[u] = c[jj * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xx[u] = a.x[seg[cc[u] >> ob] + (int)(cc[u] & om)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j + u < len) sum += vv[u] * xx[u];
+        }
+        if (r < nrows) epilogue<EPI, HALO>(a, r, sum);
+        return;
+    }
+    const int P = w >> 1;                              // pairs of positions; an odd last one follows them
+    const double2  *v2 = reinterpret_cast<const double2 *>(a.val + p) + lane;
+    const unsigned *c2 = reinterpret_cast<const unsigned *>(a.ccol + p) + lane;
+    constexpr int UP = 4;
+    double sum = 0.0;
+    // the odd last position is fetched FIRST (its product is added last): behind the loop it was a second round trip of
+    // latency in the life of a wave whose rows hold 7 entries
+    double   vt = 0.0, xt = 0.0;
+    if (w & 1) {
+        vt = a.val[p + P * 128 + lane];
+        const unsigned ct = a.ccol[p + P * 128 + lane];
+        xt = a.x[seg[ct >> ob] + (int)(ct & om)];
+    }
+    for (int q = 0; q < P; q += UP) {
+        double2  vv[UP];
+        unsigned cc[UP];
+        double   x0[UP], x1[UP];
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {                 // all stream loads first; pairs past the slice's width re-read its last one
+            const int qq = q + u < P ? q + u : P - 1;
+            vv[u] = v2[qq * 64];
+            cc[u] = c2[qq * 64];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) xx[u] = a.x[seg[cc[u] >> ob] + (int)(cc[u] & om)];
+        for (int u = 0; u < UP; ++u) {
+            const unsigned ca = cc[u] & 0xffffu, cb = cc[u] >> 16;
+            x0[u] = a.x[seg[ca >> ob] + (int)(ca & om)];
+            x1[u] = a.x[seg[cb >> ob] + (int)(cb & om)];
+        }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (j + u < len) sum += vv[u] * xx[u];    // padding (value 0) is never added: a NaN or inf in x stays in the rows that own it
+        for (int u = 0; u < UP; ++u) {                 // padding (value 0) is never added: a NaN or inf in x stays in the rows that own it
+            if (q + u < P && 2 * (q + u) < len) sum += vv[u].x * x0[u];
+            if (q + u < P && 2 * (q + u) + 1 < len) sum += vv[u].y * x1[u];
+        }
     }
+    if ((w & 1) && w - 1 < len) sum += vt * xt;
     if (r < nrows) epilogue<EPI, HALO>(a, r, sum);
 }
 

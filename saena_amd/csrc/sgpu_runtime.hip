@@ -147,6 +147,7 @@ struct CsrPart {
     unsigned short *sl_col = nullptr, *sl_len = nullptr;
     int            *sl_base = nullptr, *sl_segptr = nullptr, *sl_ptr = nullptr;   // segment bases of all groups, group g owns [sl_segptr[g], sl_segptr[g+1])
     int             nslices = 0, sl_ob = 12;
+    bool            sl_pair = false;       // two positions per lane side by side (rows of >= 16 entries), else one
     bool            sl_ok = false;
     char            sl_tried = 0;
     void free_sell() {
@@ -457,7 +458,7 @@ int build_xlds(CsrPart &P) {
     return SGPU_OK;
 }
 
-// Sliced ELLPACK of the local part (k_sell): slices of 64 rows stored position-major, padded to the slice's longest row;
+// Sliced ELLPACK of the local part (k_sell): slices of 64 rows stored position-major in pairs of positions per lane, padded to the slice's longest row;
 // 16-bit column codes against a segment table per group of 4 slices (one workgroup), as in build_cc16.  Built only where
 // it can win: padding <= 12 % of the entries.
 int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
@@ -486,6 +487,8 @@ int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
     int ob = 12;
     if (!encode_cc16(P, grp, ccol, segptr, segtab, ob)) return SGPU_OK;
     std::vector<double> val((size_t)tot + 64, 0.0);
+    const bool pair = P.nnz >= 16 * (int64_t)M;          // 16-byte value loads pay from a few pairs per row on (k_sell)
+    P.sl_pair = pair;
     const int nt = std::min(host_threads(), std::max(1, ns / 256));
     auto work = [&](int t) {
         const int s0 = (int)((long)ns * t / nt), s1 = (int)((long)ns * (t + 1) / nt);
@@ -494,8 +497,12 @@ int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
             for (int r = s * 64; r < std::min(M, s * 64 + 64); ++r) {
                 const int n = P.h_rp[r + 1] - P.h_rp[r];
                 len[(size_t)r] = (unsigned short)n;
+                const int w = (ptr[(size_t)s + 1] - p) / 64, PP = w >> 1;      // positions in pairs per lane, an odd last one alone
                 for (int j = 0; j < n; ++j) {
-                    const size_t q = (size_t)P.h_rp[r] + j, o = (size_t)p + (size_t)j * 64 + (r - s * 64);
+                    const size_t q = (size_t)P.h_rp[r] + j;
+                    const size_t o = !pair ? (size_t)p + (size_t)j * 64 + (r - s * 64)
+                                           : j < 2 * PP ? (size_t)p + (size_t)(j >> 1) * 128 + (size_t)(r - s * 64) * 2 + (j & 1)
+                                                        : (size_t)p + (size_t)PP * 128 + (r - s * 64);
                     val[o] = h_val_all[q];
                     col[o] = ccol[q];                             // (padding keeps code 0: slot 0, offset 0 = a valid column of the group)
                 }
@@ -665,18 +672,20 @@ struct EpiArgs {
 
 // seq != 0: the launch carries the fork (block 0 stores flag_x = seq when it starts)
 using SellKernelFn = void (*)(const sk::SpmvArgs, int);
-template <bool HALO>
+template <bool HALO, bool PAIR>
 SellKernelFn pick_sell_h(int epi) {
     switch (epi) {
-        case sk::EPI_SPMV:     return sk::k_sell<sk::EPI_SPMV, HALO>;
-        case sk::EPI_RESIDUAL: return sk::k_sell<sk::EPI_RESIDUAL, HALO>;
-        case sk::EPI_JACOBI:   return sk::k_sell<sk::EPI_JACOBI, HALO>;
-        case sk::EPI_CHEBY0:   return sk::k_sell<sk::EPI_CHEBY0, HALO>;
-        case sk::EPI_CHEBYK:   return sk::k_sell<sk::EPI_CHEBYK, HALO>;
-        default:               return sk::k_sell<sk::EPI_SUB, HALO>;
+        case sk::EPI_SPMV:     return sk::k_sell<sk::EPI_SPMV, HALO, PAIR>;
+        case sk::EPI_RESIDUAL: return sk::k_sell<sk::EPI_RESIDUAL, HALO, PAIR>;
+        case sk::EPI_JACOBI:   return sk::k_sell<sk::EPI_JACOBI, HALO, PAIR>;
+        case sk::EPI_CHEBY0:   return sk::k_sell<sk::EPI_CHEBY0, HALO, PAIR>;
+        case sk::EPI_CHEBYK:   return sk::k_sell<sk::EPI_CHEBYK, HALO, PAIR>;
+        default:               return sk::k_sell<sk::EPI_SUB, HALO, PAIR>;
     }
 }
-SellKernelFn pick_sell(int epi, bool halo) { return halo ? pick_sell_h<true>(epi) : pick_sell_h<false>(epi); }
+SellKernelFn pick_sell(int epi, bool halo, bool pair) {
+    return halo ? (pair ? pick_sell_h<true, true>(epi) : pick_sell_h<true, false>(epi)) : (pair ? pick_sell_h<false, true>(epi) : pick_sell_h<false, false>(epi));
+}
 using XldsKernelFn = void (*)(const sk::SpmvArgs, const sk::XldsArgs);
 template <int EPI, bool HALO>
 XldsKernelFn pick_xlds_g(int lanes) {
@@ -724,7 +733,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         if (!P.sl_ok) return fail(SGPU_ERR_STATE, "the sliced-ELLPACK form was not built");
         a.blk_row = nullptr; a.nblk = P.nslices;
         a.val = P.sl_val; a.ccol = P.sl_col; a.segtab = P.sl_base; a.segptr = P.sl_segptr; a.cc_ob = P.sl_ob; a.cmptr = P.sl_ptr; a.dst = P.sl_len;
-        SGPU_LAUNCH(pick_sell(epi, halo), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
+        SGPU_LAUNCH(pick_sell(epi, halo, P.sl_pair), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
     } else if (P.variant == 7 || P.variant == 8) {                       // compressed columns, entries in column order inside a block
         const int k = P.variant - 7;
         if (!P.cm_ok[k]) return fail(SGPU_ERR_STATE, "the column-major form of plan %d was not built", k);
@@ -1538,12 +1547,30 @@ int sgpu_op_autotune(sgpu_op *op) {
         const int gx = std::min(64, std::max(4, pow2floor((int)std::max(1.0, op->loc.xl_piece / 64.0))));
         for (int g : {gx / 2, gx, gx * 2}) if (g >= 4 && g <= 64) lanes_x.push_back(g);
     }
+    std::map<std::pair<int, int>, float> est;            // round 0's estimate of a candidate's time: a measuring sample lasts >= 1 ms
+    {                                                    // a few milliseconds of the current plan first: a process's first kernels run at ramping clocks
+        hipEvent_t w0 = guard.e0, w1 = guard.e1;
+        float ms = 0;
+        for (int burst = 0; burst < 8 && ms < 4.0f; ++burst) {
+            HIPCHK(hipEventRecord(w0, g.cs));
+            for (int i = 0; i < 8; ++i) CHK(launch_part(op->loc, epi, x.p, y.p, e));
+            HIPCHK(hipEventRecord(w1, g.cs));
+            HIPCHK(hipEventSynchronize(w1));
+            float t = 0;
+            HIPCHK(hipEventElapsedTime(&t, w0, w1));
+            ms += t;
+        }
+    }
     for (int round = 0; round < 3; ++round)
         for (int v : variants)
             for (int gl : (v == 10 ? lanes_x : lanes)) {
                 if (v == 9 && gl != lanes.front()) continue;      // a lane per row whatever the setting
                 op->loc.variant = v; op->loc.lanes = gl;
-                const int reps = round == 0 ? 3 : 6;
+                int reps = 3;
+                if (round > 0) {
+                    const float t = est.count({v, gl}) ? est[{v, gl}] : 1.0f;
+                    reps = std::min(48, std::max(6, (int)(1.0f / std::max(t, 1e-3f)) + 1));
+                }
                 HIPCHK(hipEventRecord(e0, g.cs));
                 for (int i = 0; i < reps; ++i) CHK(launch_part(op->loc, epi, x.p, y.p, e));
                 HIPCHK(hipEventRecord(e1, g.cs));
@@ -1551,7 +1578,7 @@ int sgpu_op_autotune(sgpu_op *op) {
                 float ms = 0;
                 HIPCHK(hipEventElapsedTime(&ms, e0, e1));
                 ms /= reps;
-                if (round == 0) continue;
+                if (round == 0) { est[{v, gl}] = ms; continue; }
                 auto it = seen.find({v, gl});
                 if (it == seen.end()) seen[{v, gl}] = ms; else it->second = std::min(it->second, ms);
             }
