@@ -487,7 +487,9 @@ int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
     int ob = 12;
     if (!encode_cc16(P, grp, ccol, segptr, segtab, ob)) return SGPU_OK;
     std::vector<double> val((size_t)tot + 64, 0.0);
-    const bool pair = P.nnz >= 16 * (int64_t)M;          // 16-byte value loads pay from a few pairs per row on (k_sell)
+    // 16-byte value loads pay from a few pairs per row on, and on any operator that streams from HBM (256^3 L0, 7 entries
+    // per row: 338 vs 343-350 us); the cache-resident 128^3 fine level is the one case that prefers single positions
+    const bool pair = P.nnz >= 16 * (int64_t)M || 10 * P.nnz > (int64_t)256 * 1024 * 1024;
     P.sl_pair = pair;
     const int nt = std::min(host_threads(), std::max(1, ns / 256));
     auto work = [&](int t) {
