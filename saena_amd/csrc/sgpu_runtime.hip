@@ -66,6 +66,7 @@ struct Ctx {
     bool        live = false;
     int         device = 0, rank = 0, nranks = 1;
     int         ncu = 256;            // compute units of the device (k_csr_xlds launches one workgroup per CU)
+    hipEvent_t  tk0 = nullptr, tk1 = nullptr;   // sgpu_time_kernel's events
     hipStream_t cs = nullptr, hs = nullptr;
     ncclComm_t  comm = nullptr;
     double     *partials = nullptr;   // dot partial sums
@@ -1201,6 +1202,7 @@ int sgpu_finalize(void) {
     sgpu_install_spgemm_hook(0);
     hipDeviceSynchronize();
     if (g.comm) { ncclCommDestroy(g.comm); g.comm = nullptr; }
+    if (g.tk0) { hipEventDestroy(g.tk0); hipEventDestroy(g.tk1); g.tk0 = g.tk1 = nullptr; }
     hipFree(g.partials); hipFree(g.dscalar); hipHostFree(g.hscalar); hipFree(g.dint); hipHostFree(g.hint);
     if (g.flag_x) hipFree(g.flag_x);
     if (g.flag_h) hipFree(g.flag_h);
@@ -2297,7 +2299,7 @@ int sgpu_time_kernel(sgpu_op *op, int kind, const value_t *x, const value_t *rhs
     if (kind != 0 && !rhs) return fail(SGPU_ERR_ARG, "rhs needed");
     if ((kind == 1 || kind == 3) && !op->inv_diag) return fail(SGPU_ERR_ARG, "operator has no inv_diag");
     if (kind == 3) CHK(ensure_d(op));
-    static hipEvent_t e0 = nullptr, e1 = nullptr;             // created once: not part of what a caller's wall clock around this call sees
+    hipEvent_t &e0 = g.tk0, &e1 = g.tk1;                       // created once per context: not part of what a caller's wall clock around this call sees
     if (!e0) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); }
     HIPCHK(hipEventRecord(e0, g.cs));
     for (int i = 0; i < reps; ++i) {
