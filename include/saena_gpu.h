@@ -130,7 +130,9 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
  * not apply) */
 int sgpu_op_set_variant(sgpu_op *op, int variant);
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name);
-/* time a few (variant, lanes) candidates on this operator and keep the fastest (plan-time autotune) */
+/* time the (variant, lanes) candidates that apply to this operator and keep the fastest (plan-time autotune; no
+ * collective).  Call it right after sgpu_op_create: operators of up to 768 entries per row hold a host copy of their
+ * values (8 B per entry) for the re-ordered forms from the create until this call -- or until sgpu_op_destroy. */
 int sgpu_op_autotune(sgpu_op *op);
 
 /* All vector arguments below are DEVICE pointers to this rank's slices.
