@@ -33,3 +33,21 @@ def test_committed_bench_line_has_the_contract_keys():
     assert d["check"]["ok"] is True and d["check"]["max_rel_err"] <= 1e-13
     v = d["vcycle"]
     assert v["pcg_iterations"] == 9 and f"{v['final_residual']:.6e}" == "5.355578e-05" and f"{v['initial_residual']:.6e}" == "5.992963e+04"
+
+
+def test_committed_kernel_trace_agrees_with_the_bench_line():
+    """rocprofv3 --kernel-trace of the same command (profiles/r02_bench_n1_kernel_stats_by_grid.csv, split by operator):
+    the average duration of the bench kernel on the 128^3 operator agrees with the line's HIP-event figure, in the
+    profiled run itself and in the committed unprofiled line"""
+    import csv
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_bench_n1_kernel_stats_by_grid.csv"))))
+    for name in ("r02_bench_n1_under_rocprof.json", "r02_bench_n1.json"):
+        d = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
+        kernel = d["roofline"]["kernel"].split(",")[0].split("<")[0]           # "k_sell" | "k_csr_cc16"
+        rows_per_wg = 256                                                      # k_sell: 4 slices of 64 rows per workgroup
+        cand = [r for r in rows if f"sk::{kernel}<0," in r["Name"] and int(r["Calls"]) >= 100]
+        if kernel == "k_sell":
+            cand = [r for r in cand if int(r["Workgroups"]) == (2000376 + rows_per_wg - 1) // rows_per_wg]
+        assert cand, (kernel, [r["Name"] for r in rows[:5]])
+        avg_us = float(max(cand, key=lambda r: int(r["Calls"]))["AverageNs"]) / 1e3
+        assert abs(avg_us - d["roofline"]["us_per_launch"]) <= 0.05 * avg_us, (name, avg_us, d["roofline"]["us_per_launch"])
