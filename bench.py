@@ -257,6 +257,8 @@ def measure_spmv(capi, host, np, A, rank, steps, warmup, sync_all):
 def stored_bytes(info, kernel_name):
     """bytes the SpMV's operands occupy in HBM: values, column ids as the chosen kernel stores them, row pointers, x, y"""
     nnz = info["nnz_local"] + info["nnz_remote"]
+    if kernel_name == "k_sellp":                         # no column stream: a 16-bit pattern id per row (+ a table of a few hundred ints)
+        return 8 * nnz + 2 * info["M"] + 8 * info["N_local"] + 8 * info["M"]
     if kernel_name == "k_sell":                          # 16-bit column codes, a 16-bit row length instead of the row pointer (padding < 1 % here)
         return 10 * nnz + 2 * info["M"] + 8 * info["N_local"] + 8 * info["M"]
     col_bytes = 2 if ("cc16" in kernel_name or "k_csr_cm" in kernel_name) else 4
@@ -406,7 +408,7 @@ def main():
                               "max over all ranks of max_i |y_gpu - y_host| / max_i sum_j |a_ij x_j|",
                       "max_rel_err": err, "ok": bool(err <= 1e-13)},
             "roofline": {
-                "bound": "hbm", "kernel": f"{kernel_name}, {1 if kernel_name == 'k_sell' else info['lanes_per_row']} lane(s)/row",
+                "bound": "hbm", "kernel": f"{kernel_name}, {1 if kernel_name in ('k_sell', 'k_sellp') else info['lanes_per_row']} lane(s)/row",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "us_per_launch": round(ms_kernel * 1e3, 3), "algorithmic_bytes": B_local,
@@ -430,7 +432,7 @@ def main():
         ws3 = stored_bytes(R3["info"], R3["kernel_name"])
         out["spmv_hbm_resident"] = {
             "workload": f"Poisson {args.m_hbm}^3: {R3['info']['M']} rows x {R3['info']['nnz_local']} nnz, same kernel path",
-            "kernel": f"{R3['kernel_name']}, {1 if R3['kernel_name'] == 'k_sell' else R3['info']['lanes_per_row']} lane(s)/row", "steps": steps3, "warmup": warm3,
+            "kernel": f"{R3['kernel_name']}, {1 if R3['kernel_name'] in ('k_sell', 'k_sellp') else R3['info']['lanes_per_row']} lane(s)/row", "steps": steps3, "warmup": warm3,
             "us_per_launch": round(R3["ms_kernel"] * 1e3, 3), "algorithmic_bytes": R3["B_local"], "working_set_bytes": ws3,
             "cache_resident": bool(ws3 <= INFINITY_CACHE_BYTES), "achieved": round(a3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(a3 / HBM_PEAK_GBS, 4), "check_max_rel_err": e3,

@@ -125,9 +125,12 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
  * rows of a few hundred entries) on the 16 / 32 KiB plan; 9 k_sell: sliced ELLPACK, a lane per row, 16-bit column codes
  * (operators whose slices of 64 rows pad to at most 12 % more entries); 10 k_csr_xlds: the input vector staged in LDS
  * in windows of 20224 columns, one workgroup per CU (row chunks that reach over at most 8 windows; 4-64 lanes per row
- * piece, sgpu_op_set_lanes_per_row).  7, 8 and 9 are built from a host copy of the
- * values that the library keeps only until the plan-time autotune (SGPU_ERR_ARG afterwards, and where the form does
- * not apply) */
+ * piece, sgpu_op_set_lanes_per_row); 11 k_sellp: k_sell's values without a column stream -- a 16-bit id per row into a
+ * table of (length, columns relative to the row) patterns held in LDS, 8 B per entry + 2 B per row (operators that
+ * qualify for 9 and whose rows follow few enough patterns for a table of 4096 ints: stencils on structured grids, band
+ * matrices; the local loop of src/saena_matrix_matvec.cpp:68-80 with the same sequential row sum).  7, 8, 9 and 11 are
+ * built from a host copy of the values that the library keeps only until the plan-time autotune (SGPU_ERR_ARG
+ * afterwards, and where the form does not apply) */
 int sgpu_op_set_variant(sgpu_op *op, int variant);
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name);
 /* time the (variant, lanes) candidates that apply to this operator and keep the fastest (plan-time autotune; no
@@ -179,7 +182,9 @@ typedef struct {
     int     solver_max_iter;              /* saena::options */
     value_t solver_tol;
     int     use_graph;                    /* 1 (default): capture the V-cycle once per (u, rhs) pair and replay it as a
-                                             hipGraph (single rank; with RCCL halos the launches stay eager) */
+                                             hipGraph.  One rank: the whole V-cycle.  Several ranks: the levels whose
+                                             operators exchange a halo on this rank launch eagerly (the exchange is an RCCL
+                                             group), the communication-free tail below them is one captured graph */
 } sgpu_amg_params;
 
 typedef struct sgpu_amg sgpu_amg;         /* opaque */

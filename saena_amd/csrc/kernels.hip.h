@@ -68,6 +68,10 @@ struct SpmvArgs {
     // belongs to; val / ccol then point at the re-sorted copies, cmptr[b] is the block's (quad-aligned) start in them
     const unsigned short *dst;
     const int            *cmptr;
+    // row patterns (k_sellp): pt_n table rows of pt_w + 1 ints -- a row's length, then its columns relative to the row;
+    // dst holds the pattern id of every row
+    const int            *ptab;
+    int                   pt_w, pt_n;
     // in-kernel fork to the halo stream (multi-rank interior launch only, else nullptr): block 0 stores
     // *flag_x = seq when it starts -- stream order: everything earlier on the compute stream is complete, so
     // the halo stream's pack, which polls the flag, may read x.
@@ -100,29 +104,41 @@ __device__ __forceinline__ double coherent_load(const double *p) {
 }
 // HALO = the launch is the interior half of a multi-rank apply (row mask + in-kernel fork/join); the
 // single-rank instantiations carry none of that code (it cost 1 % of the fine-level SpMV when it was a run-time test)
-template <int EPI, bool HALO>
+// NT: the once-per-sweep streams of the epilogue (rhs, inv_diag, d; the stores of y and d) bypass the caches' allocation
+// (k_sellp on operators beyond the Infinity Cache, see there)
+template <bool NT>
+__device__ __forceinline__ double ld_once(const double *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st_once(double *p, double v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <int EPI, bool HALO, bool NT = false>
 __device__ __forceinline__ void epilogue(const SpmvArgs &a, int r, double s) {
     if constexpr (HALO)
         if (a.skip && ((a.skip[r >> 5] >> (r & 31)) & 1u)) return;  // a boundary row: the halo stream's kernel writes it
     if constexpr (EPI == EPI_SPMV) {
-        a.y[r] = s;
+        st_once<NT>(a.y + r, s);
     } else if constexpr (EPI == EPI_RESIDUAL) {
-        a.y[r] = s - a.rhs[r];
+        st_once<NT>(a.y + r, s - ld_once<NT>(a.rhs + r));
     } else if constexpr (EPI == EPI_JACOBI) {
-        double t = s - a.rhs[r];
-        t *= a.inv_diag[r] * a.c0;
-        a.y[r] = a.u[r] - t;
+        double t = s - ld_once<NT>(a.rhs + r);
+        t *= ld_once<NT>(a.inv_diag + r) * a.c0;
+        st_once<NT>(a.y + r, a.u[r] - t);
     } else if constexpr (EPI == EPI_CHEBY0) {
-        const double dd = (a.c0 * a.inv_diag[r]) * (a.rhs[r] - s);
-        a.d[r] = dd;
-        a.y[r] = a.u[r] + dd;
+        const double dd = (a.c0 * ld_once<NT>(a.inv_diag + r)) * (ld_once<NT>(a.rhs + r) - s);
+        st_once<NT>(a.d + r, dd);
+        st_once<NT>(a.y + r, a.u[r] + dd);
     } else if constexpr (EPI == EPI_CHEBYK) {
-        const double res = (a.c0 * a.inv_diag[r]) * (a.rhs[r] - s);
-        const double dd  = (a.c1 * a.d[r]) + res;
-        a.d[r] = dd;
-        a.y[r] = a.u[r] + dd;
+        const double res = (a.c0 * ld_once<NT>(a.inv_diag + r)) * (ld_once<NT>(a.rhs + r) - s);
+        const double dd  = (a.c1 * ld_once<NT>(a.d + r)) + res;
+        st_once<NT>(a.d + r, dd);
+        st_once<NT>(a.y + r, a.u[r] + dd);
     } else if constexpr (EPI == EPI_SUB) {
-        a.y[r] = a.y[r] - s;
+        st_once<NT>(a.y + r, a.y[r] - s);
     }
 }
 
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cm(const SpmvArgs a) {
 // Four pairs are in flight per lane (2 / 6 / 8 measured equal or worse as single positions, profiles/r02_sell_unroll.log).
 // a.val / a.ccol: the padded arrays, a.segtab / a.segptr / a.cc_ob: the tables, a.cmptr: slice starts (multiples of 64),
 // a.dst: row lengths, a.nblk: slices.
-template <int EPI, bool HALO, bool PAIR>
+template <int EPI, bool HALO, bool PAIR, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
     __shared__ int seg[CC_MAXSEG];
     if constexpr (HALO) fork_signal(a);
@@ -557,8 +573,8 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {             // all stream loads first; positions past the slice's width re-read its last one
                 const int jj = j + u < w ? j + u : w - 1;
-                vv[u] = v[jj * 64];
-                cc[u] = c[jj * 64];
+                vv[u] = ld_once<NT>(v + jj * 64);
+                if constexpr (NT) cc[u] = __builtin_nontemporal_load(c + jj * 64); else cc[u] = c[jj * 64];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) xx[u] = a.x[seg[cc[u] >> ob] + (int)(cc[u] & om)];
@@ -566,11 +582,11 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
             for (int u = 0; u < 8; ++u)
                 if (j + u < len) sum += vv[u] * xx[u];
         }
-        if (r < nrows) epilogue<EPI, HALO>(a, r, sum);
+        if (r < nrows) epilogue<EPI, HALO, NT>(a, r, sum);
         return;
     }
     const int P = w >> 1;                              // pairs of positions; an odd last one follows them
-    const double2  *v2 = reinterpret_cast<const double2 *>(a.val + p) + lane;
+    const sk_d2v   *v2 = reinterpret_cast<const sk_d2v *>(a.val + p) + lane;
     const unsigned *c2 = reinterpret_cast<const unsigned *>(a.ccol + p) + lane;
     constexpr int UP = 4;
     double sum = 0.0;
@@ -578,19 +594,19 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
     // latency in the life of a wave whose rows hold 7 entries
     double   vt = 0.0, xt = 0.0;
     if (w & 1) {
-        vt = a.val[p + P * 128 + lane];
+        vt = ld_once<NT>(a.val + p + P * 128 + lane);
         const unsigned ct = a.ccol[p + P * 128 + lane];
         xt = a.x[seg[ct >> ob] + (int)(ct & om)];
     }
     for (int q = 0; q < P; q += UP) {
-        double2  vv[UP];
+        sk_d2v   vv[UP];
         unsigned cc[UP];
         double   x0[UP], x1[UP];
 #pragma unroll
         for (int u = 0; u < UP; ++u) {                 // all stream loads first; pairs past the slice's width re-read its last one
             const int qq = q + u < P ? q + u : P - 1;
-            vv[u] = v2[qq * 64];
-            cc[u] = c2[qq * 64];
+            if constexpr (NT) { vv[u] = __builtin_nontemporal_load(v2 + qq * 64); cc[u] = __builtin_nontemporal_load(c2 + qq * 64); }
+            else { vv[u] = v2[qq * 64]; cc[u] = c2[qq * 64]; }
         }
 #pragma unroll
         for (int u = 0; u < UP; ++u) {
@@ -605,7 +621,93 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
         }
     }
     if ((w & 1) && w - 1 < len) sum += vt * xt;
-    if (r < nrows) epilogue<EPI, HALO>(a, r, sum);
+    if (r < nrows) epilogue<EPI, HALO, NT>(a, r, sum);
+}
+
+// ---------------------------------------------------------------------------
+// K1p: sliced ELLPACK WITHOUT a column stream, for operators whose rows repeat a few patterns (stencils on structured
+// grids, band matrices).  The reference's local loop (src/saena_matrix_matvec.cpp:68-80) reads a column id per entry;
+// on the 7-point level every interior row holds the columns r - n^2, r - n, r - 1, r, r + 1, r + n, r + n^2, so the ids
+// carry one fact per ROW: which of a handful of (length, column offsets relative to the row) patterns it follows -- 27
+// for the boundary-stripped 3D Laplacian.  The values keep k_sell's layout (position-major slices of 64 rows, a lane per
+// row, pairs of positions per 16-byte load); the 16-bit column code per entry and the 16-bit length per row give way to
+// ONE 16-bit pattern id per row, and the pattern table (pt_n x (pt_w + 1) ints, <= 16 KiB) sits in LDS: 8 B per entry +
+// 2 B per row instead of 10 + 2.  Lanes of a wave that follow the same pattern gather 64 consecutive doubles of x.
+// Same products, same sequential sum per row as k_sell and k_csr_stream at one lane per row: bit-identical results.
+// a.val: k_sell's padded values, a.cmptr: slice starts, a.dst: pattern ids, a.ptab / pt_w / pt_n: the table, a.nblk: slices.
+// NT: the operator does not fit the 256 MiB Infinity Cache: the once-per-sweep streams (values, pattern ids, rhs, inv_diag,
+// the stores of y) are non-temporal, x is not.  Measured on Poisson 256^3 (1.2 GB stored, profiles/r03_sellp_nt.log):
+// 257 -> 220 us back to back; on the cache-resident 128^3 operator it loses (22.5 -> 30 us), so the launch picks by size.
+// Two slices per wave (twice the loads in flight per lane) changed nothing, four were slower (profiles/r03_sellp_ns.log).
+template <int EPI, bool HALO, bool PAIR, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_sellp(const SpmvArgs a, int nrows) {
+    extern __shared__ int ptab_lds[];
+    if constexpr (HALO) fork_signal(a);
+    {
+        const int tn = a.pt_n * (a.pt_w + 1);
+        for (int i = threadIdx.x; i < tn; i += BLOCK) ptab_lds[i] = a.ptab[i];
+    }
+    __syncthreads();
+    constexpr int SPB = BLOCK / 64;
+    const int b = xcd_remap(blockIdx.x, (a.nblk + SPB - 1) / SPB);
+    const int s = __builtin_amdgcn_readfirstlane(b * SPB + ((int)threadIdx.x >> 6));
+    if (s >= a.nblk) return;
+    const int lane = threadIdx.x & 63;
+    const int r = s * 64 + lane;
+    const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 6;
+    int pid = 0;
+    if (r < nrows) { if constexpr (NT) pid = __builtin_nontemporal_load(a.dst + r); else pid = a.dst[r]; }
+    const int *pt = ptab_lds + pid * (a.pt_w + 1);
+    const int len = r < nrows ? pt[0] : 0;
+    ++pt;
+    // column of position j of this lane's row: the table is read at a clamped position (no branch per position), positions
+    // past the row's length read x[0] and are never added
+    const int wmax = a.pt_w - 1;
+    auto colof = [&](int j) { const int c = r + pt[j < wmax ? j : wmax]; return j < len ? c : 0; };
+    double sum = 0.0;
+    if constexpr (!PAIR) {
+        const double *v = a.val + p + lane;
+        for (int j = 0; j < w; j += 8) {
+            double vv[8], xx[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = ld_once<NT>(v + (j + u < w ? j + u : w - 1) * 64);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xx[u] = a.x[colof(j + u)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j + u < len) sum += vv[u] * xx[u];
+        }
+    } else {
+        const int P = w >> 1;
+        const sk_d2v *v2 = reinterpret_cast<const sk_d2v *>(a.val + p) + lane;
+        constexpr int UP = 4;
+        double vt = 0.0, xt = 0.0;
+        if (w & 1) {                                   // the odd last position first, as in k_sell
+            vt = ld_once<NT>(a.val + p + P * 128 + lane);
+            xt = a.x[colof(w - 1)];
+        }
+        for (int q = 0; q < P; q += UP) {
+            sk_d2v vv[UP];
+            double x0[UP], x1[UP];
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                const sk_d2v *vp = v2 + (q + u < P ? q + u : P - 1) * 64;
+                if constexpr (NT) vv[u] = __builtin_nontemporal_load(vp); else vv[u] = *vp;
+            }
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                x0[u] = a.x[colof(2 * (q + u))];
+                x1[u] = a.x[colof(2 * (q + u) + 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                if (q + u < P && 2 * (q + u) < len) sum += vv[u].x * x0[u];
+                if (q + u < P && 2 * (q + u) + 1 < len) sum += vv[u].y * x1[u];
+            }
+        }
+        if ((w & 1) && w - 1 < len) sum += vt * xt;
+    }
+    if (r < nrows) epilogue<EPI, HALO, NT>(a, r, sum);
 }
 
 // ---------------------------------------------------------------------------

@@ -25,6 +25,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 extern "C" void sgpu_install_spgemm_hook(int on);
@@ -151,7 +152,23 @@ struct CsrPart {
     bool            sl_pair = false;       // two positions per lane side by side (rows of >= 16 entries), else one
     bool            sl_ok = false;
     char            sl_tried = 0;
+    // row patterns on top of the sliced-ELLPACK values (variant 11, k_sellp): a 16-bit pattern id per row and the table of
+    // patterns (sp_n rows of sp_w + 1 ints: length, then the columns relative to the row); shares sl_val / sl_ptr
+    unsigned short *sp_pat = nullptr;
+    int            *sp_tab = nullptr;
+    int             sp_w = 0, sp_n = 0;
+    int64_t         sp_bytes = 0;      // values + pattern ids + x + y as this form stores them
+    bool            sp_ok = false;
+    char            sp_tried = 0;
+    void free_sellp() { hipFree(sp_pat); hipFree(sp_tab); sp_pat = nullptr; sp_tab = nullptr; sp_ok = false; sp_tried = 0; }
+    // the column codes of k_sell alone (k_sellp keeps the values and the slice pointers)
+    void free_sell_columns() {
+        hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr);
+        sl_col = sl_len = nullptr; sl_base = sl_segptr = nullptr;
+        sl_ok = false;                                             // (variant 9 is gone for good: sl_tried stays set)
+    }
     void free_sell() {
+        free_sellp();
         hipFree(sl_val); hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr); hipFree(sl_ptr);
         sl_val = nullptr; sl_col = sl_len = nullptr; sl_base = sl_segptr = sl_ptr = nullptr; sl_ok = false; sl_tried = 0;
     }
@@ -533,6 +550,54 @@ int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
     return SGPU_OK;
 }
 
+// Row patterns of the local part (k_sellp) on top of build_sell's values: every row is (length, columns relative to the
+// row index); the operator qualifies when its rows follow at most 65 535 distinct patterns whose table fits 16 KiB of LDS
+// (4096 ints) -- stencils on structured grids (the boundary-stripped 7-point Laplacian: 27 patterns), band matrices.
+// Ids are dealt in order of first appearance, so the table does not depend on threads or hashing.
+constexpr int SP_MAX_TABLE = 4096;
+int build_sellp(CsrPart &P) {
+    if (P.sp_ok || P.sp_tried || !P.sl_ok || P.h_rp.empty()) return SGPU_OK;
+    P.sp_tried = 1;
+    const int M = P.nrows;
+    int W = 1;
+    for (int r = 0; r < M; ++r) W = std::max(W, P.h_rp[r + 1] - P.h_rp[r]);
+    if (W + 1 > SP_MAX_TABLE) return SGPU_OK;
+    const int max_pat = std::min(65535, SP_MAX_TABLE / (W + 1));
+    std::vector<int> tab;                                      // patterns back to back, W + 1 ints each
+    std::vector<unsigned short> pat(((size_t)M + 63) / 64 * 64, 0);
+    std::unordered_map<std::string, int> ids;
+    std::string key;
+    int prev = -1, npat = 0;
+    for (int r = 0; r < M; ++r) {
+        const int p0 = P.h_rp[r], n = P.h_rp[r + 1] - p0;
+        if (prev >= 0 && tab[(size_t)prev * (W + 1)] == n) {   // most rows repeat the row before
+            const int *t = &tab[(size_t)prev * (W + 1) + 1];
+            int j = 0;
+            while (j < n && P.h_col[(size_t)p0 + j] - r == t[j]) ++j;
+            if (j == n) { pat[(size_t)r] = (unsigned short)prev; continue; }
+        }
+        key.assign(reinterpret_cast<const char *>(&n), sizeof n);
+        for (int j = 0; j < n; ++j) { const int o = P.h_col[(size_t)p0 + j] - r; key.append(reinterpret_cast<const char *>(&o), sizeof o); }
+        auto it = ids.find(key);
+        if (it == ids.end()) {
+            if (npat == max_pat) return SGPU_OK;               // too many patterns: not this kind of operator
+            it = ids.emplace(key, npat++).first;
+            tab.push_back(n);
+            for (int j = 0; j < W; ++j) tab.push_back(j < n ? P.h_col[(size_t)p0 + j] - r : 0);
+        }
+        prev = it->second;
+        pat[(size_t)r] = (unsigned short)prev;
+    }
+    if (npat == 0) return SGPU_OK;
+    if (std::getenv("SAENA_SETUP_TIMING")) fprintf(stderr, "[sgpu] row patterns: %d rows follow %d patterns of <= %d entries\n", M, npat, W);
+    CHK(dev_upload(&P.sp_pat, pat.data(), pat.size()));
+    CHK(dev_upload(&P.sp_tab, tab.data(), tab.size()));
+    P.sp_w = W; P.sp_n = npat;
+    P.sp_bytes = 8 * (int64_t)P.h_rp.back() + 2 * (int64_t)M + 8 * (int64_t)P.ncols + 8 * (int64_t)M;
+    P.sp_ok = true;
+    return SGPU_OK;
+}
+
 } // namespace
 
 struct sgpu_op {
@@ -675,20 +740,38 @@ struct EpiArgs {
 
 // seq != 0: the launch carries the fork (block 0 stores flag_x = seq when it starts)
 using SellKernelFn = void (*)(const sk::SpmvArgs, int);
-template <bool HALO, bool PAIR>
+template <bool HALO, bool PAIR, bool NT>
 SellKernelFn pick_sell_h(int epi) {
     switch (epi) {
-        case sk::EPI_SPMV:     return sk::k_sell<sk::EPI_SPMV, HALO, PAIR>;
-        case sk::EPI_RESIDUAL: return sk::k_sell<sk::EPI_RESIDUAL, HALO, PAIR>;
-        case sk::EPI_JACOBI:   return sk::k_sell<sk::EPI_JACOBI, HALO, PAIR>;
-        case sk::EPI_CHEBY0:   return sk::k_sell<sk::EPI_CHEBY0, HALO, PAIR>;
-        case sk::EPI_CHEBYK:   return sk::k_sell<sk::EPI_CHEBYK, HALO, PAIR>;
-        default:               return sk::k_sell<sk::EPI_SUB, HALO, PAIR>;
+        case sk::EPI_SPMV:     return sk::k_sell<sk::EPI_SPMV, HALO, PAIR, NT>;
+        case sk::EPI_RESIDUAL: return sk::k_sell<sk::EPI_RESIDUAL, HALO, PAIR, NT>;
+        case sk::EPI_JACOBI:   return sk::k_sell<sk::EPI_JACOBI, HALO, PAIR, NT>;
+        case sk::EPI_CHEBY0:   return sk::k_sell<sk::EPI_CHEBY0, HALO, PAIR, NT>;
+        case sk::EPI_CHEBYK:   return sk::k_sell<sk::EPI_CHEBYK, HALO, PAIR, NT>;
+        default:               return sk::k_sell<sk::EPI_SUB, HALO, PAIR, NT>;
     }
 }
-SellKernelFn pick_sell(int epi, bool halo, bool pair) {
-    return halo ? (pair ? pick_sell_h<true, true>(epi) : pick_sell_h<true, false>(epi)) : (pair ? pick_sell_h<false, true>(epi) : pick_sell_h<false, false>(epi));
+template <bool NT>
+SellKernelFn pick_sell_n(int epi, bool halo, bool pair) {
+    return halo ? (pair ? pick_sell_h<true, true, NT>(epi) : pick_sell_h<true, false, NT>(epi)) : (pair ? pick_sell_h<false, true, NT>(epi) : pick_sell_h<false, false, NT>(epi));
 }
+SellKernelFn pick_sell(int epi, bool halo, bool pair, bool nt) { return nt ? pick_sell_n<true>(epi, halo, pair) : pick_sell_n<false>(epi, halo, pair); }
+template <bool HALO, bool PAIR, bool NT>
+SellKernelFn pick_sellp_h(int epi) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return sk::k_sellp<sk::EPI_SPMV, HALO, PAIR, NT>;
+        case sk::EPI_RESIDUAL: return sk::k_sellp<sk::EPI_RESIDUAL, HALO, PAIR, NT>;
+        case sk::EPI_JACOBI:   return sk::k_sellp<sk::EPI_JACOBI, HALO, PAIR, NT>;
+        case sk::EPI_CHEBY0:   return sk::k_sellp<sk::EPI_CHEBY0, HALO, PAIR, NT>;
+        case sk::EPI_CHEBYK:   return sk::k_sellp<sk::EPI_CHEBYK, HALO, PAIR, NT>;
+        default:               return sk::k_sellp<sk::EPI_SUB, HALO, PAIR, NT>;
+    }
+}
+template <bool NT>
+SellKernelFn pick_sellp_n(int epi, bool halo, bool pair) {
+    return halo ? (pair ? pick_sellp_h<true, true, NT>(epi) : pick_sellp_h<true, false, NT>(epi)) : (pair ? pick_sellp_h<false, true, NT>(epi) : pick_sellp_h<false, false, NT>(epi));
+}
+SellKernelFn pick_sellp(int epi, bool halo, bool pair, bool nt) { return nt ? pick_sellp_n<true>(epi, halo, pair) : pick_sellp_n<false>(epi, halo, pair); }
 using XldsKernelFn = void (*)(const sk::SpmvArgs, const sk::XldsArgs);
 template <int EPI, bool HALO>
 XldsKernelFn pick_xlds_g(int lanes) {
@@ -716,6 +799,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12; a.dst = nullptr; a.cmptr = nullptr;
+    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0;
     const bool halo = skip != nullptr || seq != 0;
     if (P.variant == 5) {                                         // dense rows, one wave per row
         if (!P.dense) return fail(SGPU_ERR_STATE, "the dense form was not built");
@@ -732,11 +816,23 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         sk::XldsArgs w;
         w.info = P.xl_info; w.tab = P.xl_tab; w.acc = P.xl_acc; w.ncols = P.ncols;
         SGPU_LAUNCH(pick_xlds(epi, P.lanes, halo), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, w);
+    } else if (P.variant == 11) {                                 // sliced ELLPACK values + row patterns, a lane per row
+        if (!P.sp_ok || !P.sl_val) return fail(SGPU_ERR_STATE, "the row-pattern form was not built");
+        a.blk_row = nullptr; a.nblk = P.nslices;
+        a.val = P.sl_val; a.cmptr = P.sl_ptr; a.dst = P.sp_pat; a.ptab = P.sp_tab; a.pt_w = P.sp_w; a.pt_n = P.sp_n;
+        // non-temporal streams once the stored operator (values, pattern ids, x, y) is beyond the 256 MiB Infinity Cache
+        static const int nt_env = std::getenv("SAENA_SELLP_NT") ? std::atoi(std::getenv("SAENA_SELLP_NT")) : -1;
+        const bool nt = nt_env >= 0 ? nt_env != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
+        SGPU_LAUNCH(pick_sellp(epi, halo, P.sl_pair, nt), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
     } else if (P.variant == 9) {                                  // sliced ELLPACK, a lane per row
         if (!P.sl_ok) return fail(SGPU_ERR_STATE, "the sliced-ELLPACK form was not built");
         a.blk_row = nullptr; a.nblk = P.nslices;
         a.val = P.sl_val; a.ccol = P.sl_col; a.segtab = P.sl_base; a.segptr = P.sl_segptr; a.cc_ob = P.sl_ob; a.cmptr = P.sl_ptr; a.dst = P.sl_len;
-        SGPU_LAUNCH(pick_sell(epi, halo, P.sl_pair), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
+        // non-temporal streams once the stored operator is beyond the 256 MiB Infinity Cache (k_sellp in kernels.hip.h; 128^3 L1,
+        // 843 MB: 127 -> 121 us, profiles/r03_sell_nt.log)
+        static const int nt_env = std::getenv("SAENA_SELL_NT") ? std::atoi(std::getenv("SAENA_SELL_NT")) : -1;
+        const bool nt = nt_env >= 0 ? nt_env != 0 : 10 * P.nnz + 18 * (int64_t)P.nrows > (int64_t)256 * 1024 * 1024;
+        SGPU_LAUNCH(pick_sell(epi, halo, P.sl_pair, nt), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
     } else if (P.variant == 7 || P.variant == 8) {                       // compressed columns, entries in column order inside a block
         const int k = P.variant - 7;
         if (!P.cm_ok[k]) return fail(SGPU_ERR_STATE, "the column-major form of plan %d was not built", k);
@@ -1448,7 +1544,7 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds"};   // (3, 4, 7, 8 are named with their slot/offset split below)
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp"};   // (3, 4, 7, 8 are named with their slot/offset split below)
     if (variant) *variant = op->loc.variant;
     if (kernel_name) {
         const int v = op->loc.variant;
@@ -1467,7 +1563,14 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 10) return fail(SGPU_ERR_ARG, "variant must be 0..10");
+    if (variant < 0 || variant > 11) return fail(SGPU_ERR_ARG, "variant must be 0..11");
+    if (variant == 11) {
+        CHK(build_sell(op->loc, op->h_val_all));
+        CHK(build_sellp(op->loc));
+        if (!op->loc.sp_ok)
+            return fail(SGPU_ERR_ARG, "the row-pattern form needs what the sliced-ELLPACK form needs and rows that follow at most %d-int's worth of "
+                                      "(length, relative columns) patterns", SP_MAX_TABLE);
+    }
     if (variant == 10) {
         CHK(build_xlds(op->loc));
         if (!op->loc.xl_ok)
@@ -1528,6 +1631,10 @@ int sgpu_op_autotune(sgpu_op *op) {
         if (!std::getenv("SAENA_NO_SELL")) {                                               // even rows: a lane per row
             CHK(build_sell(op->loc, op->h_val_all));
             if (op->loc.sl_ok) variants.push_back(9);
+            if (op->loc.sl_ok && !std::getenv("SAENA_NO_SELLP")) {                         // rows that repeat a few patterns: no column stream
+                CHK(build_sellp(op->loc));
+                if (op->loc.sp_ok) variants.push_back(11);
+            }
         }
     }
     if (!op->has_remote && !op->loc.h_val.empty() && (double)op->loc.nnz >= 0.5 * (double)op->loc.nrows * op->loc.ncols && build_dense(op->loc) == SGPU_OK)
@@ -1568,7 +1675,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     for (int round = 0; round < 3; ++round)
         for (int v : variants)
             for (int gl : (v == 10 ? lanes_x : lanes)) {
-                if (v == 9 && gl != lanes.front()) continue;      // a lane per row whatever the setting
+                if ((v == 9 || v == 11) && gl != lanes.front()) continue;      // a lane per row whatever the setting
                 op->loc.variant = v; op->loc.lanes = gl;
                 int reps = 3;
                 if (round > 0) {
@@ -1602,7 +1709,9 @@ int sgpu_op_autotune(sgpu_op *op) {
             op->loc.cm_val[k] = nullptr; op->loc.cm_col[k] = op->loc.cm_dst[k] = nullptr; op->loc.cm_ptr[k] = nullptr;
             op->loc.cm_ok[k] = false; op->loc.cm_tried[k] = 0;
         }
-    if (bv != 9 && !keep) op->loc.free_sell();
+    if (bv != 9 && bv != 11 && !keep) op->loc.free_sell();
+    else if (bv == 11 && !keep) op->loc.free_sell_columns();    // k_sellp keeps the values and the slice pointers only
+    else if (bv == 9 && !keep) op->loc.free_sellp();
     if (bv != 10 && !keep) op->loc.free_xlds();
     if (!keep) std::vector<double>().swap(op->h_val_all);       // (a later set_variant(7/8/9) on this operator is refused: the values are gone)
     for (int k = 0; k < 2; ++k)                       // free the compressed arrays of the plans that lost

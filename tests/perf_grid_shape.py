@@ -3,6 +3,8 @@ time is the re-fetch of x lines whose reuse distance (one grid plane of rows) ex
     python -m tests.perf_grid_shape"""
 import numpy as np
 
+import os
+os.environ.setdefault('SAENA_KEEP_HOST_VALUES', '1')
 from saena_amd import capi, host
 
 
@@ -14,7 +16,7 @@ def main():
         M = A.num_local_rows
         x, y, rhs = capi.DeviceVector(M, np.ones(M)), capi.DeviceVector(M), capi.DeviceVector(M, np.ones(M))
         cells = []
-        for v in (3, 9):
+        for v in (9, 11):
             op.set_variant(v); op.set_lanes_per_row(1)
             for kind, name in ((0, "spmv"), (1, "jacobi")):
                 op.time_kernel(kind, x, rhs, y, 5)

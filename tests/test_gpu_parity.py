@@ -115,8 +115,22 @@ def _sell_eligible(entries, M):
     return padded <= 1.12 * len(entries)
 
 
+def _sellp_eligible(entries, M):
+    """the library's rule for the row-pattern form: sliced-ELLPACK eligible, and the distinct (length, columns relative
+    to the row) patterns fit a table of 4096 ints (each pattern takes longest-row + 1 of them)"""
+    if not _sell_eligible(entries, M):
+        return False
+    row, col = np.asarray(entries["row"]), np.asarray(entries["col"])
+    order = np.lexsort((col, row))
+    row, col = row[order], col[order]
+    n = np.bincount(row, minlength=M)
+    ptr = np.concatenate([[0], np.cumsum(n)])
+    pats = {tuple(col[ptr[r]:ptr[r + 1]] - r) for r in range(M)}
+    return len(pats) * (int(n.max()) + 1) <= 4096
+
+
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11])
 def test_kernel_variants(capi, name, variant, monkeypatch):
     """32 KiB tiles / vector CSR / 16-bit compressed columns (16 and 32 KiB tiles; long rows included) / wave-streamed
     long rows / compressed columns with the block's entries in column order (16 and 32 KiB tiles) / sliced ELLPACK /
@@ -133,6 +147,10 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         with pytest.raises(capi.SgpuError, match="sliced-ELLPACK"):    # uneven rows: more than 12 % padding, refused
             G.set_variant(variant)
         return
+    if variant == 11 and not _sellp_eligible(entries, M):
+        with pytest.raises(capi.SgpuError, match="row-pattern"):       # rows that follow no small set of patterns: refused
+            G.set_variant(variant)
+        return
     G.set_variant(variant)                # the compressed-column forms serve every one of these operators
     if variant in (3, 4):
         assert "k_csr_cc16" in G.variant()[1]
@@ -142,6 +160,8 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         assert G.variant()[1] == "k_sell"
     if variant == 10:
         assert G.variant()[1] == "k_csr_xlds"
+    if variant == 11:
+        assert G.variant()[1] == "k_sellp"
     x, rhs = inputs.v2(M), inputs.rhs2(M)
     bound = abs_bound(entries, M, x)
     dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
@@ -149,7 +169,7 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         G.set_lanes_per_row(lanes)
         G.spmv(dx, dy)
         got, want = dy.download(), A.matvec(x)
-        if (lanes == 1 or variant == 9) and variant not in (2, 6, 10) and (name != "band3000_1400" or variant in (1, 4, 8)):
+        if (lanes == 1 or variant in (9, 11)) and variant not in (2, 6, 10) and (name != "band3000_1400" or variant in (1, 4, 8)):
             np.testing.assert_array_equal(got, want)          # stream variants keep the sequential row sum
         else:
             assert np.all(np.abs(got - want) <= TOL_SPMV * bound + 1e-300)
@@ -406,7 +426,7 @@ def test_halo_path_column_ordered_kernel(capi, name, nprocs, monkeypatch):
     W = util.EmulatedWorld(A)
     x, rhs = inputs.v2(M), inputs.rhs2(M)
     out = {}
-    for variant in (4, 8) + ((9,) if name == "poisson20" else ()):
+    for variant in (4, 8) + ((9, 11) if name == "poisson20" else ()):
         xs, ys, rs, us = W.slices(x, split), W.slices(np.zeros(M), split), W.slices(rhs, split), W.slices(x, split)
         W.exchange(xs); W.exchange(us)
         for r in range(nprocs):
@@ -425,9 +445,10 @@ def test_halo_path_column_ordered_kernel(capi, name, nprocs, monkeypatch):
         W.g[r].jacobi(1, us[r], rs[r])
     assert np.all(np.abs(W.gather(ys) - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
     assert rel(W.gather(us), A.jacobi(1, x, rhs)) <= TOL_SMOOTH
-    if 9 in out:                                              # sliced ELLPACK: the sequential row sum as well
-        np.testing.assert_array_equal(out[9][0], out[4][0])
-        np.testing.assert_array_equal(out[9][1], out[4][1])
+    for v in (9, 11):                                         # sliced ELLPACK, with column codes and with row patterns: the sequential row sum as well
+        if v in out:
+            np.testing.assert_array_equal(out[v][0], out[4][0])
+            np.testing.assert_array_equal(out[v][1], out[4][1])
     assert np.all(np.abs(out[8][0] - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
     assert rel(out[8][1], A.jacobi(1, x, rhs)) <= TOL_SMOOTH
 
