@@ -772,16 +772,22 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wave(const SpmvArgs a, int nrows)
             double2 w01 = ld_stream_d2(a.val + i1);
             double2 w23 = ld_stream_d2(a.val + i1 + 2);
             const int4 d = ld_stream_i4(a.col + i1);
-            const double x0 = a.x[c.x], x1 = a.x[c.y], x2 = a.x[c.z], x3 = a.x[c.w];
-            const double y0 = a.x[d.x], y1 = a.x[d.y], y2 = a.x[d.z], y3 = a.x[d.w];
-            if (i0 < p0 || i0 + 4 > p1) {                         // first / last quad of the row: drop the neighbours' entries
-                v01.x = stray(i0, p0, p1) ? 0.0 : v01.x;     v01.y = stray(i0 + 1, p0, p1) ? 0.0 : v01.y;
-                v23.x = stray(i0 + 2, p0, p1) ? 0.0 : v23.x; v23.y = stray(i0 + 3, p0, p1) ? 0.0 : v23.y;
+            double x0 = a.x[c.x], x1 = a.x[c.y], x2 = a.x[c.z], x3 = a.x[c.w];
+            double y0 = a.x[d.x], y1 = a.x[d.y], y2 = a.x[d.z], y3 = a.x[d.w];
+            // entries of the neighbouring rows in the first / last quad, and the re-read quad of a lane without a second one:
+            // BOTH factors are zeroed, so an inf or NaN of x at a column this row does not own stays out of its sum
+            if (i0 < p0 || i0 + 4 > p1) {
+                if (stray(i0, p0, p1)) { v01.x = 0.0; x0 = 0.0; }
+                if (stray(i0 + 1, p0, p1)) { v01.y = 0.0; x1 = 0.0; }
+                if (stray(i0 + 2, p0, p1)) { v23.x = 0.0; x2 = 0.0; }
+                if (stray(i0 + 3, p0, p1)) { v23.y = 0.0; x3 = 0.0; }
             }
-            if (!two) { w01.x = w01.y = w23.x = w23.y = 0.0; }
+            if (!two) { w01.x = w01.y = w23.x = w23.y = 0.0; y0 = y1 = y2 = y3 = 0.0; }
             else if (i1 + 4 > p1) {
-                w01.x = stray(i1, p0, p1) ? 0.0 : w01.x;     w01.y = stray(i1 + 1, p0, p1) ? 0.0 : w01.y;
-                w23.x = stray(i1 + 2, p0, p1) ? 0.0 : w23.x; w23.y = stray(i1 + 3, p0, p1) ? 0.0 : w23.y;
+                if (stray(i1, p0, p1)) { w01.x = 0.0; y0 = 0.0; }
+                if (stray(i1 + 1, p0, p1)) { w01.y = 0.0; y1 = 0.0; }
+                if (stray(i1 + 2, p0, p1)) { w23.x = 0.0; y2 = 0.0; }
+                if (stray(i1 + 3, p0, p1)) { w23.y = 0.0; y3 = 0.0; }
             }
             sum += v01.x * x0; sum += v01.y * x1; sum += v23.x * x2; sum += v23.y * x3;
             sum += w01.x * y0; sum += w01.y * y1; sum += w23.x * y2; sum += w23.y * y3;

@@ -135,7 +135,10 @@ __global__ __launch_bounds__(256) void k_spgemm_medium(Mats m, const int *__rest
         }
         __syncthreads();                                    // entry ka+1 of A's row adds after entry ka everywhere
         if (TRY) {
-            const bool over = counter[3] != 0 || counter[2] > MEDIUM_FILL;          // the same answer in every thread
+            // the give-up decision is read between two barriers, so no wave is already bumping the counters of entry ka+1
+            // when another reads them: every thread sees the same value and the workgroup leaves together
+            const bool over = counter[3] != 0 || counter[2] > MEDIUM_FILL;
+            __syncthreads();
             if (over) { if (tid == 0) { n_touched[loc] = -1; n_kept[loc] = 0; } return; }
         }
     }
@@ -225,6 +228,7 @@ struct Dev {                                    // RAII for the call's device bu
         return static_cast<T *>(q);
     }
 };
+extern "C" int sgpu_context_device();      // sgpu_runtime.hip: the device of this process's context
 #define SP_CHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return 1; } } while (0)
 
 int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int *a_col, const double *a_val,
@@ -246,6 +250,7 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     auto T0 = now();
+    SP_CHK(hipSetDevice(sgpu_context_device()));            // the setup may be driven from a thread that never selected this context's device
     Dev D;
     Mats m;
     long long *dap = D.alloc<long long>((size_t)a_rows + 1), *dbp = D.alloc<long long>((size_t)b_rows + 1);
@@ -290,7 +295,8 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
     double *acc = nullptr;
     int *mark = nullptr;
     int heavy_grid = 0;
-    void *d_temp = nullptr;
+    struct Temp { void *p = nullptr; ~Temp() { if (p) hipFree(p); } } temp;      // the sort's scratch: freed on every return path
+    void *&d_temp = temp.p;
     size_t temp_bytes = 0;
 
     c_ptr.assign(1, 0);
@@ -357,13 +363,13 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
         SP_CHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, need, (const int *)tcol, scol, (const double *)tval, sval, (int)items, n,
                                                            (const int *)d_ubptr, (const int *)d_ends, 0, 32, 0));
         if (need > temp_bytes) {
-            if (d_temp) hipFree(d_temp);
+            if (d_temp) { hipFree(d_temp); d_temp = nullptr; }
             SP_CHK(hipMalloc(&d_temp, need));
             temp_bytes = need;
         }
         hipError_t se = hipcub::DeviceSegmentedRadixSort::SortPairs(d_temp, need, (const int *)tcol, scol, (const double *)tval, sval, (int)items, n,
                                                                     (const int *)d_ubptr, (const int *)d_ends, 0, 32, 0);
-        if (se != hipSuccess) { if (d_temp) hipFree(d_temp); return 1; }
+        if (se != hipSuccess) return 1;
         h_kept.resize((size_t)n);
         SP_CHK(hipMemcpy(h_kept.data(), d_kept, (size_t)n * 4, hipMemcpyDeviceToHost));
         if (timing) { t_sort += secs(Tc, now()); Tc = now(); }
@@ -385,7 +391,6 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
         for (int i = 0; i < n; ++i) c_ptr.push_back((long)(base + (size_t)h_outptr[(size_t)i + 1]));
         t_down += secs(Tc, now());
     }
-    if (d_temp) hipFree(d_temp);
     if (std::getenv("SAENA_SETUP_TIMING"))
         fprintf(stderr, "[spgemm gpu] %d x %d, %lld products -> %zu entries, %zu chunk(s): upload %.2f, row kernels %.2f, sort %.2f, copy-out+download %.2f, host %.2f, total %.2f s\n",
                 a_rows, b_cols, products_total, c_col.size(), chunk_start.size() - 1, t_up, t_kern, t_sort, t_down, t_host, secs(T0, now()));

@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the plan cache (what the plan-time autotune chose, kept between processes) is off under test unless a test points it at
+# a directory of its own: tests must not depend on what an earlier run left in ~/.cache
+os.environ.setdefault("SAENA_PLAN_CACHE", "off")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

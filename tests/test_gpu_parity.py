@@ -9,6 +9,7 @@ Tolerances (fp64):
 """
 import glob
 import os
+import time
 
 import numpy as np
 import pytest
@@ -694,3 +695,74 @@ def test_multirank_library_against_compiled_reference_golden(fixture):
         res = dict(ret)
     for r in range(world):
         assert res.get(r) == "ok", f"rank {r}: {res.get(r)}"
+
+
+def test_plan_cache_makes_a_second_operator_take_the_first_one_s_plan(capi, tmp_path, monkeypatch):
+    """The plan-time autotune writes its choice to the plan cache; an operator of the same shape created afterwards (here:
+    in the same process, in production: by a later process) takes the plan from there without a sweep -- same kernel,
+    same summation order, bit-identical results.  SAENA_PLAN_CACHE=off tunes afresh."""
+    cache = tmp_path / "plans.tsv"
+    monkeypatch.setenv("SAENA_PLAN_CACHE", str(cache))
+    entries, M = orc.laplacian3d(66)                        # 262 144 rows, 1.8 M entries: above the autotune's size floor
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    x = inputs.v2(M)
+    G1 = util.gpu_operator(A)
+    G1.autotune()
+    lines = cache.read_text().strip().splitlines()
+    assert len(lines) == 1 and len(lines[0].split("\t")) >= 4
+    G2 = util.gpu_operator(A)
+    t0 = time.perf_counter()
+    G2.autotune()
+    dt = time.perf_counter() - t0
+    assert len(cache.read_text().strip().splitlines()) == 1, "the second operator must not have been tuned again"
+    assert G2.variant() == G1.variant() and G2.info()["lanes_per_row"] == G1.info()["lanes_per_row"]
+    assert dt < 1.0
+    dx, y1, y2 = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M)
+    G1.spmv(dx, y1); G2.spmv(dx, y2)
+    np.testing.assert_array_equal(y1.download(), y2.download())
+    # the 7-point level qualifies for the form without a column stream, and the fixed ranking prefers forms with the
+    # sequential row sum: the result is the oracle's bit for bit
+    assert G1.variant()[1] in ("k_sellp", "k_sell")
+    np.testing.assert_array_equal(y1.download(), A.matvec(x))
+
+
+def test_wave_streamed_kernel_keeps_a_nan_in_the_rows_that_own_it(capi):
+    """k_csr_wave reads whole 16-byte quads, so the first and last quad of a row carry entries of its neighbours: those
+    are dropped with BOTH factors zeroed -- a NaN in x at a column only the neighbouring row owns must not reach this row."""
+    M = 64
+    entries = orc.band_matrix(M, 63)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    G.set_variant(6)
+    rows, cols = np.asarray(entries["row"]), np.asarray(entries["col"])
+    owners = {c: set(rows[cols == c].tolist()) for c in (0, M - 1)}
+    for c in (0, M - 1):
+        x = inputs.v2(M)
+        x[c] = np.nan
+        for lanes in (8, 16, 64):
+            G.set_lanes_per_row(lanes)
+            dx, dy = capi.DeviceVector(M, x), capi.DeviceVector(M)
+            G.spmv(dx, dy)
+            got = dy.download()
+            bad = set(np.flatnonzero(np.isnan(got)).tolist())
+            assert bad == owners[c], f"NaN at column {c}: rows {sorted(bad ^ owners[c])} differ from the owners"
+
+
+def test_column_ordered_form_refuses_blocks_without_entries(capi, monkeypatch):
+    """A row block whose rows hold no local entry (a transfer operator's rows whose entries are all remote) has no segment
+    table: k_csr_cm is refused for such an operator instead of decoding the next block's entries through it."""
+    monkeypatch.setenv("SAENA_KEEP_HOST_VALUES", "1")
+    M = 3072
+    rows = np.concatenate([np.arange(0, 600), np.arange(2200, M)]).astype(np.int32)       # rows 600..2199 are empty: whole blocks of 256 and of 512 rows
+    entries = orc.coo_from_arrays(np.repeat(rows, 3), ((np.repeat(rows, 3) + np.tile([0, 5, 11], rows.size)) % M).astype(np.int32),
+                                  np.tile([4.0, -1.0, -2.0], rows.size))
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    for v in (7, 8):
+        with pytest.raises(capi.SgpuError, match="column-major"):
+            G.set_variant(v)
+    G.set_variant(4); G.set_lanes_per_row(1)
+    x = inputs.v2(M)
+    dx, dy = capi.DeviceVector(M, x), capi.DeviceVector(M)
+    G.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), A.matvec(x))
