@@ -33,7 +33,15 @@ saena_comm *saena_comm_self(void);
 saena_comm *saena_comm_callbacks(int rank, int nranks, void *user, saena_cb_allgather, saena_cb_alltoallv,
                                  saena_cb_allreduce_i64, saena_cb_allreduce_f64);
 saena_comm *saena_comm_rccl(void);            /* [GPU] the sgpu_init() communicator */
+/* the ranks of ONE node through POSIX shared memory (host/shm_comm.h): native, no interpreter and no device in the loop;
+ * collective over the job's ranks, `name` fresh for every job (no '/'); NULL + saena_last_error() on failure */
+saena_comm *saena_comm_shm(const char *name, int rank, int nranks);
 void        saena_comm_free(saena_comm *);
+/* the communicator's collectives, exported for its tests (counts and displacements in bytes, one per rank) */
+int saena_comm_test_alltoallv(saena_comm *, const void *send, const size_t *scounts, const size_t *sdispls, void *recv,
+                              const size_t *rcounts, const size_t *rdispls);
+int saena_comm_test_allreduce_f64(saena_comm *, double *v, int n);
+int saena_comm_test_allreduce_i64(saena_comm *, long *v, int n);
 
 /* ---- saena::matrix (reference include/saena.hpp:14-73) ---- */
 typedef struct saena_matrix_h saena_matrix_h;

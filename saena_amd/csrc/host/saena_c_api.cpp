@@ -2,6 +2,7 @@
 #include "../../../include/saena_c.h"
 #include "saena_matrix.h"
 #include "amg_setup.h"
+#include "shm_comm.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -80,7 +81,22 @@ saena_comm *saena_comm_rccl(void) {
 }
 #endif
 
+saena_comm *saena_comm_shm(const char *name, int rank, int nranks) {
+    std::string err;
+    std::unique_ptr<Comm> m = make_shm_comm(name ? name : "", rank, nranks, &err);
+    if (!m) { h_err = err; return nullptr; }
+    auto *c = new saena_comm();
+    c->c = std::move(m);
+    return c;
+}
+
 void saena_comm_free(saena_comm *c) { delete c; }
+// the collectives themselves, for tests of a communicator (byte counts and displacements as in Comm::alltoallv)
+int saena_comm_test_alltoallv(saena_comm *c, const void *send, const size_t *sc, const size_t *sd, void *recv, const size_t *rc, const size_t *rd) {
+    return guard([&] { c->c->alltoallv(send, sc, sd, recv, rc, rd); });
+}
+int saena_comm_test_allreduce_f64(saena_comm *c, double *v, int n) { return guard([&] { c->c->allreduce_sum_f64(v, n); }); }
+int saena_comm_test_allreduce_i64(saena_comm *c, long *v, int n) { return guard([&] { c->c->allreduce_sum_i64(v, n); }); }
 
 saena_matrix_h *saena_matrix_new(saena_comm *comm) { return comm ? new saena_matrix_h(comm->c.get()) : nullptr; }
 void saena_matrix_free(saena_matrix_h *A) { delete A; }

@@ -27,6 +27,10 @@ HOST_SYMBOLS = {
     "saena_comm_self": (_VP, []),
     "saena_comm_callbacks": (_VP, [C.c_int, C.c_int, _VP, CB_ALLGATHER, CB_ALLTOALLV, CB_I64, CB_F64]),
     "saena_comm_rccl": (_VP, []),
+    "saena_comm_shm": (_VP, [C.c_char_p, C.c_int, C.c_int]),
+    "saena_comm_test_alltoallv": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "saena_comm_test_allreduce_f64": (C.c_int, [_VP, _VP, C.c_int]),
+    "saena_comm_test_allreduce_i64": (C.c_int, [_VP, _VP, C.c_int]),
     "saena_comm_free": (None, [_VP]),
     "saena_matrix_new": (_VP, [_VP]),
     "saena_matrix_free": (None, [_VP]),
@@ -113,8 +117,8 @@ def _ad(a):
 
 
 class Comm:
-    """Setup-time communicator: self, the GPU runtime's RCCL communicator, or
-    torch.distributed (any backend that moves CPU tensors, e.g. gloo) through callbacks."""
+    """Setup-time communicator: self, the GPU runtime's RCCL communicator, the native shared-memory communicator of the
+    ranks of one node, or torch.distributed (any backend that moves CPU tensors, e.g. gloo) through callbacks."""
 
     def __init__(self, which="host", kind="self", dist=None):
         self.L = load(which)
@@ -125,6 +129,11 @@ class Comm:
             self.h = self.L.saena_comm_self()
         elif kind == "rccl":
             self.h = self.L.saena_comm_rccl()
+            if not self.h:
+                raise SgpuError(self.L.saena_last_error().decode())
+        elif kind == "shm":              # dist = (name, rank, nranks): the ranks of one node through shared memory (native)
+            name, self.rank, self.nranks = dist
+            self.h = self.L.saena_comm_shm(str(name).encode(), int(self.rank), int(self.nranks))
             if not self.h:
                 raise SgpuError(self.L.saena_last_error().decode())
         elif kind == "dist":

@@ -101,7 +101,7 @@ POLICIES = {
 }
 
 
-def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, policy="rows4096"):
+def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, policy="rows4096", comm_kind="dist"):
     import os
     import sys
     import torch.distributed as dist
@@ -112,7 +112,9 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, polic
     try:
         from tests.test_host_layout import assert_layout_equal, oracle_layout
         L = host.load("host")
-        comm = host.Comm("host", "dist", dist)
+        # the setup's collectives: torch.distributed through callbacks, or the native shared-memory communicator (the
+        # gloo group stays open either way: the checks below exchange halos with it)
+        comm = host.Comm("host", "dist", dist) if comm_kind == "dist" else host.Comm("host", "shm", (f"test_{port}", rank, world))
         kw = dict(host.OPTIONS001, smoother=smoother)
         if slab:      # bench.py's weak-scaled operator: even z-slabs of an m x m x (nz world + 2) grid (anisotropic: aggregates span ranks)
             nz, n2 = 8, (m - 2) ** 2
@@ -222,14 +224,17 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, polic
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,smoother,world,slab,policy", [("rows", "jacobi", 3, False, "rows4096"), ("rows", "chebyshev", 4, False, "rows4096"),
-                                                             ("rows", "jacobi", 4, True, "rows4096"), ("gathered", "jacobi", 2, False, "rows4096"),
-                                                             ("rows", "jacobi", 4, False, "model"), ("rows", "chebyshev", 4, False, "stride"),
-                                                             ("gathered", "jacobi", 4, False, "stride")])
-def test_distributed_hierarchy_gloo(mode, smoother, world, slab, policy, monkeypatch):
+@pytest.mark.parametrize("mode,smoother,world,slab,policy,comm_kind", [
+    ("rows", "jacobi", 3, False, "rows4096", "dist"), ("rows", "chebyshev", 4, False, "rows4096", "dist"),
+    ("rows", "jacobi", 4, True, "rows4096", "dist"), ("gathered", "jacobi", 2, False, "rows4096", "dist"),
+    ("rows", "jacobi", 4, False, "model", "dist"), ("rows", "chebyshev", 4, False, "stride", "dist"),
+    ("gathered", "jacobi", 4, False, "stride", "dist"),
+    ("rows", "chebyshev", 3, False, "rows4096", "shm"), ("rows", "jacobi", 4, True, "stride", "shm")])
+def test_distributed_hierarchy_gloo(mode, smoother, world, slab, policy, comm_kind, monkeypatch):
     """The hierarchy built over several ranks -- every rank building only its rows of every level (the default), or the
     older gather-then-slice form -- is the one-rank hierarchy bit for bit: every level's A, P and R layout equals the
-    oracle's layout of the one-rank operator under that level's partition."""
+    oracle's layout of the one-rank operator under that level's partition.  The setup's collectives run over gloo through
+    callbacks ("dist") or over the native shared-memory communicator ("shm", host/shm_comm.cpp)."""
     import torch.multiprocessing as mp
     from tests.test_host_layout import _free_port
     monkeypatch.setenv("SAENA_SETUP", mode)
@@ -238,7 +243,7 @@ def test_distributed_hierarchy_gloo(mode, smoother, world, slab, policy, monkeyp
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 30 if slab else 24, ret, smoother, slab, policy)) for r in range(world)]
+        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 30 if slab else 24, ret, smoother, slab, policy, comm_kind)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
