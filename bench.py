@@ -22,8 +22,9 @@ around the timed launches; states whether the working set is Infinity-Cache resi
 `spmv_hbm_resident` (N=1: the same measurement on Poisson 256^3, 1.7 GB, beyond the 256 MiB cache;
 per-GPU work of configs[3]), `check` (one more SpMV, outside the timed region, against the
 host-formed product incl. halo values), `vcycle` (pCG iterations/s and V-cycles/s on the global
-128^3 problem, host-built hierarchy; strong-scaled for N>1), `vcycle_config4` (N>1, opt-in with
---config4-vcycle: the same on the configs[3] operator) and `cpu_baseline` (the compiled reference's own matvec under mpirun on
+128^3 problem, host-built hierarchy; strong-scaled for N>1), `vcycle_config4` (N>1: the same on the configs[3]
+operator, every rank building its rows of the hierarchy, with the residual of the returned iterate recomputed on the host)
+and `cpu_baseline` (the compiled reference's own matvec under mpirun on
 this box's cores -- oracle/_ref, test infrastructure -- or the oracle's restatement as fallback;
 rank 0, N=1 only; never part of the measured path).
 
@@ -54,13 +55,14 @@ def parse():
     ap.add_argument("--hbm-m", "--m-hbm", dest="m_hbm", type=int, default=256, help="grid of the secondary HBM-resident SpMV figure at --gpus 1 (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
-    ap.add_argument("--vcycle-timeout", type=float, default=420.0, help="watchdog of the multi-rank V-cycle legs, seconds")
-    ap.add_argument("--config4-vcycle", action="store_true",
-                    help="N>1: also run the V-cycle / pCG leg on the configs[3] operator itself.  Off by default: the row-distributed host "
-                         "setup of 16.6 M rows per rank takes ~4 min over the gloo setup collectives (profiles/r02_bench_n2_323_*.json), "
-                         "which would put the whole run beyond a few minutes")
+    ap.add_argument("--vcycle-timeout", type=float, default=480.0, help="watchdog of the multi-rank V-cycle legs, seconds")
+    ap.add_argument("--config4-vcycle", action="store_true", help="(the default since round 3; kept for old command lines)")
+    ap.add_argument("--no-config4-vcycle", action="store_true",
+                    help="N>1: skip the V-cycle / pCG leg on the configs[3] operator itself (its row-distributed host setup of 16.6 M rows "
+                         "per rank is the longest part of the run: DESIGN.md 5 has the per-phase budget)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
     ap.add_argument("--spmv-timeout", type=float, default=300.0, help="N>1: watchdog of the SpMV measurement itself, seconds")
+    ap.add_argument("--assemble-timeout", type=float, default=300.0, help="N>1: watchdog of the rendezvous + assemble phase before it, seconds")
     return ap.parse_args()
 
 
@@ -113,7 +115,7 @@ def cpu_baseline(m, seconds):
                       f"(oracle/saena_oracle.c, -O2), {t * 1e3:.3f} ms each"}
 
 
-def vcycle_leg(capi, host, A, m, dist=None):
+def vcycle_leg(capi, host, A, m, dist=None, check_residual=False):
     """Second half of BASELINE.json's metric: V-cycle iterations/s of solve_pCG (options001: Jacobi 3+3,
     tol 1e-8) on the same operator, hierarchy from the host SA setup, everything device-resident.
     With more than one rank every rank calls this (the solve is collective over RCCL); the times are
@@ -157,11 +159,56 @@ def vcycle_leg(capi, host, A, m, dist=None):
     barrier()
     t_v = (time.perf_counter() - t0) / n
     levels = [S.level_info(l) for l in range(S.num_levels)]
-    return {"levels": S.num_levels, "rows": [x["rows"] for x in levels], "nnz": [x["nnzA"] for x in levels],
+    crit = {}
+    if check_residual:
+        # the criterion that needs no CPU reference at this size: ||A u - rhs|| of the returned iterate, formed ON THE HOST
+        # from this rank's layout arrays (halo values of u fetched from their owners over the rendezvous group), against
+        # tol ||rhs||; the device's own last residual must agree with it
+        capi.check(lib.sgpu_solve_pCG(h, du.ptr, dr.ptr, C.byref(it), hist.ctypes.data_as(PD), 64))
+        capi.check(lib.sgpu_device_sync())
+        r2, b2 = host_residual_sq(np, host, A, du.download(), dr.download(), dist)
+        crit = {"residual_check": {"what": "||A u - rhs||_2 of the returned iterate recomputed on the host from the layout arrays (halo of u "
+                                           "exchanged over the rendezvous group), relative to ||rhs||_2; criterion: <= 2 x solver_tol (the stopping "
+                                           "test is on the recursively updated residual)",
+                                   "host_relative_residual": float(np.sqrt(r2 / b2)), "device_relative_residual": float(hh[-1] / hh[0]),
+                                   "tol": 1e-8, "ok": bool(np.sqrt(r2 / b2) <= 2e-8)}}
+    return {**crit, "levels": S.num_levels, "rows": [x["rows"] for x in levels], "nnz": [x["nnzA"] for x in levels],
             "pcg_iterations": it.value, "pcg_iterations_per_s": round(it.value / best, 2), "pcg_solve_ms": round(best * 1e3, 3),
             "vcycles_per_s": round(1.0 / t_v, 2), "vcycle_ms": round(t_v * 1e3, 4),
             "initial_residual": float(hh[0]), "final_residual": float(hh[-1]), "relative_residual": float(hh[-1] / hh[0]),
             "options": "data/options001.xml values: jacobi 3+3, tol 1e-8, conn_str 0.2", "host_setup_s": round(t_setup, 2)}
+
+
+def host_residual_sq(np, host, A, u, rhs, dist):
+    """(sum_i (A u - rhs)_i^2, sum_i rhs_i^2) over all ranks, A u formed on the host from this rank's layout arrays -- the
+    loops of saena_matrix::matvec_sparse (src/saena_matrix_matvec.cpp:9-113): pack u[vIndex], exchange with the neighbours
+    (here: over the rendezvous group), local CSR part, remote CSC part."""
+    d = host.desc_arrays(A.desc())
+    M = d["M"]
+    rows = np.repeat(np.arange(M), d["nnzPerRow_local"])
+    g0 = int(A.split[dist.get_rank()]) if dist is not None else 0
+    y = np.bincount(rows, weights=d["val_local"] * u[d["col_local"] - g0], minlength=M).astype(np.float64)
+    if dist is not None:
+        import torch
+        send = u[d["vIndex"]] if len(d["vIndex"]) else np.zeros(0)
+        reqs, bufs, so = [], [], 0
+        for q, cnt in zip(d["sendProcRank"], d["sendProcCount"]):
+            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(send[so:so + cnt])), int(q)))
+            so += int(cnt)
+        for q, cnt in zip(d["recvProcRank"], d["recvProcCount"]):
+            t = torch.empty(int(cnt), dtype=torch.float64)
+            bufs.append(t)
+            reqs.append(dist.irecv(t, int(q)))
+        for rq in reqs:
+            rq.wait()
+        recv = np.concatenate([t.numpy() for t in bufs]) if bufs else np.zeros(0)
+        if len(recv):
+            slot = np.repeat(np.arange(len(recv)), d["nnzPerCol_remote"])
+            y += np.bincount(d["row_remote"], weights=d["val_remote"] * recv[slot], minlength=M)
+        t = torch.tensor([float(np.sum((y - rhs) ** 2)), float(np.sum(rhs ** 2))], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t[0]), float(t[1])
+    return float(np.sum((y - rhs) ** 2)), float(np.sum(rhs ** 2))
 
 
 def verify_spmv(np, host, A, op, x, y, g0):
@@ -308,11 +355,30 @@ def main():
 
     # ---- operator through the host mirror of saena::matrix (product path, no oracle) ----
     m = args.m if args.m else (128 if world == 1 else 512)
-    # Setup-time collectives (assemble, hierarchy distribution): over the RCCL communicator at one rank; with more
-    # ranks over the gloo group already open for the rendezvous -- that path is exercised at world_size 2-4 by the
-    # CPU test-suite, the RCCL one (RcclHostComm) only at one rank so far.  SAENA_BENCH_SETUP_COMM=rccl overrides.
-    # The data path (halo exchange, dots) rides RCCL either way.
-    if world > 1 and os.environ.get("SAENA_BENCH_SETUP_COMM", "gloo") != "rccl":
+    # Setup-time collectives (assemble, the row-distributed hierarchy): over the RCCL communicator at one rank; with more
+    # ranks over the native shared-memory communicator (exercised at world_size 2-4 by the CPU test-suite).
+    # SAENA_BENCH_SETUP_COMM=gloo routes them through the rendezvous group and Python callbacks instead, =rccl through
+    # RcclHostComm (staged through the device).  The data path (halo exchange, dots) rides RCCL either way.
+    def watchdog(seconds, what, code):
+        import threading
+
+        def bail():
+            print(f"bench.py rank {rank}: {what} did not finish within {seconds:.0f} s", file=sys.stderr, flush=True)
+            os._exit(code)
+        t = threading.Timer(seconds, bail)
+        t.daemon = True
+        t.start()
+        return t
+    # (N > 1: a stall in the rendezvous or in the assemble's collectives must not look like a long run either)
+    asm_dog = watchdog(args.assemble_timeout, "the rendezvous + assemble phase", 5) if world > 1 else None
+    setup_comm = os.environ.get("SAENA_BENCH_SETUP_COMM", "shm")
+    if world > 1 and setup_comm == "shm":
+        # the job's ranks sit on one node (the launch contract): the setup's collectives are memory copies through the native
+        # shared-memory communicator (saena_amd/csrc/host/shm_comm.cpp); the name is fresh for every job
+        box = [f"{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}_{int(time.time() * 1e3) % 10 ** 9}" if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = host.Comm("gpu", "shm", (box[0], rank, world))
+    elif world > 1 and setup_comm == "gloo":
         comm = host.Comm("gpu", "dist", dist)
     else:
         comm = host.Comm("gpu", "rccl")
@@ -323,6 +389,8 @@ def main():
         mg = int(round((world / 8.0) ** (1.0 / 3.0) * (m - 2))) + 2
     grid = (mg, mg, mg)
     A.laplacian3D(*grid).assemble()                      # reference partitioner: nnz-balanced contiguous row blocks
+    if asm_dog is not None:
+        asm_dog.cancel()
     grid_s = f"{mg}^3"
 
     def sync_all():
@@ -494,17 +562,18 @@ def main():
             leg["partition"] = f"{world} nnz-balanced row blocks of the global Poisson {128 if m >= 128 else m}^3 operator"
             legs["vcycle"] = leg
             A2.free()
-            if not args.config4_vcycle:
-                legs["vcycle_config4"] = {"skipped": "opt-in (--config4-vcycle): the host setup of this operator's hierarchy takes ~4 min at 16.6 M rows "
-                                                     "per rank; rehearsed at that size in profiles/r02_bench_n2_323_gpu_spgemm.json"}
+            if args.no_config4_vcycle:
+                legs["vcycle_config4"] = {"skipped": "--no-config4-vcycle"}
             else:
                 capi.check(fatal(line("the configs[3] V-cycle leg ended with a fatal signal").encode()))
                 # (2) configs[3]: the operator of the SpMV measurement above (16.6 M rows per GPU at m = 512); every
                 #     rank builds only its rows of the hierarchy (row-distributed setup)
-                leg = vcycle_leg(capi, host, A, m, dist)
+                leg = vcycle_leg(capi, host, A, m, dist, check_residual=True)
                 leg["scaling"] = "weak"
                 leg["partition"] = f"{world} nnz-balanced row blocks of Poisson {grid_s}"
                 legs["vcycle_config4"] = leg
+                if not leg["residual_check"]["ok"]:
+                    raise RuntimeError(f"configs[3] V-cycle leg: host-recomputed relative residual {leg['residual_check']['host_relative_residual']:.3e} > 2e-8")
         except Exception as e:                              # noqa: BLE001 -- reported with the SpMV line, then a failing status
             dog.cancel()
             msg = f"{type(e).__name__}: {e}"

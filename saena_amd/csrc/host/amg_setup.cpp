@@ -2,6 +2,7 @@
 // file:line in paralab/Saena).  amg_hierarchy::setup builds a hierarchy at one rank;
 // setup_rows_distributed builds the same hierarchy over several ranks, every rank its own rows.
 #include "amg_setup.h"
+#include "par.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -67,13 +68,7 @@ struct Csr {
     std::vector<value_t> val;
 };
 
-int n_threads() {
-    static const int n = [] {
-        if (const char *e = std::getenv("SAENA_SETUP_THREADS")) return std::max(1, std::atoi(e));
-        return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    }();
-    return n;
-}
+int n_threads() { return setup_threads(); }
 
 // run f(t, lo, hi) over [0,n) split into contiguous chunks of about equal `weight`
 template <class F>
@@ -90,16 +85,7 @@ void parallel_rows(index_t n, const std::vector<nnz_t> *weight_ptr, F f) {
     }
     for (int t = 1; t <= T; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
     if (T == 1) { f(0, 0, n); return; }
-    std::vector<std::thread> th;
-    std::exception_ptr err;
-    std::mutex mu;
-    for (int t = 0; t < T; ++t)
-        th.emplace_back([&, t] {
-            try { f(t, cut[t], cut[t + 1]); }
-            catch (...) { std::lock_guard<std::mutex> g(mu); err = std::current_exception(); }
-        });
-    for (auto &x : th) x.join();
-    if (err) std::rethrow_exception(err);
+    ThreadPool::get().run(T, [&](int t) { f(t, cut[(size_t)t], cut[(size_t)t + 1]); });
 }
 
 // the assembled one-rank operator as CSR (its layout arrays are row-major, columns ascending)
@@ -136,11 +122,23 @@ Csr transpose(const Csr &A) {
 spgemm_hook_fn g_spgemm_hook = nullptr;
 namespace {
 
-Csr spgemm(const Csr &A, const Csr &B, index_t row_offset = 0) {
+// the left operand as three arrays: the distributed setup multiplies R and R A with their columns re-labelled to positions
+// in the stacked right operand, and only that column array is new (row pointers and values are the operand's own)
+struct CsrRef {
+    index_t nrows = 0;
+    const nnz_t *ptr = nullptr;
+    const index_t *col = nullptr;
+    const value_t *val = nullptr;
+    CsrRef() {}
+    CsrRef(const Csr &M) : nrows(M.nrows), ptr(M.ptr.data()), col(M.col.data()), val(M.val.data()) {}
+    CsrRef(const Csr &M, const std::vector<index_t> &cols) : nrows(M.nrows), ptr(M.ptr.data()), col(cols.data()), val(M.val.data()) {}
+};
+
+Csr spgemm(const CsrRef &A, const Csr &B, index_t row_offset = 0) {
     Csr C;
     C.nrows = A.nrows; C.ncols = B.ncols;
-    if (g_spgemm_hook && (A.col.size() + B.col.size()) >= 200000 && A.nrows > 0 && B.nrows > 0) {
-        if (g_spgemm_hook(A.nrows, B.nrows, B.ncols, A.ptr.data(), A.col.data(), A.val.data(), B.ptr.data(), B.col.data(), B.val.data(),
+    if (g_spgemm_hook && A.nrows > 0 && B.nrows > 0 && ((size_t)A.ptr[A.nrows] + B.col.size()) >= 200000) {
+        if (g_spgemm_hook(A.nrows, B.nrows, B.ncols, A.ptr, A.col, A.val, B.ptr.data(), B.col.data(), B.val.data(),
                           row_offset, C.ptr, C.col, C.val) == 0)
             return C;
         C.ptr.clear(); C.col.clear(); C.val.clear();       // the GPU declined (memory): the host kernel below
@@ -245,11 +243,13 @@ Csr spgemm(const Csr &A, const Csr &B, index_t row_offset = 0) {
     C.ptr[0] = 0;
     for (index_t i = 0; i < A.nrows; ++i) C.ptr[i + 1] = C.ptr[i] + rowlen[i];
     C.col.resize((size_t)C.ptr[A.nrows]); C.val.resize((size_t)C.ptr[A.nrows]);
-    for (int t = 0; t < T; ++t) {
-        if (tcol[t].empty()) continue;
-        std::copy(tcol[t].begin(), tcol[t].end(), C.col.begin() + C.ptr[tlo[t]]);
-        std::copy(tval[t].begin(), tval[t].end(), C.val.begin() + C.ptr[tlo[t]]);
-    }
+    parallel_chunks<int>(T, 1, [&](int, int t0, int t1) {
+        for (int t = t0; t < t1; ++t) {
+            if (tcol[t].empty()) continue;
+            std::copy(tcol[t].begin(), tcol[t].end(), C.col.begin() + C.ptr[tlo[t]]);
+            std::copy(tval[t].begin(), tval[t].end(), C.val.begin() + C.ptr[tlo[t]]);
+        }
+    });
     return C;
 }
 
@@ -688,7 +688,7 @@ void amg_hierarchy::distribute(Comm &c, const std::vector<index_t> &split0) {
             const std::vector<index_t> sa = nnz_balanced_split(self, rows, levels[l].A->nnz_g, active, [&](const std::vector<index_t> &firstSplit, std::vector<long> &H) {
                 const int nb = (int)H.size();
                 for (index_t i = 0; i < rows; ++i) H[(size_t)lower_bound2(firstSplit.data(), firstSplit.data() + nb, i)] += npr[(size_t)i];
-            });
+            }, 4096);
             for (int r = 0; r <= np; ++r) sp[(size_t)r] = sa[(size_t)std::min(active, (r + stride_prev - 1) / stride_prev)];
         }
         dist[l].split = merge_split(sp, level_stride[(size_t)l]);
@@ -825,23 +825,29 @@ std::vector<index_t> outside_cols(const Csr &M, index_t lo, index_t hi) {
     return ids;
 }
 
-// local rows + fetched rows stacked; columns of `M` relabelled to row positions in that stack (order untouched)
+// local rows + fetched rows stacked (the right operand of a distributed product); the left operand's columns are
+// re-labelled to row positions in that stack (order untouched).  Copies run on threads: a level is gigabytes.
 Csr stack_rows(const Csr &local, const Csr &halo) {
     Csr B;
     B.nrows = local.nrows + halo.nrows; B.ncols = local.ncols;
-    B.ptr = local.ptr;
+    B.ptr.resize((size_t)B.nrows + 1);
+    parallel_copy(B.ptr.data(), local.ptr.data(), (size_t)local.nrows + 1);
     const nnz_t base = local.ptr[local.nrows];
-    for (index_t i = 0; i < halo.nrows; ++i) B.ptr.push_back(base + halo.ptr[i + 1]);
-    B.col = local.col; B.col.insert(B.col.end(), halo.col.begin(), halo.col.end());
-    B.val = local.val; B.val.insert(B.val.end(), halo.val.begin(), halo.val.end());
+    for (index_t i = 0; i < halo.nrows; ++i) B.ptr[(size_t)local.nrows + 1 + i] = base + halo.ptr[i + 1];
+    B.col.resize((size_t)base + halo.col.size()); B.val.resize((size_t)base + halo.val.size());
+    parallel_copy(B.col.data(), local.col.data(), (size_t)base);
+    parallel_copy(B.val.data(), local.val.data(), (size_t)base);
+    std::copy(halo.col.begin(), halo.col.end(), B.col.begin() + base);
+    std::copy(halo.val.begin(), halo.val.end(), B.val.begin() + base);
     return B;
 }
-Csr relabel_cols(const Csr &M, index_t lo, index_t hi, const FetchPlan &plan, index_t ext_rows) {
-    Csr R = M;
-    R.ncols = ext_rows;
+std::vector<index_t> relabel_cols(const Csr &M, index_t lo, index_t hi, const FetchPlan &plan) {
+    std::vector<index_t> out(M.col.size());
     const index_t nloc = hi - lo;
-    for (auto &cidx : R.col) cidx = (cidx >= lo && cidx < hi) ? cidx - lo : nloc + plan.pos(cidx);
-    return R;
+    parallel_chunks<size_t>(M.col.size(), (size_t)1 << 20, [&](int, size_t a, size_t b) {
+        for (size_t k = a; k < b; ++k) { const index_t cidx = M.col[k]; out[k] = (cidx >= lo && cidx < hi) ? cidx - lo : nloc + plan.pos(cidx); }
+    });
+    return out;
 }
 
 // the rows of this rank's block [row_lo, row_lo + X.nrows) go to their owners under `split_to`; returns the rows this
@@ -882,7 +888,8 @@ double dist_find_eig(Comm &c, const Csr &A, const std::vector<index_t> &split, c
     for (index_t i = 0; i < n; ++i) isd[i] = std::sqrt(std::fabs(inv_diag[i]));
     std::vector<double> isdE = isd;
     { const std::vector<double> h = planA.values(c, isd); isdE.insert(isdE.end(), h.begin(), h.end()); }
-    const Csr Ar = relabel_cols(A, lo, hi, planA, n + (index_t)planA.wanted.size());
+    const std::vector<index_t> arcol = relabel_cols(A, lo, hi, planA);
+    struct { const std::vector<nnz_t> &ptr; const std::vector<index_t> &col; const std::vector<value_t> &val; } Ar{A.ptr, arcol, A.val};
     auto gsum = [&](double x) { c.allreduce_sum_f64(&x, 1); return x; };
     auto matvec = [&](const std::vector<double> &x, std::vector<double> &y) {
         std::vector<double> xE = x;
@@ -1200,29 +1207,45 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         // ---- R = P^T, rows to the owners of the coarse rows (under splitC), fine columns ascending ----
         Csr R;
         {
-            // entries (coarse row, fine col) in (row, col) order by a counting sort over the coarse ids this rank touches;
-            // owners are contiguous ranges of coarse ids, so that order is also grouped by destination rank
+            // Most of P's columns are coarse ids this rank owns itself (aggregates rarely cross the partition): those entries
+            // are transposed in place; only the others travel, as (coarse row, fine col, value) triples in (row, col) order --
+            // a counting sort over the coarse ids they touch, which is also grouped by destination rank (owners are
+            // contiguous ranges of coarse ids).
+            const bool own_any = chi > clo;
+            auto is_local = [&](index_t cidx) { return own_any && cidx >= clo && cidx < chi; };
             index_t cmin = new_size, cmax = -1;
-            for (index_t cidx : P.col) { cmin = std::min(cmin, cidx); cmax = std::max(cmax, cidx); }
-            std::vector<cooEntry> send(P.col.size());
-            std::vector<int> sc((size_t)np, 0);
-            if (cmax >= cmin) {
+            nnz_t nfar = 0;
+            for (index_t cidx : P.col) if (!is_local(cidx)) { cmin = std::min(cmin, cidx); cmax = std::max(cmax, cidx); ++nfar; }
+            std::vector<cooEntry> send((size_t)nfar);
+            std::vector<int> sc((size_t)np, 0), rcnt;
+            if (nfar) {
                 std::vector<nnz_t> at((size_t)(cmax - cmin) + 2, 0);
-                for (index_t cidx : P.col) at[(size_t)(cidx - cmin) + 1]++;
+                for (index_t cidx : P.col) if (!is_local(cidx)) at[(size_t)(cidx - cmin) + 1]++;
                 for (size_t j = 0; j + 1 < at.size(); ++j) at[j + 1] += at[j];
                 for (index_t i = 0; i < nloc; ++i)
-                    for (nnz_t k = P.ptr[i]; k < P.ptr[i + 1]; ++k) send[(size_t)at[(size_t)(P.col[k] - cmin)]++] = cooEntry(P.col[k], i + lo, P.val[k]);
+                    for (nnz_t k = P.ptr[i]; k < P.ptr[i + 1]; ++k)
+                        if (!is_local(P.col[k])) send[(size_t)at[(size_t)(P.col[k] - cmin)]++] = cooEntry(P.col[k], i + lo, P.val[k]);
                 for (const auto &x : send) sc[owner_of_id(splitC, x.row)]++;
             }
-            // received blocks come from ranks in ascending order = ascending fine ids, each block in (row, col) order:
-            // a stable counting sort by row restores (row, col) order over the whole
-            const std::vector<cooEntry> got = c.alltoallv_records(send, sc);
+            // received blocks come from ranks in ascending order = ascending fine ids, each block in (row, col) order; the
+            // local entries' fine ids lie between those of the lower and of the higher ranks: filling "lower ranks, own
+            // entries by ascending fine row, higher ranks" leaves every coarse row's columns ascending
+            const std::vector<cooEntry> got = c.alltoallv_records(send, sc, &rcnt);
+            size_t nlow = 0;
+            for (int p = 0; p < me; ++p) nlow += (size_t)rcnt[(size_t)p];
             R.nrows = chi - clo; R.ncols = Mbig; R.ptr.assign((size_t)R.nrows + 1, 0);
             for (const auto &x : got) R.ptr[(size_t)(x.row - clo) + 1]++;
+            for (index_t cidx : P.col) if (is_local(cidx)) R.ptr[(size_t)(cidx - clo) + 1]++;
             for (index_t i = 0; i < R.nrows; ++i) R.ptr[i + 1] += R.ptr[i];
-            R.col.resize(got.size()); R.val.resize(got.size());
+            const size_t tot = (size_t)R.ptr[(size_t)R.nrows];
+            R.col.resize(tot); R.val.resize(tot);
             std::vector<nnz_t> at(R.ptr.begin(), R.ptr.end() - 1);
-            for (const auto &x : got) { const nnz_t q = at[(size_t)(x.row - clo)]++; R.col[(size_t)q] = x.col; R.val[(size_t)q] = x.val; }
+            auto put = [&](const cooEntry &x) { const nnz_t q = at[(size_t)(x.row - clo)]++; R.col[(size_t)q] = x.col; R.val[(size_t)q] = x.val; };
+            for (size_t j = 0; j < nlow; ++j) put(got[j]);
+            for (index_t i = 0; i < nloc; ++i)
+                for (nnz_t k = P.ptr[i]; k < P.ptr[i + 1]; ++k)
+                    if (is_local(P.col[k])) { const nnz_t q = at[(size_t)(P.col[k] - clo)]++; R.col[(size_t)q] = i + lo; R.val[(size_t)q] = P.val[k]; }
+            for (size_t j = nlow; j < got.size(); ++j) put(got[j]);
         }
         pt.lap("R = P^T");
 
@@ -1232,7 +1255,8 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             FetchPlan pl;
             pl.build(c, split, outside_cols(R, lo, hi));
             const Csr Aext = stack_rows(A, pl.rows(c, A));
-            RA = spgemm(relabel_cols(R, lo, hi, pl, Aext.nrows), Aext, clo);
+            const std::vector<index_t> rcol = relabel_cols(R, lo, hi, pl);
+            RA = spgemm(CsrRef(R, rcol), Aext, clo);
         }
         pt.lap("R*A");
         Csr AcN;
@@ -1240,7 +1264,8 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             FetchPlan pl;
             pl.build(c, split, outside_cols(RA, lo, hi));
             const Csr Pext = stack_rows(P, pl.rows(c, P));
-            AcN = spgemm(relabel_cols(RA, lo, hi, pl, Pext.nrows), Pext, clo);
+            const std::vector<index_t> rcol = relabel_cols(RA, lo, hi, pl);
+            AcN = spgemm(CsrRef(RA, rcol), Pext, clo);
             RA = Csr();
         }
         pt.lap("(RA)*P");
@@ -1268,7 +1293,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                     const int nb = (int)H.size();
                     for (index_t i = 0; i < AcN.nrows; ++i)
                         H[(size_t)lower_bound2(firstSplit.data(), firstSplit.data() + nb, i + clo)] += (long)(AcN.ptr[i + 1] - AcN.ptr[i]);
-                });
+                }, 4096);      // (a finer histogram than the fine level's nparts^2 buckets: at 2 ranks those put 75 % of a level on one rank)
                 // part a of the active ranks is rank a * stride_prev; the idle ranks in between keep empty blocks
                 for (int r = 0; r <= np; ++r) {
                     const int a = std::min(active, (r + stride_prev - 1) / stride_prev);
@@ -1276,6 +1301,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                 }
             }
             splitC = merge_split(splitB, stride);
+            pt.lap("coarse partition");
             if (splitC != splitNew) {
                 R = route_rows(c, R, clo, splitC);
                 AcN = route_rows(c, AcN, clo, splitC);
@@ -1284,7 +1310,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             }
             if (stride > stride_prev && std::getenv("SAENA_SETUP_TIMING") && me == 0)
                 fprintf(stderr, "[setup L%d] level %d (%d rows, %ld nnz) agglomerated: rank stride %d -> %d\n", l, l + 1, new_size, nnzC, stride_prev, stride);
-            pt.lap("agglomeration");
+            pt.lap("rows to their owners");
         }
         // ---- this level's transfer operators in the reference's layout ----
         {
@@ -1293,22 +1319,26 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             c.allreduce_sum_i64(&nn, 1);
             d.nnzP = nn;
             d.P.build_from_csr(c, P.ptr, P.col, P.val, split, splitC);
+            pt.lap("layout of P");
             d.R.build_from_csr(c, R.ptr, R.col, R.val, splitC, split);
+            pt.lap("layout of R");
         }
         // ---- next level ----
         std::vector<value_t> invd((size_t)(chi - clo), 1.0);
-        for (index_t i = 0; i < chi - clo; ++i)
-            for (nnz_t k = AcN.ptr[i]; k < AcN.ptr[i + 1]; ++k)
-                if (AcN.col[k] == i + clo) {
-                    if (std::fabs(AcN.val[k]) < SAENA_ALMOST_ZERO) throw std::runtime_error("there is a zero diagonal element at row index = " + std::to_string(i + clo));
-                    invd[i] = 1.0 / AcN.val[k];
-                }
+        parallel_rows(chi - clo, &AcN.ptr, [&](int, index_t r0, index_t r1) {
+            for (index_t i = r0; i < r1; ++i)
+                for (nnz_t k = AcN.ptr[i]; k < AcN.ptr[i + 1]; ++k)
+                    if (AcN.col[k] == i + clo) {
+                        if (std::fabs(AcN.val[k]) < SAENA_ALMOST_ZERO) throw std::runtime_error("there is a zero diagonal element at row index = " + std::to_string(i + clo));
+                        invd[(size_t)i] = 1.0 / AcN.val[k];
+                    }
+        });
         A = std::move(AcN);
         A.ncols = new_size;
         inv_diag.swap(invd);
         split = splitC;
         Mbig = new_size;
-        pt.lap("layouts of P, R");
+        pt.lap("inverse diagonal");
         if (ret_val == 1) max_level = l + 1;                              // :287-289 this will be the last level
     }
     levels.resize(1);

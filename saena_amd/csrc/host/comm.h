@@ -7,6 +7,7 @@
 //   CallbackComm  caller-supplied C callbacks (tests plug torch.distributed/gloo in);
 //   the RCCL communicator of the GPU runtime (sgpu_host_comm(), sgpu_runtime.hip).
 #pragma once
+#include "par.h"
 #include <cstddef>
 #include <cstring>
 #include <stdexcept>
@@ -110,7 +111,7 @@ struct CallbackComm : Comm {
         // the block a rank sends to itself never leaves the process: one memcpy here instead of a trip through the
         // callback (the setup's row routing and transposition keep most of a multi-GB level local)
         if (sc[rank] != rc[rank]) throw std::runtime_error("CallbackComm::alltoallv: self count mismatch");
-        if (sc[rank]) std::memmove(static_cast<char *>(recv) + rd[rank], static_cast<const char *>(send) + sd[rank], sc[rank]);
+        if (sc[rank]) parallel_copy(static_cast<char *>(recv) + rd[rank], static_cast<const char *>(send) + sd[rank], sc[rank]);   // (send and recv never overlap)
         std::vector<size_t> sc2(sc, sc + nranks), rc2(rc, rc + nranks);
         sc2[(size_t)rank] = 0; rc2[(size_t)rank] = 0;
         ok(cb_alltoallv(user, send, sc2.data(), sd, recv, rc2.data(), rd), "alltoallv");

@@ -2,6 +2,7 @@
 // Restates, with our own data structures, what the reference does between
 // saena::matrix::set() and the first matvec (citations: file:line in paralab/Saena).
 #include "saena_matrix.h"
+#include "par.h"
 
 #include <algorithm>
 #include <cmath>
@@ -305,13 +306,18 @@ void saena_matrix::setup_initial_data() {
 // left to right until a part holds ~nnz_g/nparts entries.  `add_local_histogram(firstSplit, H)` adds this rank's
 // entries per bucket; the histogram is summed over the ranks here.
 std::vector<index_t> nnz_balanced_split(Comm &c, index_t Mbig, nnz_t nnz_g, int nparts,
-                                        const std::function<void(const std::vector<index_t> &, std::vector<long> &)> &add_local_histogram) {
+                                        const std::function<void(const std::vector<index_t> &, std::vector<long> &)> &add_local_histogram,
+                                        int min_buckets) {
     std::vector<index_t> split((size_t)nparts + 1, 0);
     if (nparts == 1) { split[1] = Mbig; return split; }
     int n_buckets;
     if (Mbig > nparts * nparts) n_buckets = nparts < 1000 ? nparts * nparts : 1000 * nparts;
     else if (nparts <= Mbig) n_buckets = Mbig;
     else throw std::runtime_error("number of tasks cannot be greater than the number of rows of the matrix.");
+    // nparts^2 buckets are the reference's resolution (4 buckets at 2 ranks: a part boundary can only sit at 25, 50 or 75 % of
+    // the rows).  The fine operator's partition is pinned by the compiled reference and keeps it; coarse operators ask for
+    // a finer histogram.
+    if (min_buckets > n_buckets) n_buckets = (int)std::min<long>(min_buckets, Mbig);
     std::vector<index_t> splitOffset((size_t)n_buckets, 0);
     const index_t baseOffset = (index_t)std::floor(1.0 * Mbig / n_buckets);
     const float offsetRes = float(1.0 * Mbig / n_buckets) - baseOffset;
@@ -542,20 +548,42 @@ void DistLayout::build_from_csr(Comm &c, const std::vector<nnz_t> &ptr, const st
     nnzPerProcScan.assign((size_t)nprocs + 1, 0);
     struct Rem { index_t col, row; value_t val; };
     std::vector<Rem> rem;
-    nnz_t nloc = 0;
-    for (index_t i = 0; i < M; ++i)
-        for (nnz_t k = ptr[i]; k < ptr[i + 1]; ++k) {
-            if (col[k] >= lo && col[k] < hi) { ++nnzPerRow_local[i]; ++nloc; }
-            else rem.push_back({col[k], i, val[k]});
+    auto lay_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = lay_now();
+    // two passes over the rows on threads: count the local entries of every row and collect the (few) remote ones, then
+    // copy the local entries to their places (a level of the configs[3] hierarchy holds up to 0.6 G entries per rank)
+    std::vector<std::vector<Rem>> trem((size_t)setup_threads());
+    parallel_chunks<index_t>(M, 4096, [&](int t, index_t r0, index_t r1) {
+        auto &mine = trem[(size_t)t];
+        for (index_t i = r0; i < r1; ++i) {
+            index_t n = 0;
+            for (nnz_t k = ptr[i]; k < ptr[i + 1]; ++k) {
+                if (col[k] >= lo && col[k] < hi) ++n;
+                else mine.push_back({col[k], i, val[k]});
+            }
+            nnzPerRow_local[(size_t)i] = n;
         }
+    });
+    for (auto &v : trem) rem.insert(rem.end(), v.begin(), v.end());      // chunks are ascending row ranges: row order is kept
+    const double t_count = lay_now();
+    std::vector<nnz_t> lptr((size_t)M + 1, 0);
+    for (index_t i = 0; i < M; ++i) lptr[(size_t)i + 1] = lptr[(size_t)i] + nnzPerRow_local[(size_t)i];
+    const nnz_t nloc = lptr[(size_t)M];
     nnz_l_local = nloc;
     col_local.resize((size_t)nloc); val_local.resize((size_t)nloc);
-    {
-        nnz_t q = 0;
-        for (index_t i = 0; i < M; ++i)
+    parallel_chunks<index_t>(M, 4096, [&](int, index_t r0, index_t r1) {
+        for (index_t i = r0; i < r1; ++i) {
+            nnz_t q = lptr[(size_t)i];
+            if (lptr[(size_t)i + 1] - q == ptr[i + 1] - ptr[i]) {           // a row without remote entries: one copy
+                std::copy(col.begin() + ptr[i], col.begin() + ptr[i + 1], col_local.begin() + q);
+                std::copy(val.begin() + ptr[i], val.begin() + ptr[i + 1], val_local.begin() + q);
+                continue;
+            }
             for (nnz_t k = ptr[i]; k < ptr[i + 1]; ++k)
                 if (col[k] >= lo && col[k] < hi) { col_local[(size_t)q] = col[k]; val_local[(size_t)q] = val[k]; ++q; }
-    }
+        }
+    });
+    const double t_copy = lay_now();
     std::sort(rem.begin(), rem.end(), [](const Rem &a, const Rem &b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
     size_t i = 0;
     while (i < rem.size()) {                                             // the remote half of :828-859
@@ -578,7 +606,11 @@ void DistLayout::build_from_csr(Comm &c, const std::vector<nnz_t> &ptr, const st
     nnz_l_remote = (nnz_t)row_remote.size();
     col_remote_size = (index_t)vElement_remote.size();
     recvCount[rank] = 0;
+    const double t_rem = lay_now();
     finish_plan(c, split_col);
+    if (std::getenv("SAENA_LAYOUT_TIMING"))
+        fprintf(stderr, "[layout] %d rows, %ld local + %ld remote entries: classify %.3f, copy %.3f, remote part %.3f, plan %.3f s\n", M, (long)nnz_l_local,
+                (long)nnz_l_remote, t_count - t_begin, t_copy - t_count, t_rem - t_copy, lay_now() - t_rem);
 }
 
 void DistLayout::build_single_rank(index_t M_, index_t N_, const std::vector<nnz_t> &ptr, std::vector<index_t> &&col,

@@ -37,7 +37,8 @@ long lower_bound2(const index_t *left, const index_t *right, index_t val);
 // the reference's nnz-balanced contiguous row partition (saena_matrix_repart.cpp:43-170 for the fine operator, :728-980
 // for every coarse one): see saena_matrix.cpp
 std::vector<index_t> nnz_balanced_split(Comm &c, index_t Mbig, nnz_t nnz_g, int nparts,
-                                        const std::function<void(const std::vector<index_t> &, std::vector<long> &)> &add_local_histogram);
+                                        const std::function<void(const std::vector<index_t> &, std::vector<long> &)> &add_local_histogram,
+                                        int min_buckets = 0);
 
 // The halo plan + local/remote split shared by A, R and P.
 struct DistLayout {

@@ -118,15 +118,15 @@ struct ShmComm : Comm {
         size_t o = 0;
         for (int p = 0; p < nranks; ++p) {
             me.off[p] = o; me.cnt[p] = p == rank ? 0 : sc[p];
-            if (p != rank && sc[p]) { std::memcpy(seg[rank] + o, s + sd[p], sc[p]); o += sc[p]; }
+            if (p != rank && sc[p]) { parallel_copy(seg[rank] + o, s + sd[p], sc[p]); o += sc[p]; }
         }
-        if (sc[rank]) std::memmove(r + rd[rank], s + sd[rank], sc[rank]);
+        if (sc[rank]) parallel_copy(r + rd[rank], s + sd[rank], sc[rank]);      // (send and recv never overlap)
         barrier();                                       // every segment is written
         for (int k = 1; k < nranks; ++k) {               // start with the next rank: not everybody reads rank 0 first
             const int p = (rank + k) % nranks;
             const PerRank &q = ctl->r[p];
             if (q.cnt[rank] != rc[p]) die("alltoallv: rank " + std::to_string(p) + " sends " + std::to_string(q.cnt[rank]) + " bytes, " + std::to_string(rc[p]) + " expected");
-            if (rc[p]) std::memcpy(r + rd[p], peer(p) + q.off[rank], rc[p]);
+            if (rc[p]) parallel_copy(r + rd[p], peer(p) + q.off[rank], rc[p]);
         }
         barrier();                                       // every segment is read: it may be overwritten
         release(tot);
