@@ -773,13 +773,28 @@ struct FetchPlan {
         std::sort(ids.begin(), ids.end());
         ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
         wanted.swap(ids);
+        index_positions();
         lo = split[c.rank];
         scount.assign((size_t)c.nranks, 0);
         for (index_t g : wanted) scount[owner_of_id(split, g)]++;
         serve = c.alltoallv_records(wanted, scount, &rcount);
         for (auto &x : serve) x -= lo;
     }
-    index_t pos(index_t g) const { return (index_t)(std::lower_bound(wanted.begin(), wanted.end(), g) - wanted.begin()); }
+    // position of a wanted id: a table over the id range when the plan is large (the coarse levels of a hierarchy fetch a
+    // good part of the level: a binary search per entry of the operator was a second per product there), else a search
+    std::vector<index_t> where;             // where[g - wanted.front()], built by index_positions()
+    void index_positions() {
+        where.clear();
+        if (wanted.size() < 4096) return;
+        const size_t span = (size_t)(wanted.back() - wanted.front()) + 1;
+        if (span > 16 * wanted.size() + ((size_t)1 << 20)) return;
+        where.assign(span, -1);
+        for (size_t i = 0; i < wanted.size(); ++i) where[(size_t)(wanted[i] - wanted.front())] = (index_t)i;
+    }
+    index_t pos(index_t g) const {
+        if (!where.empty()) return where[(size_t)(g - wanted.front())];
+        return (index_t)(std::lower_bound(wanted.begin(), wanted.end(), g) - wanted.begin());
+    }
     // one T per wanted id, from the owner's local array
     template <class T>
     std::vector<T> values(Comm &c, const T *local) const {
@@ -816,12 +831,18 @@ struct FetchPlan {
     }
 };
 
-// ids referenced by the columns of `M` that fall outside [lo, hi)
+// ids referenced by the columns of `M` that fall outside [lo, hi), ascending: marked in a bitmap over the column range on
+// threads (a coarse level references a good part of its columns from outside: collecting and sorting every such entry was
+// a second per level), then read off in order
 std::vector<index_t> outside_cols(const Csr &M, index_t lo, index_t hi) {
+    const size_t ncols = (size_t)std::max<index_t>(M.ncols, 0);
     std::vector<index_t> ids;
-    for (index_t cidx : M.col) if (cidx < lo || cidx >= hi) ids.push_back(cidx);
-    std::sort(ids.begin(), ids.end());
-    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    if (M.col.empty() || ncols == 0) return ids;
+    std::vector<unsigned char> mark(ncols, 0);
+    parallel_chunks<size_t>(M.col.size(), (size_t)1 << 20, [&](int, size_t a, size_t b) {
+        for (size_t k = a; k < b; ++k) { const index_t cidx = M.col[k]; if (cidx < lo || cidx >= hi) __atomic_store_n(&mark[(size_t)cidx], (unsigned char)1, __ATOMIC_RELAXED); }
+    });
+    for (size_t g = 0; g < ncols; ++g) if (mark[g]) ids.push_back((index_t)g);
     return ids;
 }
 
@@ -876,6 +897,7 @@ Csr route_rows(Comm &c, const Csr &X, index_t row_lo, const std::vector<index_t>
 }
 
 struct AggState { index_t agg; char decided, is_root; char pad[2]; };
+struct AggDelta { index_t slot; AggState s; };
 
 } // namespace
 
@@ -1069,18 +1091,34 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         const int T = n_threads();
         std::vector<std::vector<index_t>> tnext((size_t)T), tdone((size_t)T);
         long rounds = 0, my_undecided = nloc;
+        std::vector<AggState> sent(planA.serve.size());                     // what every asker holds of the rows served to it
+        for (size_t q = 0; q < sent.size(); ++q) sent[q] = AggState{planA.serve[q] + lo, 0, 0, {0, 0}};
         while (true) {
-            {   // halo refresh; the rows that look at a halo row whose state changed join this round's work list
-                const std::vector<AggState> h = planA.values(c, st.data());
-                for (size_t j = 0; j < h.size(); ++j) {
-                    AggState &old = st[(size_t)nloc + j];
-                    if (old.agg != h[j].agg || old.decided != h[j].decided || old.is_root != h[j].is_root) {
-                        old = h[j];
+            {   // halo refresh; the rows that look at a halo row whose state changed join this round's work list.  Only the
+                // CHANGES travel: (position in the asker's list, new state) of the served rows whose state differs from what
+                // was sent last -- the halo of a 16 M-row block is millions of rows and a level takes ~10^3 rounds, in most of
+                // which a handful of them change
+                std::vector<AggDelta> out;
+                std::vector<int> oc((size_t)np, 0), ic;
+                size_t q = 0;
+                for (int p = 0; p < np; ++p)
+                    for (int k = 0; k < planA.rcount[(size_t)p]; ++k, ++q) {
+                        const AggState &now = st[(size_t)planA.serve[q]];
+                        AggState &was = sent[q];
+                        if (was.agg != now.agg || was.decided != now.decided || was.is_root != now.is_root) { was = now; out.push_back(AggDelta{(index_t)k, now}); ++oc[(size_t)p]; }
+                    }
+                const std::vector<AggDelta> in = c.alltoallv_records(out, oc, &ic);
+                size_t at = 0, base = 0;
+                for (int p = 0; p < np; ++p) {                                  // the ids asked of rank p are wanted[base, base + scount[p])
+                    for (int k = 0; k < ic[(size_t)p]; ++k, ++at) {
+                        const size_t j = base + (size_t)in[at].slot;
+                        st[(size_t)nloc + j] = in[at].s;
                         for (nnz_t it = tptr[(size_t)nloc + j]; it < tptr[(size_t)nloc + j + 1]; ++it) {
                             const index_t r = tcol[it];
                             if (!st[r].decided && !queued[r]) { queued[r] = 1; work.push_back(r); }
                         }
                     }
+                    base += (size_t)planA.scount[(size_t)p];
                 }
                 std::sort(work.begin(), work.end());
             }

@@ -87,3 +87,45 @@ def test_bench_failure_in_a_multi_rank_leg_is_a_failing_exit_status():
     d = json.loads(lines[0])
     assert "did not finish" in d["vcycle_error"] and d["check"]["ok"] is True and d["value"] > 0
     assert "bench.py rank" in out.stderr
+
+
+@pytest.mark.skipif(bool(os.environ.get("SAENA_SKIP_FULLSIZE")), reason="SAENA_SKIP_FULLSIZE set (development runs)")
+def test_bench_two_ranks_at_the_full_per_rank_size_of_configs3():
+    """BASELINE configs[3] is Poisson 512^3 over 8 GPUs: 16.6 M rows per GPU.  `bench.py --gpus 2` with its defaults -- the
+    cube with those rows per GPU (323^3), both V-cycle legs, every rank building its rows of the 11-level hierarchy over the
+    native shared-memory communicator -- runs here with both ranks on this card (host transport in place of RCCL):
+      * exit status 0 inside the driver's time budget, ONE JSON line;
+      * the 128^3 strong-scaled leg prints the reference's line (9 iterations, 5.992963e+04 -> 5.355578e-05);
+      * the configs[3] leg converges, and the residual of its returned iterate recomputed ON THE HOST from the layout
+        arrays is within the solver tolerance (the criterion that needs no CPU reference at this size);
+      * its residual history is the ONE-RANK history of the same 323^3 problem within 1e-10 ||r0|| (north_star's tolerance),
+        same iteration count -- the one-rank run is `bench.py --gpus 1 --grid-m 323`."""
+    import json
+    import time
+    t0 = time.time()
+    out = _bench_rehearsal(2, ["--vcycle-timeout", "900"], timeout=1100)
+    t_two = time.time() - t0
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert "vcycle_error" not in d and d["check"]["ok"] is True
+    assert "323^3" in d["metric"] and sum(d["config"]["rows_per_gpu"]) == 321 ** 3 and min(d["config"]["rows_per_gpu"]) > 16_000_000
+    v = d["vcycle"]
+    assert v["pcg_iterations"] == 9 and abs(v["initial_residual"] / 5.992963e+04 - 1) < 1e-6 and abs(v["final_residual"] / 5.355578e-05 - 1) < 2e-6
+    w = d["vcycle_config4"]
+    assert w["levels"] == 11 and w["rows"][0] == 321 ** 3 and w["relative_residual"] <= 1e-8
+    assert w["residual_check"]["ok"] is True and w["residual_check"]["host_relative_residual"] <= 2e-8
+    assert abs(w["residual_check"]["host_relative_residual"] / w["residual_check"]["device_relative_residual"] - 1) < 1e-6
+    print(f"two ranks: {t_two:.0f} s wall, host setup of the configs[3] hierarchy {w['host_setup_s']} s")
+    # the same problem at one rank
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--grid-m", "323", "--hbm-m", "0", "--no-cpu-baseline", "--steps", "10", "--warmup", "2"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-3000:]
+    o = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][-1])["vcycle"]
+    assert o["rows"] == w["rows"] and o["nnz"] == w["nnz"], "the row-distributed hierarchy must be the one-rank hierarchy"
+    h1, h2 = o["residual_history"], w["residual_history"]
+    assert len(h1) == len(h2) == 10
+    for a, b in zip(h1, h2):
+        assert abs(a - b) <= 1e-10 * h1[0], (h1, h2)
