@@ -115,6 +115,9 @@ void  saena_amg_free(saena_amg_h *S);
 /* saena::amg::set_matrix (saena.hpp:202): smoothed-aggregation setup on the host */
 int   saena_amg_set_matrix(saena_amg_h *S, saena_matrix_h *A, const saena_options_c *opts);
 int   saena_amg_num_levels(saena_amg_h *S);                               /* max_level + 1 */
+/* coarse id of every fine row of `level` (the reference's `aggregate` after aggregate_index_update, src/saena_object_setup1.cpp:
+ * 2103-2260); one-rank setups keep it, for the pins of the setup (tests/test_sa_pins.py).  out: rows of that level */
+int saena_amg_level_aggregates(saena_amg_h *, int level, index_t *out, index_t *n_aggregates);
 int   saena_amg_level_info(saena_amg_h *S, int level, index_t *rows, nnz_t *nnzA, nnz_t *nnzP, double *eig_max);
 int   saena_amg_level_split(saena_amg_h *S, int level, index_t *split_out /* nranks+1 */);   /* row partition of a level */
 /* which: 0 = A_l, 1 = P_l, 2 = R_l (this rank's share when the communicator has more than one rank) */

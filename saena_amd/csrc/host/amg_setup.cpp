@@ -588,6 +588,7 @@ int amg_hierarchy::coarsen(int l) {
         }
     }
     pt.lap("smoothed P");
+    g.agg = std::move(agg);
     // ---- R = P^T (restrict_matrix::transposeP) ----
     Csr Rc = transpose(Pc);
     pt.lap("R = P^T");

@@ -49,6 +49,8 @@ struct amg_level {
     transfer_matrix P, R;                        // empty on the coarsest level
     std::unique_ptr<saena_matrix> Ac_store;      // A of level l+1
     std::vector<index_t> roots;                  // fine index of the root of every aggregate, ascending (= coarse numbering)
+    std::vector<index_t> agg;                    // coarse id of every fine row (one-rank setup; the reference's `aggregate` after
+                                                 // aggregate_index_update, setup1:2103-2260): kept for the setup's pins
 };
 
 // One rank's share of a hierarchy that was built at one rank and then row-partitioned.

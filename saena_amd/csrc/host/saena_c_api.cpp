@@ -247,6 +247,16 @@ int saena_amg_level_split(saena_amg_h *S, int l, index_t *split_out) {
     });
 }
 
+int saena_amg_level_aggregates(saena_amg_h *S, int level, index_t *out, index_t *n_aggregates) {
+    return guard([&] {
+        if (!S->set) throw std::runtime_error("set_matrix has not been called");
+        if (!S->H.dist.empty()) throw std::runtime_error("aggregates are kept by the one-rank setup only");
+        if (level < 0 || level >= S->H.max_level) throw std::runtime_error("no aggregation on this level");
+        const auto &g = S->H.levels[(size_t)level];
+        if (out) std::copy(g.agg.begin(), g.agg.end(), out);
+        if (n_aggregates) *n_aggregates = (index_t)g.roots.size();
+    });
+}
 int saena_amg_level_info(saena_amg_h *S, int l, index_t *rows, nnz_t *nnzA, nnz_t *nnzP, double *eig) {
     return guard([&] {
         if (!S->set || l < 0 || l > S->H.max_level) throw std::runtime_error("bad level");

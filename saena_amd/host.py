@@ -82,6 +82,7 @@ HOST_SYMBOLS.update({
     "saena_amg_set_matrix": (C.c_int, [_VP, _VP, C.POINTER(OptionsC)]),
     "saena_amg_num_levels": (C.c_int, [_VP]),
     "saena_amg_level_info": (C.c_int, [_VP, C.c_int, _PI, C.POINTER(C.c_long), C.POINTER(C.c_long), _PD]),
+    "saena_amg_level_aggregates": (C.c_int, [_VP, C.c_int, _PI, _PI]),
     "saena_amg_level_desc": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(OpDesc)]),
     "saena_amg_level_split": (C.c_int, [_VP, C.c_int, _PI]),
     "saena_amg_to_device": (C.c_int, [_VP]),
@@ -407,6 +408,13 @@ class AmgSolver:
     @property
     def num_levels(self):
         return self.L.saena_amg_num_levels(self.h)
+
+    def level_aggregates(self, l):
+        """coarse id of every fine row of level l (one-rank setups), and the number of aggregates"""
+        rows = self.level_info(l)["rows"]
+        out, n = np.zeros(rows, np.int32), C.c_int()
+        _check(self.L, self.L.saena_amg_level_aggregates(self.h, l, out.ctypes.data_as(_PI), C.byref(n)))
+        return out, n.value
 
     def level_info(self, l):
         rows, na, npp, eig = C.c_int(), C.c_long(), C.c_long(), C.c_double()
