@@ -37,6 +37,9 @@ saena_comm *saena_comm_rccl(void);            /* [GPU] the sgpu_init() communica
  * collective over the job's ranks, `name` fresh for every job (no '/'); NULL + saena_last_error() on failure */
 saena_comm *saena_comm_shm(const char *name, int rank, int nranks);
 void        saena_comm_free(saena_comm *);
+/* the exchange chain of a multi-rank apply that the agglomeration of coarse levels starts from, microseconds: measured by the
+ * GPU runtime on the job's communicator at sgpu_init (0: nothing measured, the model's constant applies) */
+double      saena_measured_chain_us(void);
 /* the communicator's collectives, exported for its tests (counts and displacements in bytes, one per rank) */
 int saena_comm_test_alltoallv(saena_comm *, const void *send, const size_t *scounts, const size_t *sdispls, void *recv,
                               const size_t *rcounts, const size_t *rdispls);

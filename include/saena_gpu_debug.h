@@ -45,6 +45,10 @@ int sgpu_debug_init_host_transport(int device_id, int rank, int nranks, sgpu_hos
  * the launcher as a failure.  SIGTERM is not trapped.  NULL restores the default handlers.  `line` is copied. */
 int sgpu_debug_on_fatal_print(const char *line);
 
+/* the exchange chain sgpu_init measured on the communicator (pack -> grouped send/recv with the neighbouring rank -> a kernel
+ * on the received data; microseconds, the maximum over the ranks); 0 without a communicator.  The agglomeration of coarse
+ * levels and the one- / two-stream thresholds of a multi-rank apply start from it. */
+int sgpu_debug_chain_us(double *us);
 /* number of kernel launches + graph launches + RCCL group calls the library has enqueued since sgpu_init
  * (tests: "fewer launches per V-cycle"); counts host-side enqueues, not GPU work */
 int sgpu_debug_launch_count(long *launches);

@@ -93,6 +93,7 @@ SYMBOLS = {
     "sgpu_coarsest_solve": (C.c_int, [_VP, _VP, _VP, _PI]),
     "sgpu_debug_on_fatal_print": (C.c_int, [C.c_char_p]),
     "sgpu_debug_launch_count": (C.c_int, [C.POINTER(C.c_long)]),
+    "sgpu_debug_chain_us": (C.c_int, [C.POINTER(C.c_double)]),
     "sgpu_debug_device_info": (C.c_int, [C.c_char_p, C.c_int]),
     "sgpu_debug_allow_local_only": (C.c_int, [_VP, C.c_int]),
     "sgpu_debug_init_host_transport": (C.c_int, [C.c_int, C.c_int, C.c_int, _VP, _VP, _VP]),
@@ -467,6 +468,13 @@ def device_info():
         if vals:
             line += f", {key.replace('current_', '')} {'/'.join(sorted(vals))}"
     return line
+
+
+def chain_us():
+    """the exchange chain sgpu_init measured on the communicator, microseconds (0 without one)"""
+    v = C.c_double()
+    check(lib().sgpu_debug_chain_us(C.byref(v)))
+    return v.value
 
 
 def launch_count():

@@ -120,6 +120,7 @@ Csr transpose(const Csr &A) {
 } // namespace
 // C = A B on the GPU when libsaena_amd.so has a device context (sgpu_spgemm.hip installs this; bit-identical result)
 spgemm_hook_fn g_spgemm_hook = nullptr;
+double g_measured_chain_us = 0.0;
 namespace {
 
 // the left operand as three arrays: the distributed setup multiplies R and R A with their columns re-labelled to positions
@@ -712,7 +713,7 @@ void amg_hierarchy::distribute(Comm &c, const std::vector<index_t> &split0) {
 
 // ---- agglomeration policy (see amg_setup.h) ----
 int amg_hierarchy::next_stride(long nnzC, index_t rowsC, int np, int stride_prev) const {
-    double chain = shrink_chain_us;
+    double chain = g_measured_chain_us > 0.0 ? g_measured_chain_us : shrink_chain_us;
     index_t rows_rule = shrink_rows;
     if (const char *e = std::getenv("SAENA_SHRINK_CHAIN_US")) chain = std::atof(e);
     if (const char *e = std::getenv("SAENA_SHRINK_ROWS")) rows_rule = (index_t)std::atol(e);

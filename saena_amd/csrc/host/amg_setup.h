@@ -20,6 +20,11 @@ typedef int (*spgemm_hook_fn)(int a_rows, int b_rows, int b_cols, const long *a_
                               const long *b_ptr, const int *b_col, const double *b_val, int row_offset,
                               std::vector<long> &c_ptr, std::vector<int> &c_col, std::vector<double> &c_val);
 extern spgemm_hook_fn g_spgemm_hook;
+// The exchange chain of one multi-rank apply in microseconds (pack -> RCCL send/recv -> boundary rows), as the GPU runtime
+// MEASURED it on this job's communicator at sgpu_init (a ping-pong with the neighbouring rank; the maximum over the
+// ranks, so every rank holds the same number); 0: not measured (host-only library, one rank).  The agglomeration model
+// below starts from it instead of the constant; SAENA_SHRINK_CHAIN_US still overrides.
+extern double g_measured_chain_us;
 
 // saena::options (reference include/saena.hpp:127-193; defaults :151-155)
 struct amg_options {
@@ -90,8 +95,9 @@ public:
     // matvec per level and shrinks by a factor 2..4 when communication exceeds twice the computation, and puts the
     // coarsest level on one rank.  Here the two times are a model with measured constants: one GPU applies the level in
     // T1 = 12 B x nnz / shrink_bw + shrink_launch_us, a multi-rank apply costs at least the exchange chain
-    // shrink_chain_us (pack -> RCCL send/recv -> boundary rows: 23 us, profiles/r01_halo_loopback.md and
-    // profiles/r02_halo_loopback_modes.log).  Rules, evaluated after the coarse operator exists (its nnz is known):
+    // shrink_chain_us (pack -> RCCL send/recv -> boundary rows: measured at sgpu_init on the job's communicator,
+    // g_measured_chain_us; 23 us on one GPU with RCCL self send/recv, profiles/r01_halo_loopback.md and
+    // profiles/r02_halo_loopback_modes.log, is the fall-back when nothing was measured).  Rules, evaluated after the coarse operator exists (its nnz is known):
     //   T1 <= chain                      -> the whole level lives on rank 0 (no exchange at all below this level);
     //   chain > 2 x T1 / active ranks    -> merge groups of f = clamp(floor(chain / compute / 5), 2, 4) consecutive active
     //                                       ranks onto the first of each group (shrink_set_params' rule: ranks k f own rows);

@@ -91,6 +91,7 @@ saena_comm *saena_comm_shm(const char *name, int rank, int nranks) {
 }
 
 void saena_comm_free(saena_comm *c) { delete c; }
+double saena_measured_chain_us(void) { return g_measured_chain_us; }
 // the collectives themselves, for tests of a communicator (byte counts and displacements as in Comm::alltoallv)
 int saena_comm_test_alltoallv(saena_comm *c, const void *send, const size_t *sc, const size_t *sd, void *recv, const size_t *rc, const size_t *rd) {
     return guard([&] { c->c->alltoallv(send, sc, sd, recv, rc, rd); });

@@ -9,6 +9,7 @@
 #include "../../include/saena_gpu_debug.h"
 #include "kernels.hip.h"
 #include "host/comm.h"
+#include "host/amg_setup.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -93,6 +94,7 @@ struct Ctx {
     void                  *xuser = nullptr;
     bool multi() const { return comm != nullptr || xchg != nullptr; }
     std::vector<char> peer_seen;   // RCCL connects a peer lazily at the first send/recv with it (bit 0 send, bit 1 recv): see apply()
+    double chain_us = 0.0;         // the exchange chain measured on this communicator at init (calibrate_chain), 0: not measured
 };
 Ctx g;
 
@@ -1233,6 +1235,52 @@ int sgpu_get_unique_id(void *out128) {
     return SGPU_OK;
 }
 
+// The exchange chain of a multi-rank apply, measured on THIS communicator: pack kernel -> one grouped ncclSend/ncclRecv of a
+// halo-sized message (32 KiB) with the neighbouring rank (rank ^ 1; the last rank of an odd job and a one-rank
+// communicator exchange with themselves) -> a small kernel on the received data, on the compute stream, 20 times after 5
+// warm-up rounds (the first connects the peers), timed with events.  Every rank takes the maximum over the ranks, so the
+// agglomeration decisions that start from it (host/amg_setup.h: next_stride) are the same everywhere.  The reference
+// times a dummy matvec per level for the same decision (saena_matrix::decide_shrinking, src/saena_matrix_shrink.cpp:3-118).
+static int calibrate_chain() {
+    const int n = 4096;                                  // doubles: about one face of a 64^3 block
+    double *a = nullptr, *b = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&a), n * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&b), n * sizeof(double)));
+    struct Free { double *a, *b; hipEvent_t e0 = nullptr, e1 = nullptr; ~Free() { hipFree(a); hipFree(b); if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); } } fr{a, b};
+    HIPCHK(hipMemsetAsync(a, 0, n * sizeof(double), g.cs));
+    HIPCHK(hipEventCreate(&fr.e0)); HIPCHK(hipEventCreate(&fr.e1));
+    int peer = g.rank ^ 1;
+    if (peer >= g.nranks) peer = g.rank;
+    auto round = [&]() -> int {
+        SGPU_LAUNCH(sk::k_axpby, dim3((n + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs, 1.0, (const double *)a, 0.0, b, (size_t)n);      // "pack"
+        NCCLCHK(ncclGroupStart());
+        NCCLCHK(ncclSend(b, n, ncclDouble, peer, g.comm, g.cs));
+        NCCLCHK(ncclRecv(a, n, ncclDouble, peer, g.comm, g.cs));
+        NCCLCHK(ncclGroupEnd());
+        SGPU_LAUNCH(sk::k_axpby, dim3((n + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs, 1.0, (const double *)a, 0.0, b, (size_t)n);      // "boundary rows"
+        return SGPU_OK;
+    };
+    for (int i = 0; i < 5; ++i) CHK(round());
+    HIPCHK(hipStreamSynchronize(g.cs));
+    const int reps = 20;
+    HIPCHK(hipEventRecord(fr.e0, g.cs));
+    for (int i = 0; i < reps; ++i) CHK(round());
+    HIPCHK(hipEventRecord(fr.e1, g.cs));
+    HIPCHK(hipEventSynchronize(fr.e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, fr.e0, fr.e1));
+    double us = (double)ms * 1e3 / reps;
+    // the same number on every rank: the maximum
+    HIPCHK(hipMemcpyAsync(g.dscalar, &us, sizeof(double), hipMemcpyHostToDevice, g.cs));
+    NCCLCHK(ncclAllReduce(g.dscalar, g.dscalar, 1, ncclDouble, ncclMax, g.comm, g.cs));
+    HIPCHK(hipMemcpyAsync(&us, g.dscalar, sizeof(double), hipMemcpyDeviceToHost, g.cs));
+    HIPCHK(hipStreamSynchronize(g.cs));
+    g.chain_us = us;
+    saena_host::g_measured_chain_us = us;
+    if (std::getenv("SAENA_SETUP_TIMING") && g.rank == 0) fprintf(stderr, "[sgpu] exchange chain on this communicator: %.1f us (pack -> send/recv of %d doubles with rank %d -> rows)\n", us, n, peer);
+    return SGPU_OK;
+}
+
 int sgpu_init(int device_id, int rank, int nranks, const void *uid) {
     if (g.live) return fail(SGPU_ERR_STATE, "sgpu_init called twice");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SGPU_ERR_ARG, "bad rank %d of %d", rank, nranks);
@@ -1286,6 +1334,10 @@ int sgpu_init(int device_id, int rank, int nranks, const void *uid) {
     }
     g.live = true;
     sgpu_install_spgemm_hook(1);         // the AMG setup's Galerkin products run on this device from now on (sgpu_spgemm.hip)
+    if (g.comm && !std::getenv("SAENA_NO_CHAIN_CALIBRATION")) {
+        const int s = calibrate_chain();
+        if (s != SGPU_OK) { g.live = false; return s; }
+    }
     return SGPU_OK;
 }
 
@@ -1311,6 +1363,7 @@ int sgpu_finalize(void) {
     if (g.kflag_x) hipFree(g.kflag_x);
     hipStreamDestroy(g.cs); hipStreamDestroy(g.hs);
     g = Ctx();
+    saena_host::g_measured_chain_us = 0.0;
     return SGPU_OK;
 }
 
@@ -1506,10 +1559,13 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         // way, but the two-stream form takes 23-25 us of HOST time to enqueue against 15 us for the one-stream form, so
         // applies whose local kernel runs under ~5 us (< 1 M nnz) are host-bound on two streams (28 vs 25 us drained);
         // from ~10 us of local work on, the overlap wins (32 planes: 27 vs 31 us).
-        long thr = 1000 * 1000;
+        // both thresholds were measured with a 23 us chain (RCCL self send/recv on one GPU); they scale with the chain this
+        // job's communicator showed at init (calibrate_chain): a slower exchange moves both crossovers up
+        const double scale = g.chain_us > 0.0 ? std::min(8.0, std::max(0.5, g.chain_us / 23.0)) : 1.0;
+        long thr = (long)(1000.0 * 1000.0 * scale);
         if (const char *e = std::getenv("SAENA_SINGLE_STREAM_NNZ")) thr = std::atol(e);
         op->single_stream = (long)d->nnz_l_local < thr;
-        long ev = 30L * 1000 * 1000;       // 12 B x 30 M nnz / 5 TB/s = 72 us of interior work: the event-ordered chain (~48 us) hides behind it
+        long ev = (long)(30.0 * 1000 * 1000 * scale);   // 12 B x 30 M nnz / 5 TB/s = 72 us of interior work: the event-ordered chain (~48 us) hides behind it
         if (const char *e2 = std::getenv("SAENA_EVENT_SYNC_NNZ")) ev = std::atol(e2);
         op->events_only = (long)d->nnz_l_local >= ev;
     }
@@ -2516,6 +2572,13 @@ int sgpu_debug_device_info(char *buf, int len) {
     HIPCHK(hipGetDeviceProperties(&p, g.device));
     snprintf(buf, (size_t)len, "%s (%s), %d CUs, %d MHz core, %d MHz memory x %d bit, L2 %d KiB, %.1f GiB", p.name, p.gcnArchName, p.multiProcessorCount,
              p.clockRate / 1000, p.memoryClockRate / 1000, p.memoryBusWidth, p.l2CacheSize / 1024, (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    return SGPU_OK;
+}
+
+int sgpu_debug_chain_us(double *us) {
+    CHK(need_ctx());
+    if (!us) return fail(SGPU_ERR_ARG, "null argument");
+    *us = g.chain_us;
     return SGPU_OK;
 }
 

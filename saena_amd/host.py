@@ -28,6 +28,7 @@ HOST_SYMBOLS = {
     "saena_comm_callbacks": (_VP, [C.c_int, C.c_int, _VP, CB_ALLGATHER, CB_ALLTOALLV, CB_I64, CB_F64]),
     "saena_comm_rccl": (_VP, []),
     "saena_comm_shm": (_VP, [C.c_char_p, C.c_int, C.c_int]),
+    "saena_measured_chain_us": (C.c_double, []),
     "saena_comm_test_alltoallv": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "saena_comm_test_allreduce_f64": (C.c_int, [_VP, _VP, C.c_int]),
     "saena_comm_test_allreduce_i64": (C.c_int, [_VP, _VP, C.c_int]),

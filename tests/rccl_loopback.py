@@ -24,6 +24,12 @@ def main():
     capi.init(0, 0, 1, capi.get_unique_id())
     lib = capi.lib()
     capi.check(lib.sgpu_barrier())
+    # the exchange chain was measured on this communicator at init (here: self send/recv) and is what the agglomeration
+    # model and the one- / two-stream thresholds start from, in place of the constant of rounds 1-2
+    chain = capi.chain_us()
+    assert 2.0 < chain < 500.0, chain
+    assert host.load("gpu").saena_measured_chain_us() == chain
+    print(f"exchange chain measured at init: {chain:.1f} us", flush=True)
     n = 10007
     x = inputs.v2(n)
     dx = capi.DeviceVector(n, x)
