@@ -239,7 +239,8 @@ def pmc_traffic(m, world, kernel_name):
     """Memory-side bytes per launch from the COMMITTED rocprofv3 PMC passes of this same command (PMC counters cannot
     be read from inside the process, so this is never a measurement of the present run: the line says so with
     `traffic_measured_in_run: false`).  Only for the kernel those passes profiled; None for anything else."""
-    table = {"k_sell": "r02_pmc_spmv_128_sell.json", "k_csr_cc16<16KiB,4+12>": "r02_pmc_spmv_128_cc16.json", "k_csr_stream<16KiB>": "r01_pmc_spmv_128.json"}
+    table = {"k_sellp": "r03_pmc_spmv_128_sellp.json", "k_sell": "r02_pmc_spmv_128_sell.json", "k_csr_cc16<16KiB,4+12>": "r02_pmc_spmv_128_cc16.json",
+             "k_csr_stream<16KiB>": "r01_pmc_spmv_128.json"}
     name = table.get(kernel_name)
     path = os.path.join(ROOT, "profiles", name) if name else None
     if m == 128 and world == 1 and path and os.path.exists(path):
@@ -507,10 +508,11 @@ def main():
             "frac": round(a3 / HBM_PEAK_GBS, 4), "check_max_rel_err": e3,
         }
         # bytes leaving the L2 per launch from the COMMITTED PMC passes of this leg (tools/pmc_spmv_hbm.sh), same kernel only
-        pmc3 = os.path.join(ROOT, "profiles", "r02_pmc_spmv_256_cc16.json")
-        if args.m_hbm == 256 and "k_csr_cc16" in R3["kernel_name"] and os.path.exists(pmc3):
+        pmc_name = {"k_sellp": "r03_pmc_spmv_256_sellp.json"}.get(R3["kernel_name"], "r02_pmc_spmv_256_cc16.json" if "k_csr_cc16" in R3["kernel_name"] else None)
+        pmc3 = os.path.join(ROOT, "profiles", pmc_name) if pmc_name else None
+        if args.m_hbm == 256 and pmc3 and os.path.exists(pmc3):
             with open(pmc3) as f:
-                out["spmv_hbm_resident"].update(traffic=json.load(f)["traffic_bytes_per_launch"], traffic_source="profiles/r02_pmc_spmv_256_cc16.json",
+                out["spmv_hbm_resident"].update(traffic=json.load(f)["traffic_bytes_per_launch"], traffic_source="profiles/" + pmc_name,
                                                 traffic_measured_in_run=False)
         R3["op"].destroy()
         for k in ("x", "y"):

@@ -72,6 +72,7 @@ struct SpmvArgs {
     // dst holds the pattern id of every row
     const int            *ptab;
     int                   pt_w, pt_n;
+    int                   nt;        // non-temporal stream loads (k_csr_stream / cc16 / cm / wave / xlds): see ld_stream_*
     // in-kernel fork to the halo stream (multi-rank interior launch only, else nullptr): block 0 stores
     // *flag_x = seq when it starts -- stream order: everything earlier on the compute stream is complete, so
     // the halo stream's pack, which polls the flag, may read x.
@@ -149,32 +150,21 @@ __device__ __forceinline__ void epilogue(const SpmvArgs &a, int r, double s) {
 typedef double   sk_d2v __attribute__((ext_vector_type(2)));
 typedef int      sk_i4v __attribute__((ext_vector_type(4)));
 typedef unsigned sk_u2v __attribute__((ext_vector_type(2)));
-#ifndef SAENA_STREAM_NT
-#define SAENA_STREAM_NT 0
-#endif
-__device__ __forceinline__ double2 ld_stream_d2(const double *p) {
-#if SAENA_STREAM_NT
-    const sk_d2v v = __builtin_nontemporal_load(reinterpret_cast<const sk_d2v *>(p));
+// `nt` is a launch argument (SpmvArgs::nt), uniform over the grid: a non-temporal load where the launch asks for it
+__device__ __forceinline__ double2 ld_stream_d2(const double *p, int nt) {
+    sk_d2v v;
+    if (nt) v = __builtin_nontemporal_load(reinterpret_cast<const sk_d2v *>(p)); else v = *reinterpret_cast<const sk_d2v *>(p);
     double2 r; r.x = v.x; r.y = v.y; return r;
-#else
-    return *reinterpret_cast<const double2 *>(p);
-#endif
 }
-__device__ __forceinline__ int4 ld_stream_i4(const int *p) {
-#if SAENA_STREAM_NT
-    const sk_i4v v = __builtin_nontemporal_load(reinterpret_cast<const sk_i4v *>(p));
+__device__ __forceinline__ int4 ld_stream_i4(const int *p, int nt) {
+    sk_i4v v;
+    if (nt) v = __builtin_nontemporal_load(reinterpret_cast<const sk_i4v *>(p)); else v = *reinterpret_cast<const sk_i4v *>(p);
     int4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
-#else
-    return *reinterpret_cast<const int4 *>(p);
-#endif
 }
-__device__ __forceinline__ uint2 ld_stream_u2(const unsigned short *p) {
-#if SAENA_STREAM_NT
-    const sk_u2v v = __builtin_nontemporal_load(reinterpret_cast<const sk_u2v *>(p));
+__device__ __forceinline__ uint2 ld_stream_u2(const unsigned short *p, int nt) {
+    sk_u2v v;
+    if (nt) v = __builtin_nontemporal_load(reinterpret_cast<const sk_u2v *>(p)); else v = *reinterpret_cast<const sk_u2v *>(p);
     uint2 r; r.x = v.x; r.y = v.y; return r;
-#else
-    return *reinterpret_cast<const uint2 *>(p);
-#endif
 }
 
 // contiguous chunk of the grid per XCD (blocks b, b+8, ... share an XCD)
@@ -245,9 +235,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
             const int q = tid + it * BLOCK;
             if (q < nq) {
                 const int idx = a0 + 4 * q;
-                const double2 v01 = ld_stream_d2(a.val + idx);
-                const double2 v23 = ld_stream_d2(a.val + idx + 2);
-                const int4    c   = ld_stream_i4(a.col + idx);
+                const double2 v01 = ld_stream_d2(a.val + idx, a.nt);
+                const double2 v23 = ld_stream_d2(a.val + idx + 2, a.nt);
+                const int4    c   = ld_stream_i4(a.col + idx, a.nt);
                 double2 o01, o23;
                 o01.x = v01.x * a.x[c.x];
                 o01.y = v01.y * a.x[c.y];
@@ -269,9 +259,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_stream(const SpmvArgs a) {
             int q = tid + it * BLOCK;
             q = q < qlast ? q : qlast;
             const int idx = a0 + 4 * q;
-            v01[it] = ld_stream_d2(a.val + idx);
-            v23[it] = ld_stream_d2(a.val + idx + 2);
-            c[it]   = ld_stream_i4(a.col + idx);
+            v01[it] = ld_stream_d2(a.val + idx, a.nt);
+            v23[it] = ld_stream_d2(a.val + idx + 2, a.nt);
+            c[it]   = ld_stream_i4(a.col + idx, a.nt);
         }
         double2 o01[ITER], o23[ITER];
 #pragma unroll
@@ -368,9 +358,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
             const int q = tid + it * BLOCK;
             if (q < nq) {
                 const int idx = a0 + 4 * q;
-                const double2 v01 = ld_stream_d2(a.val + idx);
-                const double2 v23 = ld_stream_d2(a.val + idx + 2);
-                const uint2   c   = ld_stream_u2(a.ccol + idx);
+                const double2 v01 = ld_stream_d2(a.val + idx, a.nt);
+                const double2 v23 = ld_stream_d2(a.val + idx + 2, a.nt);
+                const uint2   c   = ld_stream_u2(a.ccol + idx, a.nt);
                 const unsigned c0 = c.x & 0xffffu, c1 = c.x >> 16, c2 = c.y & 0xffffu, c3 = c.y >> 16;
                 int j0 = seg[c0 >> ob] + (int)(c0 & om), j1 = seg[c1 >> ob] + (int)(c1 & om);
                 int j2 = seg[c2 >> ob] + (int)(c2 & om), j3 = seg[c3 >> ob] + (int)(c3 & om);
@@ -398,9 +388,9 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cc16(const SpmvArgs a) {
             int q = tid + it * BLOCK;
             q = q < qlast ? q : qlast;
             const int idx = a0 + 4 * q;
-            v01[it] = ld_stream_d2(a.val + idx);
-            v23[it] = ld_stream_d2(a.val + idx + 2);
-            c[it]   = ld_stream_u2(a.ccol + idx);
+            v01[it] = ld_stream_d2(a.val + idx, a.nt);
+            v23[it] = ld_stream_d2(a.val + idx + 2, a.nt);
+            c[it]   = ld_stream_u2(a.ccol + idx, a.nt);
         }
         double2 o01[ITER], o23[ITER];
 #pragma unroll
@@ -487,10 +477,10 @@ __global__ __launch_bounds__(BLOCK) void k_csr_cm(const SpmvArgs a) {
         int q = tid + it * BLOCK;
         q = q < qlast ? q : qlast;
         const int idx = c0 + 4 * q;
-        v01[it] = ld_stream_d2(a.val + idx);
-        v23[it] = ld_stream_d2(a.val + idx + 2);
-        c[it]   = ld_stream_u2(a.ccol + idx);
-        d[it]   = ld_stream_u2(a.dst + idx);
+        v01[it] = ld_stream_d2(a.val + idx, a.nt);
+        v23[it] = ld_stream_d2(a.val + idx + 2, a.nt);
+        c[it]   = ld_stream_u2(a.ccol + idx, a.nt);
+        d[it]   = ld_stream_u2(a.dst + idx, a.nt);
     }
     double2 o01[ITER], o23[ITER];
 #pragma unroll
@@ -766,12 +756,12 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wave(const SpmvArgs a, int nrows)
             const int i0 = a0 + 4 * q;
             const bool two = q + G < nq;
             const int i1 = two ? i0 + 4 * G : i0;               // (a lane without a second quad re-reads its first)
-            double2 v01 = ld_stream_d2(a.val + i0);
-            double2 v23 = ld_stream_d2(a.val + i0 + 2);
-            const int4 c = ld_stream_i4(a.col + i0);
-            double2 w01 = ld_stream_d2(a.val + i1);
-            double2 w23 = ld_stream_d2(a.val + i1 + 2);
-            const int4 d = ld_stream_i4(a.col + i1);
+            double2 v01 = ld_stream_d2(a.val + i0, a.nt);
+            double2 v23 = ld_stream_d2(a.val + i0 + 2, a.nt);
+            const int4 c = ld_stream_i4(a.col + i0, a.nt);
+            double2 w01 = ld_stream_d2(a.val + i1, a.nt);
+            double2 w23 = ld_stream_d2(a.val + i1 + 2, a.nt);
+            const int4 d = ld_stream_i4(a.col + i1, a.nt);
             double x0 = a.x[c.x], x1 = a.x[c.y], x2 = a.x[c.z], x3 = a.x[c.w];
             double y0 = a.x[d.x], y1 = a.x[d.y], y2 = a.x[d.z], y3 = a.x[d.w];
             // entries of the neighbouring rows in the first / last quad, and the re-read quad of a lane without a second one:
@@ -854,9 +844,9 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
                     v01[u].x = v01[u].y = v23[u].x = v23[u].y = 0.0;
                     c[u].x = c[u].y = 0u;
                     if (q + G * u < nq) {
-                        v01[u] = ld_stream_d2(a.val + i[u]);
-                        v23[u] = ld_stream_d2(a.val + i[u] + 2);
-                        c[u]   = ld_stream_u2(a.ccol + i[u]);
+                        v01[u] = ld_stream_d2(a.val + i[u], a.nt);
+                        v23[u] = ld_stream_d2(a.val + i[u] + 2, a.nt);
+                        c[u]   = ld_stream_u2(a.ccol + i[u], a.nt);
                     }
                 }
 #pragma unroll

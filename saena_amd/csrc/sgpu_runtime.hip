@@ -808,6 +808,8 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12; a.dst = nullptr; a.cmptr = nullptr;
     a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0;
+    static const int nt_rt = std::getenv("SAENA_STREAM_NT") ? std::atoi(std::getenv("SAENA_STREAM_NT")) : 0;
+    a.nt = nt_rt == 1 || (nt_rt == 2 && 12 * P.nnz > (int64_t)256 * 1024 * 1024) ? 1 : 0;
     const bool halo = skip != nullptr || seq != 0;
     if (P.variant == 5) {                                         // dense rows, one wave per row
         if (!P.dense) return fail(SGPU_ERR_STATE, "the dense form was not built");

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the fine-level SpMV kernel from rocprofv3 PMC counters (run on the GPU box from the repo root):
-#   bash tools/pmc_spmv.sh <variant> <out.json>      variant: 9 = k_sell, 3 = k_csr_cc16<16KiB>, 0 = k_csr_stream<16KiB>
+#   bash tools/pmc_spmv.sh <variant> <out.json>      variant: 11 = k_sellp, 9 = k_sell, 3 = k_csr_cc16<16KiB>, 0 = k_csr_stream<16KiB>
 # One pass per counter, kernel pinned (PMC collection perturbs the autotune's timings), no trace domains
 # next to --pmc.  tools/pmc_summarise.py applies the gfx950 FETCH_SIZE correction (MI355X_MICROARCH.md).
 set -e

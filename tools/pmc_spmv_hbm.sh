@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM-side traffic of the HBM-resident SpMV (Poisson 256^3, the bench line's `spmv_hbm_resident`) from rocprofv3 PMC counters:
-#   bash tools/pmc_spmv_hbm.sh <variant: 3 k_csr_cc16, 9 k_sell> <out.json>
+#   bash tools/pmc_spmv_hbm.sh <variant: 3 k_csr_cc16, 9 k_sell, 11 k_sellp> <out.json>
 # One pass per counter, kernel pinned, no trace domains next to --pmc; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md).
 V=${1:-3}; OUT=${2:-gpurun_out/pmc_spmv_hbm.json}
 D=gpurun_out/pmc_hbm_v$V; rm -rf $D; mkdir -p $D
@@ -18,7 +18,7 @@ d, v = sys.argv[1], int(sys.argv[2])
 rows = []
 for f in sorted(glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True)):
     rows += list(csv.DictReader(open(f)))
-want = {3: "k_csr_cc16<0,", 9: "k_sell<0,"}[v]
+want = {3: "k_csr_cc16<0,", 9: "k_sell<0,", 11: "k_sellp<0,"}[v]
 g = defaultdict(lambda: defaultdict(list))
 for r in rows:
     name = r["Kernel_Name"].replace(", ", ",")
@@ -31,7 +31,9 @@ mean = {k: sum(x) / len(x) for k, x in c.items()}
 fetch = 2.0 * mean["FETCH_SIZE"] * 1024.0
 write = mean["WRITE_SIZE"] * 1024.0
 rd, rd32 = mean["TCC_EA0_RDREQ_sum"], mean["TCC_EA0_RDREQ_32B_sum"]
-alg, stored = 1699609508, 1470964804
+nnz, M = 114322352, 16387064
+alg = 12 * nnz + 4 * (M + 1) + 16 * M
+stored = {3: 10 * nnz + 4 * (M + 1) + 16 * M, 9: 10 * nnz + 2 * M + 16 * M, 11: 8 * nnz + 2 * M + 16 * M}[v]      # values + column form + x + y
 print(json.dumps({"workload": "Poisson 256^3 SpMV (16387064 rows, 114322352 nnz), 1 MI355X", "kernel_filter": want, "workgroups": wg,
                   "launches": {k: len(x) for k, x in c.items()}, "fetch_bytes_corrected": fetch, "write_bytes": write,
                   "cross_check_rdreq_bytes": (rd - rd32) * 128 + rd32 * 32,
