@@ -14,8 +14,9 @@
 //   medium (ub <= 2048)  one workgroup per row, 4096-slot hash table in LDS;
 //   heavy                first the same LDS table, abandoned when more than 3072 distinct columns turn up (a row of R A
 //                        on the second level has 13 700 products and 760 entries); the rows that overflow go to
-//                        persistent workgroups with a dense accumulator of their own in HBM (the coarse levels' rows
-//                        reach 10^5-10^6 products; an MI355X has the memory: 12 B x columns per workgroup).
+//                        persistent workgroups with a dense accumulator: in LDS, one window of 20 224 columns after the
+//                        other (round 3, k_spgemm_lds: B of up to 16 windows = 323 K columns, which covers every coarse
+//                        level of the 256^3 / 512^3 hierarchies), else of their own in HBM (12 B x columns per workgroup).
 // Each row leaves its touched (column, value) pairs unsorted in a scratch segment; dropped entries (|v| <= 1e-14 off
 // the diagonal, saena_object_setup_matmat.cpp:2423,2442) get the key INT_MAX; one segmented radix sort per chunk of rows
 // orders every segment by column, and the kept prefix of each segment is copied out.
@@ -203,6 +204,81 @@ __global__ __launch_bounds__(256) void k_spgemm_heavy(Mats m, const int *__restr
     }
 }
 
+// ---- heavy rows, accumulator in LDS (round 3) ----
+// The HBM accumulator above pays an L2 round trip per product (agent-scope atomics: 20 G products/s on the chip, 3-6 s per
+// product on the densest levels of a 16 M-row hierarchy).  Here a 1024-thread workgroup per CU keeps the accumulator of ONE
+// window of LDS_COLS columns in its LDS (161 792 B, as k_csr_xlds does with x) and walks the row of A once per window: for
+// entry ka it takes the piece of B's row k that falls in the window -- [bw[k][w], bw[k][w+1]), a table made once per product
+// by k_window_starts -- and adds a * b into the slots of its columns; the columns of one row of B are distinct, so no two
+// lanes meet, and a barrier separates ka from ka + 1: every output entry adds its products in the order of A's row, the
+// host's order, bit for bit.  A slot that nothing touched holds a sentinel (a NaN bit pattern no sum produces from finite
+// data) instead of a separate mark: the window is scanned once at the end, touched slots emitted (dropped entries get the
+// key INT_MAX like everywhere) and reset.  A (ka, window) pair without entries costs no barrier.
+constexpr int LDS_COLS = 20224;
+constexpr int LDS_MAXW = 16;
+constexpr int LDS_BLOCK = 1024;
+constexpr unsigned long long LDS_SENTINEL = 0x7FF8A5A5C3C35A5AULL;
+__global__ __launch_bounds__(256) void k_window_starts(const long long *__restrict__ b_ptr, const int *__restrict__ b_col, int b_rows, int W,
+                                                       long long *__restrict__ bw) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)b_rows * (W + 1)) return;
+    const int k = (int)(t / (W + 1)), w = (int)(t % (W + 1));
+    long long lo = b_ptr[k], hi = b_ptr[k + 1];
+    const long long bound = (long long)w * LDS_COLS;       // first entry of row k with column >= bound (columns ascend in a row)
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (b_col[mid] < bound) lo = mid + 1; else hi = mid; }
+    bw[t] = lo;
+}
+__global__ __launch_bounds__(LDS_BLOCK) void k_spgemm_lds(Mats m, const int *__restrict__ rows, int nrows, int r0, const int *__restrict__ ubptr,
+                                                          int *__restrict__ tcol, double *__restrict__ tval, int *__restrict__ n_touched,
+                                                          int *__restrict__ n_kept, int row_offset, const long long *__restrict__ bw, int W, int b_cols) {
+    __shared__ double acc[LDS_COLS];
+    __shared__ int counter[2];
+    const int tid = threadIdx.x;
+    const double sentinel = __longlong_as_double((long long)LDS_SENTINEL);
+    for (int s = tid; s < LDS_COLS; s += LDS_BLOCK) acc[s] = sentinel;
+    for (int idx = blockIdx.x; idx < nrows; idx += gridDim.x) {
+        const int i = rows[idx], loc = i - r0;
+        const long long u0 = ubptr[loc];
+        if (tid < 2) counter[tid] = 0;
+        __syncthreads();
+        const long long a0 = m.a_ptr[i], a1 = m.a_ptr[i + 1];
+        for (int w = 0; w < W; ++w) {
+            const int base = w * LDS_COLS;
+            bool any = false;
+            for (long long ka = a0; ka < a1; ++ka) {
+                const int k = m.a_col[ka];
+                const long long s0 = bw[(long long)k * (W + 1) + w], s1 = bw[(long long)k * (W + 1) + w + 1];
+                if (s0 == s1) continue;                    // uniform over the workgroup: nothing written, no barrier needed
+                const double a = m.a_val[ka];
+                for (long long kb = s0 + tid; kb < s1; kb += LDS_BLOCK) {
+                    const int j = m.b_col[kb] - base;
+                    const double v = a * m.b_val[kb];
+                    const double old = acc[j];
+                    acc[j] = (__double_as_longlong(old) == (long long)LDS_SENTINEL ? 0.0 : old) + v;       // the host: acc = 0.0, then += a b
+                }
+                any = true;
+                __syncthreads();
+            }
+            if (!any) continue;
+            const int width = min(LDS_COLS, b_cols - base);
+            for (int sl = tid; sl < width; sl += LDS_BLOCK) {
+                const double v = acc[sl];
+                if (__double_as_longlong(v) == (long long)LDS_SENTINEL) continue;
+                acc[sl] = sentinel;
+                const int j = base + sl;
+                const bool drop = !(fabs(v) > ALMOST_ZERO || i + row_offset == j);
+                const int pos = atomicAdd(&counter[0], 1);
+                tcol[u0 + pos] = drop ? INT_MAX : j;
+                tval[u0 + pos] = v;
+                if (drop) atomicAdd(&counter[1], 1);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { n_touched[loc] = counter[0]; n_kept[loc] = counter[0] - counter[1]; }
+        __syncthreads();
+    }
+}
+
 // segment ends for the sort: begin + touched
 __global__ void k_seg_ends(const int *__restrict__ ubptr, const int *__restrict__ n_touched, int *__restrict__ ends, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,6 +371,13 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
     double *acc = nullptr;
     int *mark = nullptr;
     int heavy_grid = 0;
+    // heavy rows accumulate in LDS, a window of LDS_COLS columns at a time, when B has at most LDS_MAXW windows of columns
+    // (SAENA_SPGEMM_NO_LDS=1: the accumulator in HBM for every heavy row, as before round 3)
+    const int n_windows = (b_cols + LDS_COLS - 1) / LDS_COLS;
+    const bool use_lds = n_windows <= LDS_MAXW && !std::getenv("SAENA_SPGEMM_NO_LDS");
+    long long *d_bw = nullptr;
+    int lds_grid = 256;
+    { int dev = 0, ncu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) lds_grid = ncu; }
     struct Temp { void *p = nullptr; ~Temp() { if (p) hipFree(p); } } temp;      // the sort's scratch: freed on every return path
     void *&d_temp = temp.p;
     size_t temp_bytes = 0;
@@ -338,6 +421,18 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
             for (int i : heavy) if (h_kept[(size_t)(i - r0)] < 0) over.push_back(i);
             heavy.swap(over);
             if (!heavy.empty()) SP_CHK(hipMemcpy(d_rows + light.size() + medium.size(), heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice));
+        }
+        if (!heavy.empty() && use_lds) {
+            if (!d_bw) {                                                       // where each window starts in every row of B: once per product
+                d_bw = D.alloc<long long>((size_t)b_rows * (size_t)(n_windows + 1));
+                if (!d_bw) return 1;
+                const long long cells = (long long)b_rows * (n_windows + 1);
+                hipLaunchKernelGGL(k_window_starts, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, 0, (const long long *)dbp, (const int *)dbc, b_rows, n_windows, d_bw);
+            }
+            hipLaunchKernelGGL(k_spgemm_lds, dim3((unsigned)std::min<size_t>((size_t)lds_grid, heavy.size())), dim3(LDS_BLOCK), 0, 0, m,
+                               (const int *)(d_rows + light.size() + medium.size()), (int)heavy.size(), r0, (const int *)d_ubptr, tcol, tval,
+                               d_touched, d_kept, row_offset, (const long long *)d_bw, n_windows, b_cols);
+            heavy.clear();
         }
         if (!heavy.empty()) {
             if (!acc) {

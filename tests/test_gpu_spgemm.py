@@ -39,10 +39,12 @@ print("RESULT " + json.dumps(out))
 """
 
 
-def _run(m, host_spgemm):
+def _run(m, host_spgemm, hbm_accumulator=False):
     env = dict(os.environ)
     if host_spgemm:
         env["SAENA_HOST_SPGEMM"] = "1"
+    if hbm_accumulator:
+        env["SAENA_SPGEMM_NO_LDS"] = "1"            # heavy rows on the dense accumulator in HBM (the only form before round 3)
     env["SAENA_SETUP_TIMING"] = "1"
     out = subprocess.run([sys.executable, "-c", WORKER % dict(root=ROOT, m=m)], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
@@ -57,5 +59,7 @@ def test_gpu_spgemm_builds_the_host_hierarchy_bit_for_bit(m):
     ref, err_host = _run(m, host_spgemm=True)
     assert "[spgemm gpu]" in err_gpu and "[spgemm gpu]" not in err_host, "the first run must have used the device kernel, the second the host's"
     assert gpu == ref, {k: (gpu.get(k), ref.get(k)) for k in set(gpu) | set(ref) if gpu.get(k) != ref.get(k)}
-    if m == 64:       # all three accumulators were exercised: light (wave/row), medium (workgroup/row), heavy (dense in HBM)
+    if m == 64:       # all accumulators were exercised: light (wave/row), medium (workgroup/row), heavy (dense, in LDS windows)
         assert gpu["levels"] >= 6
+        hbm, err_hbm = _run(m, host_spgemm=False, hbm_accumulator=True)        # ... and heavy with the dense accumulator in HBM
+        assert "[spgemm gpu]" in err_hbm and hbm == ref
