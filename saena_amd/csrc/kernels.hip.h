@@ -40,6 +40,7 @@ enum Epi : int {
     EPI_CHEBY0,        // d = (c*inv_diag)*(rhs - s);              y = u + d
     EPI_CHEBYK,        // d = d1*d + (c*inv_diag)*(rhs - s);       y = u + d
     EPI_SUB,           // y = y - s            (u -= P e)
+    EPI_RSWEEP,        // y = s; first smoother sweep of the NEXT level from a zero iterate with rhs = s (restriction + k_zero_sweep)
     EPI_COUNT
 };
 
@@ -54,6 +55,7 @@ struct SpmvArgs {
     const double *inv_diag;
     const double *u;         // smoother input iterate (== x for the local part)
     double       *d;         // chebyshev direction
+    double       *y2;        // EPI_RSWEEP: the next level's iterate after its first sweep
     double        c0;        // omega | c
     double        c1;        // d1
     int           nblk;
@@ -140,6 +142,17 @@ __device__ __forceinline__ void epilogue(const SpmvArgs &a, int r, double s) {
         st_once<NT>(a.y + r, a.u[r] + dd);
     } else if constexpr (EPI == EPI_SUB) {
         st_once<NT>(a.y + r, a.y[r] - s);
+    } else if constexpr (EPI == EPI_RSWEEP) {
+        // the restriction's row r is the coarse level's right-hand side AND the input of that level's first sweep from a zero
+        // iterate: k_zero_sweep's arithmetic, on the value just computed instead of on the one read back
+        st_once<NT>(a.y + r, s);
+        if (a.c1 != 0.0) {                                     // Chebyshev step 0 (c0 = 1 / theta): d = (c0 inv_diag) rhs, u = d
+            const double dd = (a.c0 * a.inv_diag[r]) * s;
+            a.d[r] = dd;
+            a.y2[r] = dd;
+        } else {                                               // Jacobi: u = rhs (inv_diag omega)
+            a.y2[r] = s * (a.inv_diag[r] * a.c0);
+        }
     }
 }
 

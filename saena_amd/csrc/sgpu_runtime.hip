@@ -690,6 +690,7 @@ KernelFn pick_h(int epi, int lanes, bool big) {
         case sk::EPI_JACOBI:   return pick_cap<F, sk::EPI_JACOBI, H>(lanes, big);
         case sk::EPI_CHEBY0:   return pick_cap<F, sk::EPI_CHEBY0, H>(lanes, big);
         case sk::EPI_CHEBYK:   return pick_cap<F, sk::EPI_CHEBYK, H>(lanes, big);
+        case sk::EPI_RSWEEP:   return pick_cap<F, sk::EPI_RSWEEP, H>(lanes, big);
         default:               return pick_cap<F, sk::EPI_SUB, H>(lanes, big);
     }
 }
@@ -715,6 +716,7 @@ VecKernelFn pick_vec_h(int epi, int lanes) {
         case sk::EPI_JACOBI:   return pick_vec_g<sk::EPI_JACOBI, H>(lanes);
         case sk::EPI_CHEBY0:   return pick_vec_g<sk::EPI_CHEBY0, H>(lanes);
         case sk::EPI_CHEBYK:   return pick_vec_g<sk::EPI_CHEBYK, H>(lanes);
+        case sk::EPI_RSWEEP:   return pick_vec_g<sk::EPI_RSWEEP, H>(lanes);
         default:               return pick_vec_g<sk::EPI_SUB, H>(lanes);
     }
 }
@@ -736,6 +738,7 @@ VecKernelFn pick_wave_h(int epi, int lanes) {
         case sk::EPI_JACOBI:   return pick_wave_g<sk::EPI_JACOBI, H>(lanes);
         case sk::EPI_CHEBY0:   return pick_wave_g<sk::EPI_CHEBY0, H>(lanes);
         case sk::EPI_CHEBYK:   return pick_wave_g<sk::EPI_CHEBYK, H>(lanes);
+        case sk::EPI_RSWEEP:   return pick_wave_g<sk::EPI_RSWEEP, H>(lanes);
         default:               return pick_wave_g<sk::EPI_SUB, H>(lanes);
     }
 }
@@ -743,7 +746,7 @@ VecKernelFn pick_wave(int epi, int lanes, bool halo) { return halo ? pick_wave_h
 
 struct EpiArgs {
     const double *rhs = nullptr, *inv_diag = nullptr, *u = nullptr;
-    double       *d = nullptr;
+    double       *d = nullptr, *y2 = nullptr;
     double        c0 = 0.0, c1 = 0.0;
 };
 
@@ -757,6 +760,7 @@ SellKernelFn pick_sell_h(int epi) {
         case sk::EPI_JACOBI:   return sk::k_sell<sk::EPI_JACOBI, HALO, PAIR, NT>;
         case sk::EPI_CHEBY0:   return sk::k_sell<sk::EPI_CHEBY0, HALO, PAIR, NT>;
         case sk::EPI_CHEBYK:   return sk::k_sell<sk::EPI_CHEBYK, HALO, PAIR, NT>;
+        case sk::EPI_RSWEEP:   return sk::k_sell<sk::EPI_RSWEEP, HALO, PAIR, NT>;
         default:               return sk::k_sell<sk::EPI_SUB, HALO, PAIR, NT>;
     }
 }
@@ -773,6 +777,7 @@ SellKernelFn pick_sellp_h(int epi) {
         case sk::EPI_JACOBI:   return sk::k_sellp<sk::EPI_JACOBI, HALO, PAIR, NT>;
         case sk::EPI_CHEBY0:   return sk::k_sellp<sk::EPI_CHEBY0, HALO, PAIR, NT>;
         case sk::EPI_CHEBYK:   return sk::k_sellp<sk::EPI_CHEBYK, HALO, PAIR, NT>;
+        case sk::EPI_RSWEEP:   return sk::k_sellp<sk::EPI_RSWEEP, HALO, PAIR, NT>;
         default:               return sk::k_sellp<sk::EPI_SUB, HALO, PAIR, NT>;
     }
 }
@@ -795,6 +800,7 @@ XldsKernelFn pick_xlds_h(int epi, int lanes) {
         case sk::EPI_JACOBI:   return pick_xlds_g<sk::EPI_JACOBI, HALO>(lanes);
         case sk::EPI_CHEBY0:   return pick_xlds_g<sk::EPI_CHEBY0, HALO>(lanes);
         case sk::EPI_CHEBYK:   return pick_xlds_g<sk::EPI_CHEBYK, HALO>(lanes);
+        case sk::EPI_RSWEEP:   return pick_xlds_g<sk::EPI_RSWEEP, HALO>(lanes);
         default:               return pick_xlds_g<sk::EPI_SUB, HALO>(lanes);
     }
 }
@@ -805,7 +811,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     sk::SpmvArgs a;
     a.flag_x = seq ? g.kflag_x : nullptr; a.seq = seq;
     a.row_ptr = P.row_ptr; a.col = P.col; a.val = P.val;
-    a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d;
+    a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d; a.y2 = e.y2;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12; a.dst = nullptr; a.cmptr = nullptr;
     a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0;
@@ -819,7 +825,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         void (*kd)(const sk::SpmvArgs, const double *, int, int) =
             epi == sk::EPI_SPMV ? sk::k_dense_rows<sk::EPI_SPMV> : epi == sk::EPI_RESIDUAL ? sk::k_dense_rows<sk::EPI_RESIDUAL>
             : epi == sk::EPI_JACOBI ? sk::k_dense_rows<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows<sk::EPI_CHEBY0>
-            : epi == sk::EPI_CHEBYK ? sk::k_dense_rows<sk::EPI_CHEBYK> : sk::k_dense_rows<sk::EPI_SUB>;
+            : epi == sk::EPI_CHEBYK ? sk::k_dense_rows<sk::EPI_CHEBYK> : epi == sk::EPI_RSWEEP ? sk::k_dense_rows<sk::EPI_RSWEEP> : sk::k_dense_rows<sk::EPI_SUB>;
         SGPU_LAUNCH(kd, dim3((P.nrows + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, (const double *)P.dense, P.nrows, P.ncols);
     } else if (P.variant == 10) {                                 // x in LDS, a workgroup per CU
         if (!P.xl_ok) return fail(SGPU_ERR_STATE, "the x-in-LDS form was not built");
@@ -1113,12 +1119,13 @@ int zero_sweep(sgpu_op *op, int cheby, double c0, const double *rhs, double *y, 
 }
 
 // zero_first: the iterate in `u` is known to be zero (its CONTENT is not read): the first sweep skips the matrix
-int jacobi_pp(sgpu_op *op, int iter, double omega, double *u, double *alt, const double *rhs, double **out, bool zero_first = false) {
+// zero_done: that first sweep has already been written to `alt` by the restriction's epilogue (EPI_RSWEEP)
+int jacobi_pp(sgpu_op *op, int iter, double omega, double *u, double *alt, const double *rhs, double **out, bool zero_first = false, bool zero_done = false) {
     if (!op->inv_diag && op->M > 0) return fail(SGPU_ERR_ARG, "jacobi: operator has no inv_diag");   // (a rank may own no rows of a level)
     double *cur = u, *nxt = alt;
     for (int j = 0; j < iter; ++j) {
         if (j == 0 && zero_first) {
-            CHK(zero_sweep(op, 0, omega, rhs, nxt, nullptr));
+            if (!zero_done) CHK(zero_sweep(op, 0, omega, rhs, nxt, nullptr));
         } else {
             EpiArgs e; e.rhs = rhs; e.inv_diag = op->inv_diag; e.u = cur; e.c0 = omega;
             CHK(apply(op, sk::EPI_JACOBI, cur, nxt, e));
@@ -1130,7 +1137,7 @@ int jacobi_pp(sgpu_op *op, int iter, double omega, double *u, double *alt, const
 }
 
 // saena_matrix::chebyshev scalars, src/saena_matrix.cpp:1084-1091,1113-1117
-int cheby_pp(sgpu_op *op, int iter, double eig_max, double *u, double *alt, const double *rhs, double **out, bool zero_first = false) {
+int cheby_pp(sgpu_op *op, int iter, double eig_max, double *u, double *alt, const double *rhs, double **out, bool zero_first = false, bool zero_done = false) {
     if (!op->inv_diag && op->M > 0) return fail(SGPU_ERR_ARG, "chebyshev: operator has no inv_diag");
     CHK(ensure_d(op));
     const double alpha = 0.13 * eig_max, beta = eig_max;
@@ -1140,7 +1147,7 @@ int cheby_pp(sgpu_op *op, int iter, double eig_max, double *u, double *alt, cons
     double *cur = u, *nxt = alt;
     if (iter <= 0) { *out = cur; return SGPU_OK; }
     if (zero_first) {
-        CHK(zero_sweep(op, 1, 1.0 / theta, rhs, nxt, op->dvec));
+        if (!zero_done) CHK(zero_sweep(op, 1, 1.0 / theta, rhs, nxt, op->dvec));
         std::swap(cur, nxt);
     } else {
         EpiArgs e; e.rhs = rhs; e.inv_diag = op->inv_diag; e.u = cur; e.d = op->dvec; e.c0 = 1.0 / theta;
@@ -2149,12 +2156,12 @@ int coarse_solve(sgpu_amg *h, double *u, const double *rhs, int *iters) {
     return coarse_cg_dist(h, A, u, rhs, iters);
 }
 
-int smooth_pp(sgpu_amg *h, int l, int iter, double *u, double *alt, const double *rhs, double **out, bool zero_first = false) {
+int smooth_pp(sgpu_amg *h, int l, int iter, double *u, double *alt, const double *rhs, double **out, bool zero_first = false, bool zero_done = false) {
     if (h->prm.smoother == 0) {
         const double om = h->prm.jacobi_omega != 0.0 ? h->prm.jacobi_omega : JACOBI_OMEGA_REF;
-        return jacobi_pp(h->A[l], iter, om, u, alt, rhs, out, zero_first);
+        return jacobi_pp(h->A[l], iter, om, u, alt, rhs, out, zero_first, zero_done);
     }
-    return cheby_pp(h->A[l], iter, h->eig[l], u, alt, rhs, out, zero_first);
+    return cheby_pp(h->A[l], iter, h->eig[l], u, alt, rhs, out, zero_first, zero_done);
 }
 
 // saena_object::vcycle (src/saena_object_solve.cpp:961-1431).  u/alt are the two
@@ -2162,7 +2169,7 @@ int smooth_pp(sgpu_amg *h, int l, int iter, double *u, double *alt, const double
 // u_zero: the iterate is zero by construction (every coarse level, :1249; the fine level when the V-cycle
 // preconditions CG, :2640) and the buffer's CONTENT is not read: the first pre-smoothing sweep then needs no
 // pass over the matrix (k_zero_sweep) and the zero fill itself is skipped.  Results are those of the plain sweep.
-int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, double **out, bool u_zero);
+int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, double **out, bool u_zero, bool zero_done = false);
 
 // the communication-free sub-V-cycle from `tail_level` down as one graph launch (captured at its first use)
 int tail_run(sgpu_amg *h, double **out) {
@@ -2192,7 +2199,9 @@ int tail_run(sgpu_amg *h, double **out) {
     return SGPU_OK;
 }
 
-int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, double **out, bool u_zero) {
+// zero_done: the first pre-smoothing sweep of this level (from its zero iterate) was written to `alt` by the epilogue of the
+// restriction that produced `rhs` (EPI_RSWEEP: one launch fewer per coarse level; the same arithmetic on the same numbers)
+int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, double **out, bool u_zero, bool zero_done) {
     const size_t n = (size_t)h->A[l]->M;
     if (l == h->tail_level && !h->tail_capturing && u_zero && u == h->u[l] && alt == h->alt[l] && rhs == h->rhs[l]) return tail_run(h, out);
     if (l == h->nlevels - 1) {                             // :991-1057
@@ -2203,7 +2212,7 @@ int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, 
     }
     double *cur = u, *oth = alt, *t = nullptr;
     if (h->prm.preSmooth) {                                // :1105-1107
-        CHK(smooth_pp(h, l, h->prm.preSmooth, cur, oth, rhs, &t, u_zero));
+        CHK(smooth_pp(h, l, h->prm.preSmooth, cur, oth, rhs, &t, u_zero, u_zero && zero_done));
         if (t != cur) std::swap(cur, oth);
     } else if (u_zero) {
         CHK(sgpu_vec_fill(cur, 0.0, n));
@@ -2212,9 +2221,27 @@ int vcycle_level(sgpu_amg *h, int l, double *u, double *alt, const double *rhs, 
         EpiArgs e; e.rhs = rhs;
         CHK(apply(h->A[l], sk::EPI_RESIDUAL, cur, h->res[l], e));
     }
-    CHK(apply(h->R[l], sk::EPI_SPMV, h->res[l], h->rhs[l + 1], EpiArgs()));   // :1175
+    // :1175 res_coarse = R res.  One rank, and a next level that smooths: the restriction's epilogue also writes that level's
+    // first sweep from the zero iterate (k_zero_sweep's arithmetic on the value it has just summed) -- one launch fewer per
+    // coarse level, which is what the small levels are made of (SAENA_NO_RSWEEP=1: two launches, as before round 3)
+    const bool no_rsweep = std::getenv("SAENA_NO_RSWEEP") != nullptr;       // (read per call: a captured graph keeps what it was captured with)
+    sgpu_op *An = h->A[l + 1];
+    const bool fuse = !no_rsweep && !g.multi() && h->prm.preSmooth > 0 && l + 1 < h->nlevels - 1 && An->inv_diag && An->M > 0 &&
+                      !h->R[l]->has_remote && h->R[l]->loc.variant != 5;
+    if (fuse) {
+        EpiArgs e; e.inv_diag = An->inv_diag; e.y2 = h->alt[l + 1];
+        if (h->prm.smoother == 0) { e.c0 = h->prm.jacobi_omega != 0.0 ? h->prm.jacobi_omega : JACOBI_OMEGA_REF; e.c1 = 0.0; }
+        else {
+            CHK(ensure_d(An));
+            const double alpha = 0.13 * h->eig[l + 1], beta = h->eig[l + 1], theta = (beta + alpha) / 2.0;      // cheby_pp's constants
+            e.d = An->dvec; e.c0 = 1.0 / theta; e.c1 = 1.0;
+        }
+        CHK(apply(h->R[l], sk::EPI_RSWEEP, h->res[l], h->rhs[l + 1], e));
+    } else {
+        CHK(apply(h->R[l], sk::EPI_SPMV, h->res[l], h->rhs[l + 1], EpiArgs()));
+    }
     double *uc = nullptr;                                                     // :1249 uCorrCoarse = 0, :1254
-    CHK(vcycle_level(h, l + 1, h->u[l + 1], h->alt[l + 1], h->rhs[l + 1], &uc, true));
+    CHK(vcycle_level(h, l + 1, h->u[l + 1], h->alt[l + 1], h->rhs[l + 1], &uc, true, fuse));
     CHK(apply(h->P[l], sk::EPI_SUB, uc, cur, EpiArgs()));                     // :1325 + :1360-1361
     if (h->prm.postSmooth) {                               // :1397-1399
         CHK(smooth_pp(h, l, h->prm.postSmooth, cur, oth, rhs, &t));

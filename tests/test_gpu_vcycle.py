@@ -123,6 +123,37 @@ def test_graph_replay_equals_eager(capi, hier, smoother):
         np.testing.assert_array_equal(dug.download(), due.download())
 
 
+@pytest.mark.parametrize("smoother,pre", [("jacobi", 3), ("chebyshev", 3), ("jacobi", 1), ("chebyshev", 1)])
+def test_restriction_fused_with_the_next_level_s_first_sweep(capi, hier, smoother, pre, monkeypatch):
+    """One rank: the restriction's epilogue also writes the coarse level's first sweep from its zero iterate (EPI_RSWEEP, one
+    launch fewer per coarse level).  Same arithmetic on the same numbers: the V-cycle and the pCG history are those of the
+    two-launch form (SAENA_NO_RSWEEP=1) bit for bit, with fewer launches."""
+    O, Gf, (OA, _, _), _ = build(capi, hier, smoother, pre=pre)
+    n = OA[0].Mbig
+    rhs, u0 = inputs.rhs2(n), inputs.v2(n) * 0.01
+    duf, dr = capi.DeviceVector(n, u0), capi.DeviceVector(n, rhs)
+    Gf.vcycle(duf, dr)                                                  # captures with the fused form
+    l0 = capi.launch_count(); Gf.vcycle(duf, dr); fused_launch = capi.launch_count() - l0
+    monkeypatch.setenv("SAENA_NO_RSWEEP", "1")
+    _, Gs, _, _ = build(capi, hier, smoother, pre=pre, use_graph=False)
+    _, Ge, _, _ = build(capi, hier, smoother, pre=pre, use_graph=False)
+    dus = capi.DeviceVector(n, u0)
+    Gs.vcycle(dus, dr); Gs.vcycle(dus, dr)
+    np.testing.assert_array_equal(duf.download(), dus.download())
+    l0 = capi.launch_count(); Gs.vcycle(dus, dr); plain = capi.launch_count() - l0
+    monkeypatch.delenv("SAENA_NO_RSWEEP")
+    due = capi.DeviceVector(n, u0)
+    Ge.vcycle(due, dr); Ge.vcycle(due, dr); Ge.vcycle(due, dr)
+    l0 = capi.launch_count(); Ge.vcycle(due, dr); fused = capi.launch_count() - l0
+    assert fused == plain - (len(OA) - 2), (fused, plain)               # one launch fewer per coarse level that smooths
+    assert fused_launch == 1                                            # (the graph form: one launch whatever it holds)
+    # the Krylov loop through it: same history as the oracle's, as before
+    du2 = capi.DeviceVector(n)
+    it_g, hist_g, conv = Gf.solve_pCG(du2, dr)
+    _, it_o, hist_o = O.solve_pCG(rhs)
+    assert conv and it_g == it_o and np.all(np.abs(np.array(hist_g) - np.array(hist_o)) <= TOL_HIST * hist_o[0])
+
+
 def test_plain_cg(capi, hier):
     """saena::amg::solve_CG: CG without the V-cycle (rho aliases r); same iteration count and residuals as the oracle"""
     O, G, (OA, _, _), _ = build(capi, hier, "jacobi", max_iter=400)
