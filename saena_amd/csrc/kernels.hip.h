@@ -888,6 +888,85 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
 }
 
 // ---------------------------------------------------------------------------
+// K1y: sliced ELLPACK inside the (row chunk, column window) blocks of k_csr_xlds -- for the levels of a few hundred entries
+// per row (256^3 L2: 263), where the tile kernels are either gather-bound (k_csr_cc16: 2.6 L1->L2 requests per line of stream)
+// or carry 12 B per entry (k_csr_cm), and where k_csr_xlds's (row, window) pieces of ~66 entries are too short for a group
+// of lanes each.  Here a LANE owns a row piece, as in k_sell: the pieces of one (chunk, window) block are sorted by length and
+// packed 64 to a slice, position-major in pairs (16-byte value loads, 4-byte loads of two 16-bit window-relative column ids:
+// 10 B per stored entry, ~3 % padding because each block sorts its own rows), the lane walks its piece and gathers from the
+// window of x in LDS, and the partial sum of a row travels from window to window through `acc` (16 B per row and window
+// against ~660 B of piece).  A row's pieces are added in ascending column order, window by window, each piece sequentially:
+// deterministic; the order is k_csr_xlds's, not the sequential one.  Every row appears in its chunk's LAST window (with an
+// empty piece if need be): that is where its epilogue runs.
+// meta[slice * 64 + lane] = row in chunk (16 bits; 0xffff: no row) | piece length << 16 (15 bits) | first piece of the row << 31.
+// pairs of positions a lane keeps in flight: 8 (426 us on 256^3 L2) against 4 (437 us), profiles/r03_sellx_steps.log
+constexpr int SELLX_UP = 8;
+struct SellxArgs {
+    const int4           *info;      // per workgroup: first column, windows, -, -
+    const int            *bptr;      // [chunks x (XL_MAXT + 1)]: first slice of block (chunk, window)
+    const int            *sptr;      // [slices + 1] entry offsets (multiples of 64)
+    const unsigned       *meta;
+    const double         *val;
+    const unsigned short *col;
+    double               *acc;
+    int                   ncols;
+};
+template <int EPI, bool HALO>
+__global__ __launch_bounds__(XL_BLOCK) void k_sellx(const SpmvArgs a, const SellxArgs w) {
+    __shared__ __attribute__((aligned(16))) double xs[XL_MAX];
+    if constexpr (HALO) fork_signal(a);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = XL_BLOCK / 64;
+    const int r0 = a.blk_row[blockIdx.x];
+    const int4 inf = w.info[blockIdx.x];
+    const int T = inf.y;
+    for (int t = 0; t < T; ++t) {
+        if (t > 0) __syncthreads();                               // everyone is done with the previous window
+        const int base = inf.x + t * XL_MAX;
+        const int n = w.ncols - base < XL_MAX ? w.ncols - base : XL_MAX;
+        for (int i = tid; i < n; i += XL_BLOCK) xs[i] = a.x[base + i];
+        __syncthreads();
+        const int s0 = w.bptr[blockIdx.x * (XL_MAXT + 1) + t], s1 = w.bptr[blockIdx.x * (XL_MAXT + 1) + t + 1];
+        for (int s = s0 + wave; s < s1; s += NW) {
+            const int p = w.sptr[s], P = (w.sptr[s + 1] - p) >> 7;           // pairs of positions
+            const unsigned meta = w.meta[s * 64 + lane];
+            const int len = (int)((meta >> 16) & 0x7fffu);
+            const sk_d2v   *v2 = reinterpret_cast<const sk_d2v *>(w.val + p) + lane;
+            const unsigned *c2 = reinterpret_cast<const unsigned *>(w.col + p) + lane;
+            const unsigned row = meta & 0xffffu;
+            // the row's partial sum of the windows before this one: fetched now, needed after the piece (a dependent L2 round
+            // trip at the end of every slice otherwise)
+            double prev = 0.0;
+            if (row != 0xffffu && !(meta >> 31)) prev = w.acc[r0 + (int)row];
+            constexpr int UP = SELLX_UP;
+            double sum = 0.0;
+            for (int q = 0; q < P; q += UP) {
+                sk_d2v   vv[UP];
+                unsigned cc[UP];
+#pragma unroll
+                for (int u = 0; u < UP; ++u) {
+                    const int qq = q + u < P ? q + u : P - 1;
+                    if (a.nt) { vv[u] = __builtin_nontemporal_load(v2 + qq * 64); cc[u] = __builtin_nontemporal_load(c2 + qq * 64); }
+                    else { vv[u] = v2[qq * 64]; cc[u] = c2[qq * 64]; }
+                }
+#pragma unroll
+                for (int u = 0; u < UP; ++u) {                   // padding is never added: a NaN or inf in x stays in the rows that own it
+                    const double x0 = xs[cc[u] & 0xffffu], x1 = xs[cc[u] >> 16];
+                    if (q + u < P && 2 * (q + u) < len) sum += vv[u].x * x0;
+                    if (q + u < P && 2 * (q + u) + 1 < len) sum += vv[u].y * x1;
+                }
+            }
+            if (row != 0xffffu) {
+                const int r = r0 + (int)row;
+                if (!(meta >> 31)) sum = prev + sum;
+                if (t < T - 1) w.acc[r] = sum;
+                else epilogue<EPI, HALO>(a, r, sum);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K1c: dense row-major operator (saena_matrix_dense::matvec_dense, src/saena_matrix_dense.cpp:181-260,
 // the reference's optional `switch_to_dense` storage for coarse levels that are mostly full).  One wave per row streams
 // the row with coalesced 8-byte loads (no column ids: 8 B per entry instead of 12), the fused epilogues are the sparse ones.

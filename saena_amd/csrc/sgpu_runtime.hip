@@ -184,12 +184,26 @@ struct CsrPart {
     int4           *xl_info = nullptr;
     double         *xl_acc = nullptr;
     int             xl_nblk = 0, xl_maxt = 1;
+    std::vector<int>  xl_blk_h;            // host copies of the chunk plan (k_sellx is built on top of it)
+    std::vector<int4> xl_info_h;
     double          xl_piece = 0.0;
     bool            xl_ok = false;
     char            xl_tried = 0;
     void free_xlds() {
         hipFree(xl_col); hipFree(xl_blk); hipFree(xl_tab); hipFree(xl_info); hipFree(xl_acc);
         xl_col = nullptr; xl_blk = xl_tab = nullptr; xl_info = nullptr; xl_acc = nullptr; xl_ok = false; xl_tried = 0;
+    }
+    // sliced ELLPACK inside the (chunk, window) blocks of the x-in-LDS form (variant 12, k_sellx): shares xl_blk / xl_info / xl_acc
+    double         *sx_val = nullptr;
+    unsigned short *sx_col = nullptr;
+    unsigned       *sx_meta = nullptr;
+    int            *sx_bptr = nullptr, *sx_sptr = nullptr;
+    double          sx_pad = 0.0;          // stored / actual entries
+    bool            sx_ok = false;
+    char            sx_tried = 0;
+    void free_sellx() {
+        hipFree(sx_val); hipFree(sx_col); hipFree(sx_meta); hipFree(sx_bptr); hipFree(sx_sptr);
+        sx_val = nullptr; sx_col = nullptr; sx_meta = nullptr; sx_bptr = sx_sptr = nullptr; sx_ok = false; sx_tried = 0;
     }
     int             cc_ob[2] = {12, 12};   // offset bits of the slot/offset split (12: 16 segments of 4096 columns ... 8: 256 of 256)
     char            cc_tried[2] = {0, 0};  // build_cc16 ran and found no split that fits (do not try again)
@@ -202,6 +216,7 @@ struct CsrPart {
         row_ptr = col = blk_row = blk_row_big = rows = nullptr; val = nullptr;
         free_sell();
         free_xlds();
+        free_sellx();
     }
 };
 
@@ -474,6 +489,7 @@ int build_xlds(CsrPart &P) {
         for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
         for (auto &x : th) x.join();
     }
+    P.xl_blk_h = blk; P.xl_info_h = info;
     CHK(dev_upload(&P.xl_col, col.data(), col.size()));
     CHK(dev_upload(&P.xl_blk, blk.data(), blk.size()));
     CHK(dev_upload(&P.xl_tab, tab.data(), tab.size()));
@@ -604,6 +620,113 @@ int build_sellp(CsrPart &P) {
     P.sp_w = W; P.sp_n = npat;
     P.sp_bytes = 8 * (int64_t)P.h_rp.back() + 2 * (int64_t)M + 8 * (int64_t)P.ncols + 8 * (int64_t)M;
     P.sp_ok = true;
+    return SGPU_OK;
+}
+
+// Sliced ELLPACK inside the (row chunk, column window) blocks of the x-in-LDS plan (k_sellx): per block the rows with a piece
+// in that window (every row in the chunk's last window), sorted by piece length, 64 to a slice, position-major in pairs.
+// Built where it can pay: at most 25 % padding, chunks of at most 65 534 rows.
+int build_sellx(CsrPart &P, const std::vector<double> &h_val_all) {
+    if (P.sx_ok || P.sx_tried || !P.xl_ok || P.xl_blk_h.empty()) return SGPU_OK;
+    P.sx_tried = 1;
+    if (h_val_all.size() != P.h_col.size()) return SGPU_OK;
+    const int nb = P.xl_nblk;
+    const std::vector<int> &blk = P.xl_blk_h;
+    for (int b = 0; b < nb; ++b) if (blk[(size_t)b + 1] - blk[(size_t)b] > 65534) return SGPU_OK;
+    struct Piece { int k, p0, len; };
+    // pass 1: per block the sorted piece list and its slices' widths
+    std::vector<std::vector<std::vector<Piece>>> pieces((size_t)nb);       // [chunk][window] -> pieces sorted by length
+    std::vector<int> bptr((size_t)nb * (sk::XL_MAXT + 1) + 1, 0);
+    std::vector<int64_t> chunk_entries((size_t)nb, 0), chunk_slices((size_t)nb, 0);
+    const int nt = std::min(host_threads(), std::max(1, nb / 8));
+    auto pass1 = [&](int t) {
+        for (int b = (int)((long)nb * t / nt); b < (int)((long)nb * (t + 1) / nt); ++b) {
+            const int r0 = blk[(size_t)b], rows = blk[(size_t)b + 1] - r0, cmin = P.xl_info_h[(size_t)b].x, T = P.xl_info_h[(size_t)b].y;
+            auto &pw = pieces[(size_t)b];
+            pw.assign((size_t)T, {});
+            for (int k = 0; k < rows; ++k) {
+                const int p0 = P.h_rp[(size_t)r0 + k], p1 = P.h_rp[(size_t)r0 + k + 1];
+                int p = p0;
+                for (int w = 0; w < T; ++w) {
+                    const int lim = w == T - 1 ? INT32_MAX : cmin + (w + 1) * sk::XL_MAX;
+                    const int q0 = p;
+                    while (p < p1 && P.h_col[(size_t)p] < lim) ++p;
+                    if (p > q0 || w == T - 1) pw[(size_t)w].push_back(Piece{k, q0, p - q0});
+                }
+            }
+            int64_t ent = 0, sl = 0;
+            for (int w = 0; w < T; ++w) {
+                auto &v = pw[(size_t)w];
+                std::stable_sort(v.begin(), v.end(), [](const Piece &x, const Piece &y) { return x.len > y.len; });
+                for (size_t i = 0; i < v.size(); i += 64) { ent += (int64_t)((v[i].len + 1) & ~1) * 64; ++sl; }
+            }
+            chunk_entries[(size_t)b] = ent; chunk_slices[(size_t)b] = sl;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(pass1, t);
+        for (auto &x : th) x.join();
+    }
+    int64_t tot = 0, nsl = 0;
+    std::vector<int64_t> e0((size_t)nb), s0((size_t)nb);
+    for (int b = 0; b < nb; ++b) { e0[(size_t)b] = tot; s0[(size_t)b] = nsl; tot += chunk_entries[(size_t)b]; nsl += chunk_slices[(size_t)b]; }
+    if (tot > (int64_t)INT32_MAX - 1024 || nsl > INT32_MAX / 64) return SGPU_OK;
+    P.sx_pad = (double)tot / (double)std::max<int64_t>(1, P.nnz);
+    const double pad_limit = std::getenv("SAENA_SELLX_PAD") ? atof(std::getenv("SAENA_SELLX_PAD")) : 1.25;
+    if (P.sx_pad > pad_limit) return SGPU_OK;
+    std::vector<double> val((size_t)tot + 128, 0.0);
+    std::vector<unsigned short> col((size_t)tot + 128, 0);
+    std::vector<unsigned> meta((size_t)nsl * 64, 0xffffu);
+    std::vector<int> sptr((size_t)nsl + 1, 0);
+    auto pass2 = [&](int t) {
+        for (int b = (int)((long)nb * t / nt); b < (int)((long)nb * (t + 1) / nt); ++b) {
+            const int cmin = P.xl_info_h[(size_t)b].x, T = P.xl_info_h[(size_t)b].y;
+            std::vector<char> seen((size_t)(blk[(size_t)b + 1] - blk[(size_t)b]), 0);
+            int64_t e = e0[(size_t)b], sl = s0[(size_t)b];
+            for (int w = 0; w <= sk::XL_MAXT; ++w) {
+                bptr[(size_t)b * (sk::XL_MAXT + 1) + (size_t)w] = (int)sl;
+                if (w >= T) continue;
+                const auto &v = pieces[(size_t)b][(size_t)w];
+                const int wbase = cmin + w * sk::XL_MAX;
+                for (size_t i = 0; i < v.size(); i += 64, ++sl) {
+                    const int width = (v[i].len + 1) & ~1, PP = width >> 1;
+                    sptr[(size_t)sl] = (int)e;
+                    for (size_t j = i; j < std::min(v.size(), i + 64); ++j) {
+                        const Piece &pc = v[j];
+                        const int lane = (int)(j - i);
+                        const unsigned first = seen[(size_t)pc.k] ? 0u : 1u;
+                        seen[(size_t)pc.k] = 1;
+                        meta[(size_t)sl * 64 + (size_t)lane] = (unsigned)pc.k | ((unsigned)pc.len << 16) | (first << 31);
+                        for (int q = 0; q < pc.len; ++q) {
+                            const size_t o = (size_t)e + (size_t)(q >> 1) * 128 + (size_t)lane * 2 + (size_t)(q & 1);
+                            val[o] = h_val_all[(size_t)pc.p0 + q];
+                            col[o] = (unsigned short)(P.h_col[(size_t)pc.p0 + q] - wbase);
+                        }
+                    }
+                    (void)PP;
+                    e += (int64_t)width * 64;
+                }
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(pass2, t);
+        for (auto &x : th) x.join();
+    }
+    sptr[(size_t)nsl] = (int)tot;
+    bptr[(size_t)nb * (sk::XL_MAXT + 1)] = (int)nsl;
+    if (std::getenv("SAENA_SETUP_TIMING"))
+        fprintf(stderr, "[sgpu] sliced ELLPACK in LDS windows: %d rows, %lld entries, %.1f %% padding, %lld slices in %d chunks of <= %d windows\n", P.nrows,
+                (long long)P.nnz, 100.0 * (P.sx_pad - 1.0), (long long)nsl, nb, P.xl_maxt);
+    CHK(dev_upload(&P.sx_val, val.data(), val.size()));
+    CHK(dev_upload(&P.sx_col, col.data(), col.size()));
+    CHK(dev_upload(&P.sx_meta, meta.data(), meta.size(), 64));
+    CHK(dev_upload(&P.sx_sptr, sptr.data(), sptr.size()));
+    CHK(dev_upload(&P.sx_bptr, bptr.data(), bptr.size()));
+    if (!P.xl_acc && P.xl_maxt > 1) HIPCHK(hipMalloc(&P.xl_acc, (size_t)P.nrows * sizeof(double)));
+    P.sx_ok = true;
     return SGPU_OK;
 }
 
@@ -804,6 +927,19 @@ XldsKernelFn pick_xlds_h(int epi, int lanes) {
         default:               return pick_xlds_g<sk::EPI_SUB, HALO>(lanes);
     }
 }
+using SellxKernelFn = void (*)(const sk::SpmvArgs, const sk::SellxArgs);
+template <bool HALO>
+SellxKernelFn pick_sellx_h(int epi) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return sk::k_sellx<sk::EPI_SPMV, HALO>;
+        case sk::EPI_RESIDUAL: return sk::k_sellx<sk::EPI_RESIDUAL, HALO>;
+        case sk::EPI_JACOBI:   return sk::k_sellx<sk::EPI_JACOBI, HALO>;
+        case sk::EPI_CHEBY0:   return sk::k_sellx<sk::EPI_CHEBY0, HALO>;
+        case sk::EPI_CHEBYK:   return sk::k_sellx<sk::EPI_CHEBYK, HALO>;
+        case sk::EPI_RSWEEP:   return sk::k_sellx<sk::EPI_RSWEEP, HALO>;
+        default:               return sk::k_sellx<sk::EPI_SUB, HALO>;
+    }
+}
 XldsKernelFn pick_xlds(int epi, int lanes, bool halo) { return halo ? pick_xlds_h<true>(epi, lanes) : pick_xlds_h<false>(epi, lanes); }
 
 int launch_part(const CsrPart &P, int epi, const double *x, double *y, const EpiArgs &e, const unsigned *skip = nullptr, uint64_t seq = 0) {
@@ -827,8 +963,15 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
             : epi == sk::EPI_JACOBI ? sk::k_dense_rows<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows<sk::EPI_CHEBY0>
             : epi == sk::EPI_CHEBYK ? sk::k_dense_rows<sk::EPI_CHEBYK> : epi == sk::EPI_RSWEEP ? sk::k_dense_rows<sk::EPI_RSWEEP> : sk::k_dense_rows<sk::EPI_SUB>;
         SGPU_LAUNCH(kd, dim3((P.nrows + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, (const double *)P.dense, P.nrows, P.ncols);
+    } else if (P.variant == 12) {                                 // sliced ELLPACK in the LDS windows, a workgroup per CU
+        if (!P.sx_ok || !P.xl_ok) return fail(SGPU_ERR_STATE, "the sliced-ELLPACK-in-LDS form was not built");
+        a.blk_row = P.xl_blk; a.nblk = P.xl_nblk;
+        sk::SellxArgs w;
+        w.info = P.xl_info; w.bptr = P.sx_bptr; w.sptr = P.sx_sptr; w.meta = P.sx_meta; w.val = P.sx_val; w.col = P.sx_col; w.acc = P.xl_acc; w.ncols = P.ncols;
+        if (nt_rt == 0 && !std::getenv("SAENA_STREAM_NT")) a.nt = 10 * P.nnz > (int64_t)256 * 1024 * 1024 ? 1 : 0;      // non-temporal streams beyond the Infinity Cache (438 -> 426 us)
+        SGPU_LAUNCH(halo ? pick_sellx_h<true>(epi) : pick_sellx_h<false>(epi), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, w);
     } else if (P.variant == 10) {                                 // x in LDS, a workgroup per CU
-        if (!P.xl_ok) return fail(SGPU_ERR_STATE, "the x-in-LDS form was not built");
+        if (!P.xl_ok || !P.xl_col) return fail(SGPU_ERR_STATE, "the x-in-LDS form was not built");
         a.blk_row = P.xl_blk; a.nblk = P.xl_nblk; a.ccol = P.xl_col;
         sk::XldsArgs w;
         w.info = P.xl_info; w.tab = P.xl_tab; w.acc = P.xl_acc; w.ncols = P.ncols;
@@ -1621,7 +1764,7 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp"};   // (3, 4, 7, 8 are named with their slot/offset split below)
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx"};   // (3, 4, 7, 8 are named with their slot/offset split below)
     if (variant) *variant = op->loc.variant;
     if (kernel_name) {
         const int v = op->loc.variant;
@@ -1640,7 +1783,14 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 11) return fail(SGPU_ERR_ARG, "variant must be 0..11");
+    if (variant < 0 || variant > 12) return fail(SGPU_ERR_ARG, "variant must be 0..12");
+    if (variant == 12) {
+        CHK(build_xlds(op->loc));
+        CHK(build_sellx(op->loc, op->h_val_all));
+        if (!op->loc.sx_ok)
+            return fail(SGPU_ERR_ARG, "the sliced-ELLPACK-in-LDS form needs the x-in-LDS plan (row chunks over at most %d column windows), at most 25 %% padding "
+                                      "and the host copy of the values (kept until the plan-time autotune, or with SAENA_KEEP_HOST_VALUES=1)", sk::XL_MAXT);
+    }
     if (variant == 11) {
         CHK(build_sell(op->loc, op->h_val_all));
         CHK(build_sellp(op->loc));
@@ -1732,7 +1882,7 @@ bool plan_cache_lookup(uint64_t key, int *v, int *lanes) {
     bool hit = false;
     while (fgets(line, sizeof line, f)) {               // the last line of a key wins
         unsigned long long k; int vv, ll;
-        if (sscanf(line, "%llx %d %d", &k, &vv, &ll) == 3 && k == key && vv >= 0 && vv <= 11 && ll >= 1 && ll <= 64) { *v = vv; *lanes = ll; hit = true; }
+        if (sscanf(line, "%llx %d %d", &k, &vv, &ll) == 3 && k == key && vv >= 0 && vv <= 12 && ll >= 1 && ll <= 64) { *v = vv; *lanes = ll; hit = true; }
     }
     fclose(f);
     return hit;
@@ -1760,7 +1910,9 @@ void finish_plan(sgpu_op *op, int bv) {
     if (bv != 9 && bv != 11 && !keep) op->loc.free_sell();
     else if (bv == 11 && !keep) op->loc.free_sell_columns();    // k_sellp keeps the values and the slice pointers only
     else if (bv == 9 && !keep) op->loc.free_sellp();
-    if (bv != 10 && !keep) op->loc.free_xlds();
+    if (bv != 12 && !keep) op->loc.free_sellx();
+    if (bv != 10 && bv != 12 && !keep) op->loc.free_xlds();
+    else if (bv == 12 && !keep) { hipFree(op->loc.xl_col); hipFree(op->loc.xl_tab); op->loc.xl_col = nullptr; op->loc.xl_tab = nullptr; }      // k_sellx keeps the chunk plan only
     if (!keep) std::vector<double>().swap(op->h_val_all);       // (a later set_variant(7/8/9/11) on this operator is refused: the values are gone)
     for (int k = 0; k < 2 && !keep; ++k)              // free the compressed arrays of the plans that lost
         if (op->loc.cc_ok[k] && bv != 3 + k && bv != 7 + k) {
@@ -1842,6 +1994,10 @@ int sgpu_op_autotune(sgpu_op *op) {
         CHK(build_xlds(op->loc));                                                                    // long rows over few columns: x in LDS
         if (op->loc.xl_ok && op->loc.xl_piece >= 24.0) variants.push_back(10);
     }
+    if (op->loc.xl_ok && !op->h_val_all.empty() && avg_row >= 96.0 && avg_row <= 1024.0 && !std::getenv("SAENA_NO_SELLX")) {
+        CHK(build_sellx(op->loc, op->h_val_all));                                                    // a few hundred entries per row: a lane per row piece, x in LDS
+        if (op->loc.sx_ok) variants.push_back(12);
+    }
     const double t_xl = now_s();
     if (!op->h_val_all.empty() && avg_row >= 96.0 && avg_row <= 768.0 && !std::getenv("SAENA_NO_CM")) {   // rows of a few hundred entries: column order inside the block
         CHK(build_cm(op->loc, 1, op->h_val_all));
@@ -1869,7 +2025,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     std::vector<std::pair<int, int>> cands;
     for (int v : variants)
         for (int gl : (v == 10 ? lanes_x : lanes)) {
-            if ((v == 9 || v == 11) && gl != lanes.front()) continue;      // a lane per row whatever the setting
+            if ((v == 9 || v == 11 || v == 12) && gl != lanes.front()) continue;      // a lane per row (piece) whatever the setting
             if (v == 5 && gl != lanes.front()) continue;                   // one wave per dense row likewise
             cands.push_back({v, gl});
         }

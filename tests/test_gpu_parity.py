@@ -131,7 +131,7 @@ def _sellp_eligible(entries, M):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12])
 def test_kernel_variants(capi, name, variant, monkeypatch):
     """32 KiB tiles / vector CSR / 16-bit compressed columns (16 and 32 KiB tiles; long rows included) / wave-streamed
     long rows / compressed columns with the block's entries in column order (16 and 32 KiB tiles) / sliced ELLPACK /
@@ -148,6 +148,13 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         with pytest.raises(capi.SgpuError, match="sliced-ELLPACK"):    # uneven rows: more than 12 % padding, refused
             G.set_variant(variant)
         return
+    if variant == 12:                     # sliced ELLPACK in LDS windows: refused where its padding exceeds 25 % (the library's own count)
+        try:
+            G.set_variant(variant)
+        except capi.SgpuError as e:
+            assert "sliced-ELLPACK-in-LDS" in str(e)
+            return
+        assert G.variant()[1] == "k_sellx"
     if variant == 11 and not _sellp_eligible(entries, M):
         with pytest.raises(capi.SgpuError, match="row-pattern"):       # rows that follow no small set of patterns: refused
             G.set_variant(variant)
@@ -170,7 +177,7 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         G.set_lanes_per_row(lanes)
         G.spmv(dx, dy)
         got, want = dy.download(), A.matvec(x)
-        if (lanes == 1 or variant in (9, 11)) and variant not in (2, 6, 10) and (name != "band3000_1400" or variant in (1, 4, 8)):
+        if (lanes == 1 or variant in (9, 11)) and variant not in (2, 6, 10, 12) and (name != "band3000_1400" or variant in (1, 4, 8)):
             np.testing.assert_array_equal(got, want)          # stream variants keep the sequential row sum
         else:
             assert np.all(np.abs(got - want) <= TOL_SPMV * bound + 1e-300)
@@ -266,6 +273,46 @@ def test_x_in_lds_column_windows(capi):
         du = capi.DeviceVector(M, x)
         G.jacobi(2, du, dr)
         assert rel(du.download(), A.jacobi(2, x, rhs)) <= TOL_SMOOTH
+    # the same windows with a LANE per row piece (k_sellx: pieces sorted by length inside every (chunk, window) block, 64 to a
+    # slice): every fused epilogue, a few rows emptied so that some pieces are missing and some rows have none at all
+    import os
+    os.environ["SAENA_KEEP_HOST_VALUES"] = "1"
+    try:
+        keep = ~((rows % 97 == 3) & (cols > rows + 20000)) & ~(rows % 1013 == 7)      # some rows lose their far clusters, some lose everything
+        e3 = orc.coo_from_arrays(rows[keep], cols[keep], np.sin(0.37 * rows[keep] + 0.11 * cols[keep]) + (rows[keep] == cols[keep]) * 150.0)
+        A3 = orc.OracleOp(e3, M, M, orc.split_even(M, 1))
+        G3 = util.gpu_operator(A3)
+        G3.set_variant(12)
+        assert G3.variant()[1] == "k_sellx"
+        b3 = abs_bound(e3, M, x)
+        G3.spmv(dx, dy)
+        assert np.all(np.abs(dy.download() - A3.matvec(x)) <= TOL_SPMV * b3 + 1e-300)
+        G3.residual(dx, dr, dy)
+        assert rel(dy.download(), A3.residual(x, rhs)) <= TOL_SMOOTH
+        has_diag = np.ones(M, bool); has_diag[np.arange(M) % 1013 == 7] = False
+        if has_diag.all():
+            du = capi.DeviceVector(M, x)
+            G3.jacobi(3, du, dr)
+            assert rel(du.download(), A3.jacobi(3, x, rhs)) <= TOL_SMOOTH
+        du = capi.DeviceVector(M, rhs)
+        G3.prolong_correct(dx, du)
+        assert rel(du.download(), rhs - A3.matvec(x)) <= TOL_SMOOTH
+        # ... and on the full operator the smoothers
+        G.set_variant(12)
+        du = capi.DeviceVector(M, x)
+        G.jacobi(3, du, dr)
+        assert rel(du.download(), A.jacobi(3, x, rhs)) <= TOL_SMOOTH
+        A.set_eig(1.9371)
+        du = capi.DeviceVector(M, x)
+        G.chebyshev(3, 1.9371, du, dr)
+        assert rel(du.download(), A.chebyshev(3, x, rhs)) <= TOL_SMOOTH
+        xn = x.copy(); xn[41000] = np.nan                  # a NaN in x reaches exactly the rows that own column 41000
+        G.spmv(capi.DeviceVector(M, xn), dy)
+        got = dy.download()
+        owners = np.zeros(M, bool); owners[rows[cols == 41000]] = True
+        assert np.array_equal(np.isnan(got), owners)
+    finally:
+        os.environ.pop("SAENA_KEEP_HOST_VALUES", None)
     rng = np.random.default_rng(5)
     rr = np.repeat(np.arange(2048), 24)
     key = np.unique(rr.astype(np.int64) * (1 << 20) + rng.integers(0, 1 << 20, size=rr.size))
