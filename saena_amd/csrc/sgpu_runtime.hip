@@ -1994,6 +1994,8 @@ int sgpu_op_autotune(sgpu_op *op) {
         CHK(build_xlds(op->loc));                                                                    // long rows over few columns: x in LDS
         if (op->loc.xl_ok && op->loc.xl_piece >= 24.0) variants.push_back(10);
     }
+    // (on the transfers it does not pay: P1 of 256^3, 18 entries per row, 504 us against 350; P2 ties; R2 165 against 156 us,
+    //  profiles/r03_sellx_steps.log)
     if (op->loc.xl_ok && !op->h_val_all.empty() && avg_row >= 96.0 && avg_row <= 1024.0 && !std::getenv("SAENA_NO_SELLX")) {
         CHK(build_sellx(op->loc, op->h_val_all));                                                    // a few hundred entries per row: a lane per row piece, x in LDS
         if (op->loc.sx_ok) variants.push_back(12);

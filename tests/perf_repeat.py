@@ -1,6 +1,6 @@
 """Run-to-run spread of an operator's kernels (development aid): python -m tests.perf_repeat m level[,level...] v1,v2,... trials [lanes,...]
-Times each variant `trials` times, interleaved, with fresh input/output vectors every second trial (A of each level;
-Jacobi sweep)."""
+Times each variant `trials` times, interleaved, with fresh input/output vectors every second trial (A of each level:
+Jacobi sweep; PERF_REPEAT_WHICH=1 / 2: P / R of each level, plain product)."""
 import os
 import sys
 
@@ -22,7 +22,9 @@ def main():
     A = host.Matrix(host.Comm("gpu", "rccl")).laplacian3D(m).assemble()
     S = host.AmgSolver(A, host.options(L, **host.OPTIONS001)).to_device()
     for level in levels:
-        op = S.device_op(level, 0)
+        which = int(os.environ.get("PERF_REPEAT_WHICH", "0"))
+        op = S.device_op(level, which)
+        kind = 1 if which == 0 else 0
         print(f"L{level}: autotune chose {op.variant()} lanes {op.info()['lanes_per_row']}", flush=True)
         tuned = op.info()["lanes_per_row"]
         x = y = rhs = None
@@ -38,8 +40,8 @@ def main():
                         cells.append(f"v{v} refused")
                         break
                     op.set_lanes_per_row(lanes or tuned)
-                    op.time_kernel(1, x, rhs, y, 3)
-                    cells.append(f"v{v} G{lanes or tuned} {op.time_kernel(1, x, rhs, y, 30) * 1e3:7.1f} us")
+                    op.time_kernel(kind, x, rhs, y, 3)
+                    cells.append(f"v{v} G{lanes or tuned} {op.time_kernel(kind, x, rhs, y, 30) * 1e3:7.1f} us")
             print(f"trial {t}: " + " | ".join(cells), flush=True)
 
 
