@@ -88,6 +88,43 @@ void parallel_rows(index_t n, const std::vector<nnz_t> *weight_ptr, F f) {
     ThreadPool::get().run(T, [&](int t) { f(t, cut[(size_t)t], cut[(size_t)t + 1]); });
 }
 
+// A row of (coarse column, value) pairs ordered by column, equal columns in their original order -- std::stable_sort's result
+// without the buffer it allocates per call (one call per fine row: 16 M of them per level): insertion sort for the short
+// rows of the stencil levels, else a sort of (column, position) keys.
+void stable_sort_by_first(std::vector<std::pair<index_t, value_t>> &row, std::vector<std::pair<long, value_t>> &scratch) {
+    const size_t n = row.size();
+    if (n <= 16) {
+        for (size_t i = 1; i < n; ++i) {
+            const auto x = row[i];
+            size_t j = i;
+            while (j > 0 && row[j - 1].first > x.first) { row[j] = row[j - 1]; --j; }
+            row[j] = x;
+        }
+        return;
+    }
+    scratch.resize(n);
+    for (size_t i = 0; i < n; ++i) scratch[i] = {((long)row[i].first << 32) | (long)i, row[i].second};
+    std::sort(scratch.begin(), scratch.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    for (size_t i = 0; i < n; ++i) row[i] = {(index_t)(scratch[i].first >> 32), scratch[i].second};
+}
+
+// who looks at whom: tcol[tptr[j] .. tptr[j+1]) = the rows whose pattern holds column j.  Counted and filled on threads with
+// atomic counters (a level holds 0.3 G strong connections per rank); the ORDER inside a list depends on the threads and does
+// not matter: the lists only queue rows for re-evaluation, and the queue is sorted before use.
+void transpose_pattern(index_t nrows, index_t ncols, const std::vector<nnz_t> &ptr, const std::vector<index_t> &col,
+                       std::vector<nnz_t> &tptr, std::vector<index_t> &tcol) {
+    tptr.assign((size_t)ncols + 1, 0);
+    parallel_chunks<size_t>(col.size(), (size_t)1 << 20, [&](int, size_t a, size_t b) {
+        for (size_t k = a; k < b; ++k) __atomic_fetch_add(&tptr[(size_t)col[k] + 1], (nnz_t)1, __ATOMIC_RELAXED);
+    });
+    for (index_t j = 0; j < ncols; ++j) tptr[(size_t)j + 1] += tptr[(size_t)j];
+    std::vector<nnz_t> fill(tptr.begin(), tptr.end() - 1);
+    parallel_rows(nrows, &ptr, [&](int, index_t r0, index_t r1) {
+        for (index_t i = r0; i < r1; ++i)
+            for (nnz_t it = ptr[(size_t)i]; it < ptr[(size_t)i + 1]; ++it) tcol[(size_t)__atomic_fetch_add(&fill[(size_t)col[(size_t)it]], (nnz_t)1, __ATOMIC_RELAXED)] = i;
+    });
+}
+
 // the assembled one-rank operator as CSR (its layout arrays are row-major, columns ascending)
 Csr csr_of(const DistLayout &L, index_t ncols) {
     Csr C;
@@ -332,13 +369,7 @@ index_t amg_hierarchy::aggregate(const saena_matrix &A, const std::vector<nnz_t>
     const int T = n_threads();
     std::vector<nnz_t> tptr((size_t)size + 1, 0);                 // who looks at row j: the transposed pattern
     std::vector<index_t> tcol(col.size());
-    for (index_t c : col) tptr[(size_t)c + 1]++;
-    for (index_t i = 0; i < size; ++i) tptr[i + 1] += tptr[i];
-    {
-        std::vector<nnz_t> fill(tptr.begin(), tptr.end() - 1);
-        for (index_t i = 0; i < size; ++i)
-            for (nnz_t it = ptr[i]; it < ptr[i + 1]; ++it) tcol[fill[col[it]]++] = i;
-    }
+    transpose_pattern(size, size, ptr, col, tptr, tcol);
     std::vector<std::vector<index_t>> troots((size_t)T), tnext((size_t)T), tdone((size_t)T);
     std::vector<char> queued((size_t)size, 0);
     std::vector<index_t> work((size_t)size);
@@ -475,37 +506,67 @@ double amg_hierarchy::find_eig(const saena_matrix &A) {
 
 // filter (setup2:852-916): entries with |v| <= THRE are lumped into the diagonal (one-rank CSR form)
 static void filter_csr(Csr &C, double THRE, index_t row_offset = 0) {
+    // rows are independent: count what every row keeps (on threads), then write the rows to their places (on threads); a
+    // level that loses nothing and misses no diagonal entry -- the common case -- is left as it is
     const index_t n = C.nrows;
     std::vector<nnz_t> nptr((size_t)n + 1, 0);
-    std::vector<index_t> ncol;
-    std::vector<value_t> nval;
-    ncol.reserve(C.col.size() + (size_t)n); nval.reserve(C.col.size() + (size_t)n);
-    for (index_t i = 0; i < n; ++i) {
-        value_t add2diag = 0.0;
-        bool has_diag = false;
-        const size_t row_start = ncol.size();
-        size_t diag_pos = 0;
-        const index_t gi = i + row_offset;
-        for (nnz_t k = C.ptr[i]; k < C.ptr[i + 1]; ++k) {
-            const index_t j = C.col[k];
-            if (std::fabs(C.val[k]) > THRE || j == gi) {
-                if (j == gi) { has_diag = true; diag_pos = ncol.size(); }
-                ncol.push_back(j); nval.push_back(C.val[k]);
-            } else {
-                add2diag += C.val[k];
+    std::vector<char> changed((size_t)n_threads(), 0);
+    parallel_rows(n, &C.ptr, [&](int t, index_t r0, index_t r1) {
+        for (index_t i = r0; i < r1; ++i) {
+            const index_t gi = i + row_offset;
+            nnz_t kept = 0;
+            bool has_diag = false;
+            for (nnz_t k = C.ptr[i]; k < C.ptr[i + 1]; ++k) {
+                if (C.col[k] == gi) { has_diag = true; ++kept; }
+                else if (std::fabs(C.val[k]) > THRE) ++kept;
             }
+            if (!has_diag) ++kept;
+            if (kept != C.ptr[i + 1] - C.ptr[i] || !has_diag) changed[(size_t)t] = 1;
+            nptr[(size_t)i + 1] = kept;
         }
-        if (has_diag) {
-            nval[diag_pos] += add2diag;
-            if (std::fabs(nval[diag_pos]) < SAENA_ALMOST_ZERO) nval[diag_pos] = 1.0;
-        } else {                                             // :896-903 missing diagonal -> 1.0, kept in column order
-            size_t pos = row_start;
-            while (pos < ncol.size() && ncol[pos] < gi) ++pos;
-            ncol.insert(ncol.begin() + pos, gi);
-            nval.insert(nval.begin() + pos, 1.0);
-        }
-        nptr[i + 1] = (nnz_t)ncol.size();
+    });
+    bool any = false;
+    for (char c : changed) any = any || c;
+    if (!any) {                                             // nothing dropped, every diagonal present: only the ~0 diagonal rule applies
+        parallel_rows(n, &C.ptr, [&](int, index_t r0, index_t r1) {
+            for (index_t i = r0; i < r1; ++i)
+                for (nnz_t k = C.ptr[i]; k < C.ptr[i + 1]; ++k)
+                    if (C.col[k] == i + row_offset && std::fabs(C.val[k]) < SAENA_ALMOST_ZERO) C.val[k] = 1.0;
+        });
+        return;
     }
+    for (index_t i = 0; i < n; ++i) nptr[(size_t)i + 1] += nptr[(size_t)i];
+    std::vector<index_t> ncol((size_t)nptr[(size_t)n]);
+    std::vector<value_t> nval((size_t)nptr[(size_t)n]);
+    parallel_rows(n, &C.ptr, [&](int, index_t r0, index_t r1) {
+        for (index_t i = r0; i < r1; ++i) {
+            value_t add2diag = 0.0;
+            bool has_diag = false;
+            const index_t gi = i + row_offset;
+            nnz_t q = nptr[(size_t)i], diag_pos = 0;
+            bool placed = false;                             // a missing diagonal goes in at its place in column order (:896-903)
+            for (nnz_t k = C.ptr[i]; k < C.ptr[i + 1]; ++k) {
+                const index_t j = C.col[k];
+                if (std::fabs(C.val[k]) > THRE || j == gi) {
+                    if (j == gi) { has_diag = true; diag_pos = q; }
+                    ncol[(size_t)q] = j; nval[(size_t)q] = C.val[k]; ++q;
+                } else {
+                    add2diag += C.val[k];
+                }
+            }
+            if (has_diag) {
+                nval[(size_t)diag_pos] += add2diag;
+                if (std::fabs(nval[(size_t)diag_pos]) < SAENA_ALMOST_ZERO) nval[(size_t)diag_pos] = 1.0;
+            } else {
+                nnz_t pos = nptr[(size_t)i];
+                while (pos < q && ncol[(size_t)pos] < gi) ++pos;
+                for (nnz_t m = q; m > pos; --m) { ncol[(size_t)m] = ncol[(size_t)m - 1]; nval[(size_t)m] = nval[(size_t)m - 1]; }
+                ncol[(size_t)pos] = gi; nval[(size_t)pos] = 1.0;
+                placed = true;
+            }
+            (void)placed;
+        }
+    });
     C.ptr.swap(nptr); C.col.swap(ncol); C.val.swap(nval);
 }
 
@@ -562,6 +623,7 @@ int amg_hierarchy::coarsen(int l) {
         parallel_rows(A.M, &Ac_.ptr, [&](int t, index_t lo, index_t hi) {
             tlo[t] = lo;
             std::vector<std::pair<index_t, value_t>> row;
+            std::vector<std::pair<long, value_t>> sort_scratch;
             for (index_t i = lo; i < hi; ++i) {
                 row.clear();
                 for (nnz_t k = Ac_.ptr[i]; k < Ac_.ptr[i + 1]; ++k) {
@@ -569,7 +631,7 @@ int amg_hierarchy::coarsen(int l) {
                     if (i == Ac_.col[k]) vtmp += 1;                      // I in (I - w Q A)
                     row.emplace_back(agg[Ac_.col[k]], vtmp);
                 }
-                std::stable_sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+                stable_sort_by_first(row, sort_scratch);
                 nnz_t cnt = 0;
                 for (size_t q = 0; q < row.size(); ++q) {                // setup1:205-217 add duplicates, drop ~0
                     value_t v = row[q].second;
@@ -1079,13 +1141,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         for (index_t j = nloc; j < next; ++j) st[j] = AggState{planA.wanted[(size_t)(j - nloc)], 0, 0, {0, 0}};
         std::vector<nnz_t> tptr((size_t)next + 1, 0);               // who looks at ext position e: the transposed pattern
         std::vector<index_t> tcol(scol.size());
-        for (index_t e : scol) tptr[(size_t)e + 1]++;
-        for (index_t e = 0; e < next; ++e) tptr[e + 1] += tptr[e];
-        {
-            std::vector<nnz_t> fill(tptr.begin(), tptr.end() - 1);
-            for (index_t i = 0; i < nloc; ++i)
-                for (nnz_t it = sptr[i]; it < sptr[i + 1]; ++it) tcol[fill[scol[it]]++] = i;
-        }
+        transpose_pattern(nloc, next, sptr, scol, tptr, tcol);
         std::vector<index_t> aggregate2((size_t)nloc);
         std::vector<char> dec_nei((size_t)nloc, 0), is_root_nei((size_t)nloc, 0), queued((size_t)nloc, 1);
         std::vector<index_t> work((size_t)nloc);
@@ -1215,6 +1271,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             parallel_rows(nloc, &A.ptr, [&](int t, index_t r0, index_t r1) {
                 tlo[(size_t)t] = r0; thi[(size_t)t] = r1;
                 std::vector<std::pair<index_t, value_t>> row;
+                std::vector<std::pair<long, value_t>> sort_scratch;
                 auto &oc = tcol[(size_t)t];
                 auto &ov = tval[(size_t)t];
                 for (index_t i = r0; i < r1; ++i) {
@@ -1224,7 +1281,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                         if (i + lo == A.col[k]) vtmp += 1;
                         row.emplace_back(aggcExt[(size_t)aext[(size_t)k]], vtmp);
                     }
-                    std::stable_sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+                    stable_sort_by_first(row, sort_scratch);
                     nnz_t cnt = 0;
                     for (size_t q = 0; q < row.size(); ++q) {
                         value_t v = row[q].second;
