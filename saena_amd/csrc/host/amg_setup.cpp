@@ -1274,6 +1274,8 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                 std::vector<std::pair<long, value_t>> sort_scratch;
                 auto &oc = tcol[(size_t)t];
                 auto &ov = tval[(size_t)t];
+                oc.reserve((size_t)(A.ptr[r1] - A.ptr[r0]) / 2 + 16);      // (P holds at most A's entries; growing by doubling re-touches gigabytes)
+                ov.reserve(oc.capacity());
                 for (index_t i = r0; i < r1; ++i) {
                     row.clear();
                     for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
