@@ -130,7 +130,9 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
  * qualify for 9 and whose rows follow few enough patterns for a table of 4096 ints: stencils on structured grids, band
  * matrices; the local loop of src/saena_matrix_matvec.cpp:68-80 with the same sequential row sum); 12 k_sellx: sliced
  * ELLPACK inside the (row chunk, column window) blocks of the x-in-LDS plan, a lane per row piece (rows of a few hundred
- * entries; at most 25 % padding).  7, 8, 9, 11 and 12 are
+ * entries; at most 25 % padding); 13 k_rowt: row templates -- rows that repeat (length, relative columns, values) served
+ * from a table in LDS, a 16-bit template id per row and nothing else of the operator (constant-coefficient stencils; never
+ * chosen by the autotune unless SAENA_ROW_TEMPLATES=1).  7, 8, 9, 11, 12 and 13 are
  * built from a host copy of the values that the library keeps only until the plan-time autotune (SGPU_ERR_ARG
  * afterwards, and where the form does not apply) */
 int sgpu_op_set_variant(sgpu_op *op, int variant);

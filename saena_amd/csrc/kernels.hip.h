@@ -714,6 +714,48 @@ __global__ __launch_bounds__(BLOCK) void k_sellp(const SpmvArgs a, int nrows) {
 }
 
 // ---------------------------------------------------------------------------
+// K1t: row templates -- k_sellp taken one step further, for operators whose rows repeat patterns AND values (constant-
+// coefficient stencils on structured grids: the boundary-stripped 7-point Laplacian has 27 distinct rows, whatever its size).
+// A template is (length, columns relative to the row, values); the table sits in LDS, a thread owns a row and reads NOTHING of
+// the operator but its 16-bit template id: 2 B per row instead of 8 B per entry + 2 B per row.  Same products, same sequential
+// sum as the CSR loop (the template's values are the row's values bit for bit): bit-identical results.
+// OPT-IN (SAENA_ROW_TEMPLATES=1 adds it to the plan-time autotune): the contract's algorithmic bytes count 12 B per entry, which
+// this kernel does not move -- its rate in those units says nothing about the memory system.
+// a.dst: template ids, a.ptab: pt_n x (pt_w + 1) ints (length, offsets), a.val: pt_n x pt_w doubles (the templates' values).
+template <int EPI, bool HALO, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_rowt(const SpmvArgs a, int nrows) {
+    extern __shared__ double rt_lds[];
+    if constexpr (HALO) fork_signal(a);
+    double *vt = rt_lds;                                           // [pt_n][pt_w]
+    int    *it = reinterpret_cast<int *>(rt_lds + (size_t)a.pt_n * a.pt_w);       // [pt_n][pt_w + 1]
+    for (int i = threadIdx.x; i < a.pt_n * a.pt_w; i += BLOCK) vt[i] = a.val[i];
+    for (int i = threadIdx.x; i < a.pt_n * (a.pt_w + 1); i += BLOCK) it[i] = a.ptab[i];
+    __syncthreads();
+    const int b = xcd_remap(blockIdx.x, (nrows + BLOCK - 1) / BLOCK);
+    const int r = b * BLOCK + (int)threadIdx.x;
+    if (r >= nrows) return;
+    int pid;
+    if constexpr (NT) pid = __builtin_nontemporal_load(a.dst + r); else pid = a.dst[r];
+    const int *pt = it + pid * (a.pt_w + 1);
+    const double *pv = vt + pid * a.pt_w;
+    const int len = pt[0];
+    double sum = 0.0;
+    for (int j = 0; j < len; j += 8) {
+        double xx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                              // (clamped table position, address 0 past the row's end: no branch per entry)
+            const int jj = j + u < a.pt_w ? j + u : a.pt_w - 1;
+            const int c = r + pt[1 + jj];
+            xx[u] = a.x[j + u < len ? c : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j + u < len) sum += pv[j + u < a.pt_w ? j + u : a.pt_w - 1] * xx[u];
+    }
+    epilogue<EPI, HALO, NT>(a, r, sum);
+}
+
+// ---------------------------------------------------------------------------
 // K1b: vector CSR (no LDS staging): G lanes own one row and stream it straight from
 // global memory, 256/G rows per workgroup.  Rows are contiguous in val/col, so a
 // wave still reads whole 128-B lines; there is no barrier and no LDS round trip.

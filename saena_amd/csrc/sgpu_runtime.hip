@@ -193,6 +193,14 @@ struct CsrPart {
         hipFree(xl_col); hipFree(xl_blk); hipFree(xl_tab); hipFree(xl_info); hipFree(xl_acc);
         xl_col = nullptr; xl_blk = xl_tab = nullptr; xl_info = nullptr; xl_acc = nullptr; xl_ok = false; xl_tried = 0;
     }
+    // row templates (variant 13, k_rowt, opt-in): a template id per row; tables of (length, relative columns) and of values
+    unsigned short *rt_pat = nullptr;
+    int            *rt_itab = nullptr;
+    double         *rt_vtab = nullptr;
+    int             rt_w = 0, rt_n = 0;
+    bool            rt_ok = false;
+    char            rt_tried = 0;
+    void free_rowt() { hipFree(rt_pat); hipFree(rt_itab); hipFree(rt_vtab); rt_pat = nullptr; rt_itab = nullptr; rt_vtab = nullptr; rt_ok = false; rt_tried = 0; }
     // sliced ELLPACK inside the (chunk, window) blocks of the x-in-LDS form (variant 12, k_sellx): shares xl_blk / xl_info / xl_acc
     double         *sx_val = nullptr;
     unsigned short *sx_col = nullptr;
@@ -217,6 +225,7 @@ struct CsrPart {
         free_sell();
         free_xlds();
         free_sellx();
+        free_rowt();
     }
 };
 
@@ -623,6 +632,58 @@ int build_sellp(CsrPart &P) {
     return SGPU_OK;
 }
 
+// Row templates (k_rowt): every row as (length, columns relative to the row, values); the operator qualifies when its rows
+// follow at most 65 535 templates whose tables fit 32 KiB of LDS.  Ids in order of first appearance.
+constexpr int RT_MAX_BYTES = 32768;
+int build_rowt(CsrPart &P, const std::vector<double> &h_val_all) {
+    if (P.rt_ok || P.rt_tried || P.h_rp.empty()) return SGPU_OK;
+    P.rt_tried = 1;
+    const int M = P.nrows;
+    if (M == 0 || h_val_all.size() != P.h_col.size()) return SGPU_OK;
+    int W = 1;
+    for (int r = 0; r < M; ++r) W = std::max(W, P.h_rp[(size_t)r + 1] - P.h_rp[(size_t)r]);
+    const int per = (W + 1) * 4 + W * 8;
+    if (per > RT_MAX_BYTES) return SGPU_OK;
+    const int max_pat = std::min(65535, RT_MAX_BYTES / per);
+    std::vector<int> itab;
+    std::vector<double> vtab;
+    std::vector<unsigned short> pat((size_t)M, 0);
+    std::unordered_map<std::string, int> ids;
+    std::string key;
+    int prev = -1, npat = 0;
+    for (int r = 0; r < M; ++r) {
+        const int p0 = P.h_rp[(size_t)r], n = P.h_rp[(size_t)r + 1] - p0;
+        if (prev >= 0 && itab[(size_t)prev * (W + 1)] == n) {          // most rows repeat the row before
+            const int *t = &itab[(size_t)prev * (W + 1) + 1];
+            const double *v = &vtab[(size_t)prev * W];
+            int j = 0;
+            while (j < n && P.h_col[(size_t)p0 + j] - r == t[j] && std::memcmp(&h_val_all[(size_t)p0 + j], &v[j], 8) == 0) ++j;
+            if (j == n) { pat[(size_t)r] = (unsigned short)prev; continue; }
+        }
+        key.assign(reinterpret_cast<const char *>(&n), sizeof n);
+        for (int j = 0; j < n; ++j) { const int o = P.h_col[(size_t)p0 + j] - r; key.append(reinterpret_cast<const char *>(&o), sizeof o); }
+        key.append(reinterpret_cast<const char *>(&h_val_all[(size_t)p0]), (size_t)n * 8);
+        auto f = ids.find(key);
+        if (f == ids.end()) {
+            if (npat == max_pat) return SGPU_OK;                       // too many distinct rows: not this kind of operator
+            f = ids.emplace(key, npat++).first;
+            itab.push_back(n);
+            for (int j = 0; j < W; ++j) itab.push_back(j < n ? P.h_col[(size_t)p0 + j] - r : 0);
+            for (int j = 0; j < W; ++j) vtab.push_back(j < n ? h_val_all[(size_t)p0 + j] : 0.0);
+        }
+        prev = f->second;
+        pat[(size_t)r] = (unsigned short)prev;
+    }
+    if (npat == 0) return SGPU_OK;
+    if (std::getenv("SAENA_SETUP_TIMING")) fprintf(stderr, "[sgpu] row templates: %d rows follow %d templates of <= %d entries\n", M, npat, W);
+    CHK(dev_upload(&P.rt_pat, pat.data(), pat.size()));
+    CHK(dev_upload(&P.rt_itab, itab.data(), itab.size()));
+    CHK(dev_upload(&P.rt_vtab, vtab.data(), vtab.size()));
+    P.rt_w = W; P.rt_n = npat;
+    P.rt_ok = true;
+    return SGPU_OK;
+}
+
 // Sliced ELLPACK inside the (row chunk, column window) blocks of the x-in-LDS plan (k_sellx): per block the rows with a piece
 // in that window (every row in the chunk's last window), sorted by piece length, 64 to a slice, position-major in pairs.
 // Built where it can pay: at most 25 % padding, chunks of at most 65 534 rows.
@@ -927,6 +988,18 @@ XldsKernelFn pick_xlds_h(int epi, int lanes) {
         default:               return pick_xlds_g<sk::EPI_SUB, HALO>(lanes);
     }
 }
+template <bool HALO, bool NT>
+SellKernelFn pick_rowt_h(int epi) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return sk::k_rowt<sk::EPI_SPMV, HALO, NT>;
+        case sk::EPI_RESIDUAL: return sk::k_rowt<sk::EPI_RESIDUAL, HALO, NT>;
+        case sk::EPI_JACOBI:   return sk::k_rowt<sk::EPI_JACOBI, HALO, NT>;
+        case sk::EPI_CHEBY0:   return sk::k_rowt<sk::EPI_CHEBY0, HALO, NT>;
+        case sk::EPI_CHEBYK:   return sk::k_rowt<sk::EPI_CHEBYK, HALO, NT>;
+        case sk::EPI_RSWEEP:   return sk::k_rowt<sk::EPI_RSWEEP, HALO, NT>;
+        default:               return sk::k_rowt<sk::EPI_SUB, HALO, NT>;
+    }
+}
 using SellxKernelFn = void (*)(const sk::SpmvArgs, const sk::SellxArgs);
 template <bool HALO>
 SellxKernelFn pick_sellx_h(int epi) {
@@ -963,6 +1036,14 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
             : epi == sk::EPI_JACOBI ? sk::k_dense_rows<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows<sk::EPI_CHEBY0>
             : epi == sk::EPI_CHEBYK ? sk::k_dense_rows<sk::EPI_CHEBYK> : epi == sk::EPI_RSWEEP ? sk::k_dense_rows<sk::EPI_RSWEEP> : sk::k_dense_rows<sk::EPI_SUB>;
         SGPU_LAUNCH(kd, dim3((P.nrows + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, (const double *)P.dense, P.nrows, P.ncols);
+    } else if (P.variant == 13) {                                 // row templates: a thread per row, no operator stream at all
+        if (!P.rt_ok) return fail(SGPU_ERR_STATE, "the row-template form was not built");
+        a.blk_row = nullptr; a.nblk = 0;
+        a.val = P.rt_vtab; a.dst = P.rt_pat; a.ptab = P.rt_itab; a.pt_w = P.rt_w; a.pt_n = P.rt_n;
+        const bool nt = 26 * (int64_t)P.nrows > (int64_t)256 * 1024 * 1024;       // ids + x + y (+ rhs) beyond the Infinity Cache
+        const size_t lds = (size_t)P.rt_n * ((size_t)P.rt_w * 8 + (size_t)(P.rt_w + 1) * 4);
+        SellKernelFn k = halo ? (nt ? pick_rowt_h<true, true>(epi) : pick_rowt_h<true, false>(epi)) : (nt ? pick_rowt_h<false, true>(epi) : pick_rowt_h<false, false>(epi));
+        SGPU_LAUNCH(k, dim3((P.nrows + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), lds, g.cs, a, P.nrows);
     } else if (P.variant == 12) {                                 // sliced ELLPACK in the LDS windows, a workgroup per CU
         if (!P.sx_ok || !P.xl_ok) return fail(SGPU_ERR_STATE, "the sliced-ELLPACK-in-LDS form was not built");
         a.blk_row = P.xl_blk; a.nblk = P.xl_nblk;
@@ -1764,7 +1845,7 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx"};   // (3, 4, 7, 8 are named with their slot/offset split below)
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx", "k_rowt"};   // (3, 4, 7, 8 are named with their slot/offset split below)
     if (variant) *variant = op->loc.variant;
     if (kernel_name) {
         const int v = op->loc.variant;
@@ -1783,7 +1864,13 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 12) return fail(SGPU_ERR_ARG, "variant must be 0..12");
+    if (variant < 0 || variant > 13) return fail(SGPU_ERR_ARG, "variant must be 0..13");
+    if (variant == 13) {
+        CHK(build_rowt(op->loc, op->h_val_all));
+        if (!op->loc.rt_ok)
+            return fail(SGPU_ERR_ARG, "the row-template form needs rows that repeat at most %d bytes' worth of (length, relative columns, values) templates "
+                                      "and the host copy of the values (kept until the plan-time autotune, or with SAENA_KEEP_HOST_VALUES=1)", RT_MAX_BYTES);
+    }
     if (variant == 12) {
         CHK(build_xlds(op->loc));
         CHK(build_sellx(op->loc, op->h_val_all));
@@ -1882,7 +1969,7 @@ bool plan_cache_lookup(uint64_t key, int *v, int *lanes) {
     bool hit = false;
     while (fgets(line, sizeof line, f)) {               // the last line of a key wins
         unsigned long long k; int vv, ll;
-        if (sscanf(line, "%llx %d %d", &k, &vv, &ll) == 3 && k == key && vv >= 0 && vv <= 12 && ll >= 1 && ll <= 64) { *v = vv; *lanes = ll; hit = true; }
+        if (sscanf(line, "%llx %d %d", &k, &vv, &ll) == 3 && k == key && vv >= 0 && vv <= 13 && ll >= 1 && ll <= 64) { *v = vv; *lanes = ll; hit = true; }
     }
     fclose(f);
     return hit;
@@ -1910,6 +1997,7 @@ void finish_plan(sgpu_op *op, int bv) {
     if (bv != 9 && bv != 11 && !keep) op->loc.free_sell();
     else if (bv == 11 && !keep) op->loc.free_sell_columns();    // k_sellp keeps the values and the slice pointers only
     else if (bv == 9 && !keep) op->loc.free_sellp();
+    if (bv != 13 && !keep) op->loc.free_rowt();
     if (bv != 12 && !keep) op->loc.free_sellx();
     if (bv != 10 && bv != 12 && !keep) op->loc.free_xlds();
     else if (bv == 12 && !keep) { hipFree(op->loc.xl_col); hipFree(op->loc.xl_tab); op->loc.xl_col = nullptr; op->loc.xl_tab = nullptr; }      // k_sellx keeps the chunk plan only
@@ -1921,7 +2009,7 @@ void finish_plan(sgpu_op *op, int bv) {
         }
 }
 // does the form add a row's products one after the other in column order (the reference's sum, whatever else is tuned)?
-bool sequential_sum(int v, int lanes) { return v == 9 || v == 11 || (lanes == 1 && (v == 0 || v == 1 || v == 3 || v == 4 || v == 7 || v == 8)); }
+bool sequential_sum(int v, int lanes) { return v == 9 || v == 11 || v == 13 || (lanes == 1 && (v == 0 || v == 1 || v == 3 || v == 4 || v == 7 || v == 8)); }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 } // namespace
 
@@ -1973,6 +2061,10 @@ int sgpu_op_autotune(sgpu_op *op) {
             if (!std::getenv("SAENA_NO_SELLP")) {                                                    // rows that repeat a few patterns: no column stream
                 CHK(build_sellp(op->loc));
                 if (op->loc.sp_ok) variants.push_back(11);
+                if (op->loc.sp_ok && std::getenv("SAENA_ROW_TEMPLATES")) {                               // OPT-IN: rows that also repeat their values
+                    CHK(build_rowt(op->loc, op->h_val_all));
+                    if (op->loc.rt_ok) variants.push_back(13);
+                }
             }
         }
     }
@@ -2027,7 +2119,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     std::vector<std::pair<int, int>> cands;
     for (int v : variants)
         for (int gl : (v == 10 ? lanes_x : lanes)) {
-            if ((v == 9 || v == 11 || v == 12) && gl != lanes.front()) continue;      // a lane per row (piece) whatever the setting
+            if ((v == 9 || v == 11 || v == 12 || v == 13) && gl != lanes.front()) continue;      // a lane per row (piece) whatever the setting
             if (v == 5 && gl != lanes.front()) continue;                   // one wave per dense row likewise
             cands.push_back({v, gl});
         }

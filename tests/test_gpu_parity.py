@@ -744,6 +744,39 @@ def test_multirank_library_against_compiled_reference_golden(fixture):
         assert res.get(r) == "ok", f"rank {r}: {res.get(r)}"
 
 
+@pytest.mark.parametrize("name", ["poisson12", "poisson20", "band300_7", "irregular5000"])
+def test_row_templates(capi, name, monkeypatch):
+    """k_rowt (opt-in): rows that repeat (length, relative columns, values) -- the boundary-stripped Laplacian has 27 distinct rows --
+    are served from a table in LDS, the kernel reads a 16-bit template id per row and nothing else of the operator: bit-identical
+    to the CSR loop for every epilogue; an operator whose rows do not repeat is refused."""
+    monkeypatch.setenv("SAENA_KEEP_HOST_VALUES", "1")
+    entries, M = get_problem(name)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    if not name.startswith("poisson"):
+        with pytest.raises(capi.SgpuError, match="row-template"):
+            G.set_variant(13)
+        return
+    G.set_variant(13)
+    assert G.variant()[1] == "k_rowt"
+    x, rhs = inputs.v2(M), inputs.rhs2(M)
+    dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
+    G.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), A.matvec(x))
+    G.residual(dx, dr, dy)
+    np.testing.assert_array_equal(dy.download(), A.residual(x, rhs))
+    du = capi.DeviceVector(M, x)
+    G.jacobi(3, du, dr)
+    np.testing.assert_array_equal(du.download(), A.jacobi(3, x, rhs))
+    A.set_eig(1.9371)
+    du = capi.DeviceVector(M, x)
+    G.chebyshev(3, 1.9371, du, dr)
+    assert rel(du.download(), A.chebyshev(3, x, rhs)) <= TOL_SMOOTH
+    du = capi.DeviceVector(M, rhs)
+    G.prolong_correct(dx, du)
+    np.testing.assert_array_equal(du.download(), rhs - A.matvec(x))
+
+
 def test_plan_cache_makes_a_second_operator_take_the_first_one_s_plan(capi, tmp_path, monkeypatch):
     """The plan-time autotune writes its choice to the plan cache; an operator of the same shape created afterwards (here:
     in the same process, in production: by a later process) takes the plan from there without a sweep -- same kernel,
