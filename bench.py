@@ -239,7 +239,7 @@ def pmc_traffic(m, world, kernel_name):
     """Memory-side bytes per launch from the COMMITTED rocprofv3 PMC passes of this same command (PMC counters cannot
     be read from inside the process, so this is never a measurement of the present run: the line says so with
     `traffic_measured_in_run: false`).  Only for the kernel those passes profiled; None for anything else."""
-    table = {"k_sellp": "r03_pmc_spmv_128_sellp.json", "k_sell": "r02_pmc_spmv_128_sell.json", "k_csr_cc16<16KiB,4+12>": "r02_pmc_spmv_128_cc16.json",
+    table = {"k_sellp": "r03_pmc_spmv_128_sellp.json", "k_sellp2": "r03_pmc_spmv_128_sellp2.json", "k_sell": "r02_pmc_spmv_128_sell.json", "k_csr_cc16<16KiB,4+12>": "r02_pmc_spmv_128_cc16.json",
              "k_csr_stream<16KiB>": "r01_pmc_spmv_128.json"}
     name = table.get(kernel_name)
     path = os.path.join(ROOT, "profiles", name) if name else None
@@ -306,7 +306,7 @@ def measure_spmv(capi, host, np, A, rank, steps, warmup, sync_all):
 def stored_bytes(info, kernel_name):
     """bytes the SpMV's operands occupy in HBM: values, column ids as the chosen kernel stores them, row pointers, x, y"""
     nnz = info["nnz_local"] + info["nnz_remote"]
-    if kernel_name == "k_sellp":                         # no column stream: a 16-bit pattern id per row (+ a table of a few hundred ints)
+    if kernel_name in ("k_sellp", "k_sellp2"):           # no column stream: a 16-bit pattern id per row (+ a table of a few hundred ints)
         return 8 * nnz + 2 * info["M"] + 8 * info["N_local"] + 8 * info["M"]
     if kernel_name == "k_sell":                          # 16-bit column codes, a 16-bit row length instead of the row pointer (padding < 1 % here)
         return 10 * nnz + 2 * info["M"] + 8 * info["N_local"] + 8 * info["M"]
@@ -478,11 +478,11 @@ def main():
                               "max over all ranks of max_i |y_gpu - y_host| / max_i sum_j |a_ij x_j|",
                       "max_rel_err": err, "ok": bool(err <= 1e-13)},
             "roofline": {
-                "bound": "hbm", "kernel": f"{kernel_name}, {1 if kernel_name in ('k_sell', 'k_sellp') else info['lanes_per_row']} lane(s)/row",
+                "bound": "hbm", "kernel": f"{kernel_name}, {1 if kernel_name in ('k_sell', 'k_sellp') else 0.5 if kernel_name == 'k_sellp2' else info['lanes_per_row']} lane(s)/row",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "us_per_launch": round(ms_kernel * 1e3, 3), "algorithmic_bytes": B_local,
-                "working_set_bytes": ws, "cache_resident": bool(ws <= INFINITY_CACHE_BYTES),
+                "working_set_bytes": ws, "stored_bytes_rate_gbs": round(ws / (ms_kernel * 1e-3) / 1e9, 2), "cache_resident": bool(ws <= INFINITY_CACHE_BYTES),
                 "note": ("the operator and vectors fit the 256 MiB Infinity Cache: repeated launches are served by it, so `achieved` "
                          "can exceed what HBM alone sustains (~6.1 TB/s reads); see spmv_hbm_resident for the HBM-bound figure"
                          if ws <= INFINITY_CACHE_BYTES else "working set beyond the 256 MiB Infinity Cache: HBM-bound"),
@@ -502,13 +502,14 @@ def main():
         ws3 = stored_bytes(R3["info"], R3["kernel_name"])
         out["spmv_hbm_resident"] = {
             "workload": f"Poisson {args.m_hbm}^3: {R3['info']['M']} rows x {R3['info']['nnz_local']} nnz, same kernel path",
-            "kernel": f"{R3['kernel_name']}, {1 if R3['kernel_name'] in ('k_sell', 'k_sellp') else R3['info']['lanes_per_row']} lane(s)/row", "steps": steps3, "warmup": warm3,
+            "kernel": f"{R3['kernel_name']}, {1 if R3['kernel_name'] in ('k_sell', 'k_sellp') else 0.5 if R3['kernel_name'] == 'k_sellp2' else R3['info']['lanes_per_row']} lane(s)/row", "steps": steps3, "warmup": warm3,
             "us_per_launch": round(R3["ms_kernel"] * 1e3, 3), "algorithmic_bytes": R3["B_local"], "working_set_bytes": ws3,
+            "stored_bytes_rate_gbs": round(ws3 / (R3["ms_kernel"] * 1e-3) / 1e9, 2),
             "cache_resident": bool(ws3 <= INFINITY_CACHE_BYTES), "achieved": round(a3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(a3 / HBM_PEAK_GBS, 4), "check_max_rel_err": e3,
         }
         # bytes leaving the L2 per launch from the COMMITTED PMC passes of this leg (tools/pmc_spmv_hbm.sh), same kernel only
-        pmc_name = {"k_sellp": "r03_pmc_spmv_256_sellp.json"}.get(R3["kernel_name"], "r02_pmc_spmv_256_cc16.json" if "k_csr_cc16" in R3["kernel_name"] else None)
+        pmc_name = {"k_sellp": "r03_pmc_spmv_256_sellp.json", "k_sellp2": "r03_pmc_spmv_256_sellp2.json"}.get(R3["kernel_name"], "r02_pmc_spmv_256_cc16.json" if "k_csr_cc16" in R3["kernel_name"] else None)
         pmc3 = os.path.join(ROOT, "profiles", pmc_name) if pmc_name else None
         if args.m_hbm == 256 and pmc3 and os.path.exists(pmc3):
             with open(pmc3) as f:

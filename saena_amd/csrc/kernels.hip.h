@@ -161,8 +161,41 @@ __device__ __forceinline__ void epilogue(const SpmvArgs &a, int r, double s) {
 // data would not sweep the x lines out of L1.  Measured on the 256^3 hierarchy (profiles/r02_perf_levels_256_nt.log):
 // every level got SLOWER (L0 335 -> 381 us, L1 1327 -> 1534 us, L2 629 -> 678 us), so plain loads stay the default.
 typedef double   sk_d2v __attribute__((ext_vector_type(2)));
+typedef double   sk_d2v8 __attribute__((ext_vector_type(2), aligned(8)));      // the same, promised 8-byte alignment only
 typedef int      sk_i4v __attribute__((ext_vector_type(4)));
 typedef unsigned sk_u2v __attribute__((ext_vector_type(2)));
+// the same for the two consecutive rows r (even) and r + 1 of one lane: 16-byte loads and stores, the arithmetic of epilogue<> per row
+template <bool NT>
+__device__ __forceinline__ sk_d2v ld_once2(const double *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const sk_d2v *>(p));
+    else return *reinterpret_cast<const sk_d2v *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st_once2(double *p, sk_d2v v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<sk_d2v *>(p));
+    else *reinterpret_cast<sk_d2v *>(p) = v;
+}
+template <int EPI, bool NT>
+__device__ __forceinline__ void epilogue2(const SpmvArgs &a, int r, double s0, double s1) {
+    sk_d2v s; s.x = s0; s.y = s1;
+    if constexpr (EPI == EPI_SPMV) {
+        st_once2<NT>(a.y + r, s);
+    } else if constexpr (EPI == EPI_RESIDUAL) {
+        const sk_d2v b = ld_once2<NT>(a.rhs + r);
+        sk_d2v o; o.x = s.x - b.x; o.y = s.y - b.y;
+        st_once2<NT>(a.y + r, o);
+    } else if constexpr (EPI == EPI_JACOBI) {
+        const sk_d2v b = ld_once2<NT>(a.rhs + r), dg = ld_once2<NT>(a.inv_diag + r), u = *reinterpret_cast<const sk_d2v *>(a.u + r);
+        double t0 = s.x - b.x, t1 = s.y - b.y;
+        t0 *= dg.x * a.c0; t1 *= dg.y * a.c0;
+        sk_d2v o; o.x = u.x - t0; o.y = u.y - t1;
+        st_once2<NT>(a.y + r, o);
+    } else {                                                      // the remaining forms: per row
+        epilogue<EPI, false, NT>(a, r, s0);
+        epilogue<EPI, false, NT>(a, r + 1, s1);
+    }
+}
+
 // `nt` is a launch argument (SpmvArgs::nt), uniform over the grid: a non-temporal load where the launch asks for it
 __device__ __forceinline__ double2 ld_stream_d2(const double *p, int nt) {
     sk_d2v v;
@@ -711,6 +744,82 @@ __global__ __launch_bounds__(BLOCK) void k_sellp(const SpmvArgs a, int nrows) {
         if ((w & 1) && w - 1 < len) sum += vt * xt;
     }
     if (r < nrows) epilogue<EPI, HALO, NT>(a, r, sum);
+}
+
+// ---------------------------------------------------------------------------
+// K1q: k_sellp with a lane owning TWO consecutive rows.  On the 7-point level a gather instruction of k_sellp moves 64
+// consecutive doubles, and its cost is per INSTRUCTION (~20 ns per instruction and CU whatever the 64 addresses are,
+// profiles/r02_gather_bench.log): 7 gathers per 64 rows are ~17 us of the cache-resident 128^3 operator's 23 us.  Rows r and
+// r + 1 of a stencil follow the same pattern almost always (a grid line ends every 254 rows), so their columns r + o and r + 1 + o
+// are adjacent: ONE 16-byte load serves both, and the values of the two rows at position j sit side by side for one 16-byte
+// load as well (slices of 128 rows, position-major: [j][lane][row 2 lane, row 2 lane + 1]).  Half the gather instructions, the
+// same bytes, the same sequential sum per row: bit-identical to k_sellp.  Lanes whose two rows differ in pattern (1 % of them)
+// take two 8-byte gathers.
+// a.val: the row-paired values, a.cmptr: slice starts (multiples of 128), a.dst: pattern ids, a.ptab / pt_w / pt_n: the table,
+// a.nblk: slices of 128 rows.
+template <int EPI, bool HALO, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
+    extern __shared__ int ptab_lds[];
+    if constexpr (HALO) fork_signal(a);
+    {
+        const int tn = a.pt_n * (a.pt_w + 1);
+        for (int i = threadIdx.x; i < tn; i += BLOCK) ptab_lds[i] = a.ptab[i];
+    }
+    __syncthreads();
+    constexpr int SPB = BLOCK / 64;
+    const int b = xcd_remap(blockIdx.x, (a.nblk + SPB - 1) / SPB);
+    const int s = __builtin_amdgcn_readfirstlane(b * SPB + ((int)threadIdx.x >> 6));
+    if (s >= a.nblk) return;
+    const int lane = threadIdx.x & 63;
+    const int rA = s * 128 + 2 * lane, rB = rA + 1;
+    const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 7;
+    unsigned ids = 0;
+    if (rA < nrows) {                                               // (the id array is padded to a multiple of 128 rows)
+        const unsigned *ip = reinterpret_cast<const unsigned *>(a.dst) + (rA >> 1);
+        if constexpr (NT) ids = __builtin_nontemporal_load(ip); else ids = *ip;
+    }
+    const int pidA = (int)(ids & 0xffffu), pidB = (int)(ids >> 16);
+    const int *ptA = ptab_lds + pidA * (a.pt_w + 1), *ptB = ptab_lds + pidB * (a.pt_w + 1);
+    const int lenA = rA < nrows ? ptA[0] : 0, lenB = rB < nrows ? ptB[0] : 0;
+    ++ptA; ++ptB;
+    const bool same = pidA == pidB && rB < nrows;                 // the two rows read adjacent columns at every position
+    const int wmax = a.pt_w - 1;
+    const sk_d2v *v2 = reinterpret_cast<const sk_d2v *>(a.val + p) + lane;
+    double sumA = 0.0, sumB = 0.0;
+    for (int j = 0; j < w; j += 8) {
+        sk_d2v vv[8];
+        double xa[8], xb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const sk_d2v *vp = v2 + (j + u < w ? j + u : w - 1) * 64;
+            if constexpr (NT) vv[u] = __builtin_nontemporal_load(vp); else vv[u] = *vp;
+        }
+        if (same) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = rA + ptA[j + u < wmax ? j + u : wmax];
+                const sk_d2v8 xx = *reinterpret_cast<const sk_d2v8 *>(a.x + (j + u < lenA ? c : 0));     // a 16-byte load at an 8-byte aligned address
+                xa[u] = xx.x; xb[u] = xx.y;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jj = j + u < wmax ? j + u : wmax;
+                xa[u] = a.x[j + u < lenA ? rA + ptA[jj] : 0];
+                xb[u] = a.x[j + u < lenB ? rB + ptB[jj] : 0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (j + u < lenA) sumA += vv[u].x * xa[u];
+            if (j + u < lenB) sumB += vv[u].y * xb[u];
+        }
+    }
+    if constexpr (!HALO) {
+        if (rB < nrows) { epilogue2<EPI, NT>(a, rA, sumA, sumB); return; }       // rows 2 l and 2 l + 1: 16-byte loads and stores
+    }
+    if (rA < nrows) epilogue<EPI, HALO, NT>(a, rA, sumA);
+    if (rB < nrows) epilogue<EPI, HALO, NT>(a, rB, sumB);
 }
 
 // ---------------------------------------------------------------------------

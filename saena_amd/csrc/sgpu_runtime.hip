@@ -193,6 +193,13 @@ struct CsrPart {
         hipFree(xl_col); hipFree(xl_blk); hipFree(xl_tab); hipFree(xl_info); hipFree(xl_acc);
         xl_col = nullptr; xl_blk = xl_tab = nullptr; xl_info = nullptr; xl_acc = nullptr; xl_ok = false; xl_tried = 0;
     }
+    // k_sellp with a lane per two rows (variant 14, k_sellp2): the values row-paired in slices of 128 rows; shares sp_pat / sp_tab
+    double         *sp2_val = nullptr;
+    int            *sp2_ptr = nullptr;
+    int             sp2_nslices = 0;
+    bool            sp2_ok = false;
+    char            sp2_tried = 0;
+    void free_sellp2() { hipFree(sp2_val); hipFree(sp2_ptr); sp2_val = nullptr; sp2_ptr = nullptr; sp2_ok = false; sp2_tried = 0; }
     // row templates (variant 13, k_rowt, opt-in): a template id per row; tables of (length, relative columns) and of values
     unsigned short *rt_pat = nullptr;
     int            *rt_itab = nullptr;
@@ -226,6 +233,7 @@ struct CsrPart {
         free_xlds();
         free_sellx();
         free_rowt();
+        free_sellp2();
     }
 };
 
@@ -598,7 +606,7 @@ int build_sellp(CsrPart &P) {
     if (W + 1 > SP_MAX_TABLE) return SGPU_OK;
     const int max_pat = std::min(65535, SP_MAX_TABLE / (W + 1));
     std::vector<int> tab;                                      // patterns back to back, W + 1 ints each
-    std::vector<unsigned short> pat(((size_t)M + 63) / 64 * 64, 0);
+    std::vector<unsigned short> pat(((size_t)M + 127) / 128 * 128, 0);
     std::unordered_map<std::string, int> ids;
     std::string key;
     int prev = -1, npat = 0;
@@ -629,6 +637,39 @@ int build_sellp(CsrPart &P) {
     P.sp_w = W; P.sp_n = npat;
     P.sp_bytes = 8 * (int64_t)P.h_rp.back() + 2 * (int64_t)M + 8 * (int64_t)P.ncols + 8 * (int64_t)M;
     P.sp_ok = true;
+    return SGPU_OK;
+}
+
+// The row-paired values of k_sellp2 on top of build_sellp's pattern ids: slices of 128 rows, a slice padded to its longest
+// row, position-major with the values of rows 2 l and 2 l + 1 side by side.
+int build_sellp2(CsrPart &P, const std::vector<double> &h_val_all) {
+    if (P.sp2_ok || P.sp2_tried || !P.sp_ok || P.h_rp.empty()) return SGPU_OK;
+    P.sp2_tried = 1;
+    const int M = P.nrows;
+    if (M < 2 || h_val_all.size() != P.h_col.size()) return SGPU_OK;
+    const int ns = (M + 127) / 128;
+    std::vector<int> ptr((size_t)ns + 1, 0);
+    int64_t tot = 0;
+    for (int s = 0; s < ns; ++s) {
+        int w = 0;
+        for (int r = s * 128; r < std::min(M, s * 128 + 128); ++r) w = std::max(w, P.h_rp[(size_t)r + 1] - P.h_rp[(size_t)r]);
+        tot += (int64_t)w * 128;
+        if (tot > (int64_t)INT32_MAX - 1024) return SGPU_OK;
+        ptr[(size_t)s + 1] = (int)tot;
+    }
+    if ((double)tot > 1.12 * (double)P.nnz) return SGPU_OK;
+    std::vector<double> val((size_t)tot + 128, 0.0);
+    saena_host::parallel_chunks<int>(ns, 64, [&](int, int s0, int s1) {
+        for (int s = s0; s < s1; ++s)
+            for (int r = s * 128; r < std::min(M, s * 128 + 128); ++r) {
+                const int p0 = P.h_rp[(size_t)r], n = P.h_rp[(size_t)r + 1] - p0, l = r - s * 128;
+                for (int j = 0; j < n; ++j) val[(size_t)ptr[(size_t)s] + (size_t)j * 128 + (size_t)l] = h_val_all[(size_t)p0 + j];
+            }
+    });
+    CHK(dev_upload(&P.sp2_val, val.data(), val.size()));
+    CHK(dev_upload(&P.sp2_ptr, ptr.data(), ptr.size()));
+    P.sp2_nslices = ns;
+    P.sp2_ok = true;
     return SGPU_OK;
 }
 
@@ -989,6 +1030,18 @@ XldsKernelFn pick_xlds_h(int epi, int lanes) {
     }
 }
 template <bool HALO, bool NT>
+SellKernelFn pick_sellp2_h(int epi) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return sk::k_sellp2<sk::EPI_SPMV, HALO, NT>;
+        case sk::EPI_RESIDUAL: return sk::k_sellp2<sk::EPI_RESIDUAL, HALO, NT>;
+        case sk::EPI_JACOBI:   return sk::k_sellp2<sk::EPI_JACOBI, HALO, NT>;
+        case sk::EPI_CHEBY0:   return sk::k_sellp2<sk::EPI_CHEBY0, HALO, NT>;
+        case sk::EPI_CHEBYK:   return sk::k_sellp2<sk::EPI_CHEBYK, HALO, NT>;
+        case sk::EPI_RSWEEP:   return sk::k_sellp2<sk::EPI_RSWEEP, HALO, NT>;
+        default:               return sk::k_sellp2<sk::EPI_SUB, HALO, NT>;
+    }
+}
+template <bool HALO, bool NT>
 SellKernelFn pick_rowt_h(int epi) {
     switch (epi) {
         case sk::EPI_SPMV:     return sk::k_rowt<sk::EPI_SPMV, HALO, NT>;
@@ -1036,6 +1089,14 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
             : epi == sk::EPI_JACOBI ? sk::k_dense_rows<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows<sk::EPI_CHEBY0>
             : epi == sk::EPI_CHEBYK ? sk::k_dense_rows<sk::EPI_CHEBYK> : epi == sk::EPI_RSWEEP ? sk::k_dense_rows<sk::EPI_RSWEEP> : sk::k_dense_rows<sk::EPI_SUB>;
         SGPU_LAUNCH(kd, dim3((P.nrows + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, (const double *)P.dense, P.nrows, P.ncols);
+    } else if (P.variant == 14) {                                 // k_sellp with a lane per two rows
+        if (!P.sp2_ok || !P.sp_ok) return fail(SGPU_ERR_STATE, "the row-paired row-pattern form was not built");
+        a.blk_row = nullptr; a.nblk = P.sp2_nslices;
+        a.val = P.sp2_val; a.cmptr = P.sp2_ptr; a.dst = P.sp_pat; a.ptab = P.sp_tab; a.pt_w = P.sp_w; a.pt_n = P.sp_n;
+        static const int nt_env2 = std::getenv("SAENA_SELLP_NT") ? std::atoi(std::getenv("SAENA_SELLP_NT")) : -1;
+        const bool nt = nt_env2 >= 0 ? nt_env2 != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
+        SellKernelFn k = halo ? (nt ? pick_sellp2_h<true, true>(epi) : pick_sellp2_h<true, false>(epi)) : (nt ? pick_sellp2_h<false, true>(epi) : pick_sellp2_h<false, false>(epi));
+        SGPU_LAUNCH(k, dim3((P.sp2_nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
     } else if (P.variant == 13) {                                 // row templates: a thread per row, no operator stream at all
         if (!P.rt_ok) return fail(SGPU_ERR_STATE, "the row-template form was not built");
         a.blk_row = nullptr; a.nblk = 0;
@@ -1845,7 +1906,7 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx", "k_rowt"};   // (3, 4, 7, 8 are named with their slot/offset split below)
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx", "k_rowt", "k_sellp2"};   // (3, 4, 7, 8 are named with their slot/offset split below)
     if (variant) *variant = op->loc.variant;
     if (kernel_name) {
         const int v = op->loc.variant;
@@ -1864,7 +1925,14 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 13) return fail(SGPU_ERR_ARG, "variant must be 0..13");
+    if (variant < 0 || variant > 14) return fail(SGPU_ERR_ARG, "variant must be 0..14");
+    if (variant == 14) {
+        CHK(build_sell(op->loc, op->h_val_all));
+        CHK(build_sellp(op->loc));
+        CHK(build_sellp2(op->loc, op->h_val_all));
+        if (!op->loc.sp2_ok)
+            return fail(SGPU_ERR_ARG, "the row-paired row-pattern form needs what the row-pattern form needs (k_sellp) and the host copy of the values");
+    }
     if (variant == 13) {
         CHK(build_rowt(op->loc, op->h_val_all));
         if (!op->loc.rt_ok)
@@ -1969,7 +2037,7 @@ bool plan_cache_lookup(uint64_t key, int *v, int *lanes) {
     bool hit = false;
     while (fgets(line, sizeof line, f)) {               // the last line of a key wins
         unsigned long long k; int vv, ll;
-        if (sscanf(line, "%llx %d %d", &k, &vv, &ll) == 3 && k == key && vv >= 0 && vv <= 13 && ll >= 1 && ll <= 64) { *v = vv; *lanes = ll; hit = true; }
+        if (sscanf(line, "%llx %d %d", &k, &vv, &ll) == 3 && k == key && vv >= 0 && vv <= 14 && ll >= 1 && ll <= 64) { *v = vv; *lanes = ll; hit = true; }
     }
     fclose(f);
     return hit;
@@ -1994,7 +2062,12 @@ void finish_plan(sgpu_op *op, int bv) {
             op->loc.cm_val[k] = nullptr; op->loc.cm_col[k] = op->loc.cm_dst[k] = nullptr; op->loc.cm_ptr[k] = nullptr;
             op->loc.cm_ok[k] = false; op->loc.cm_tried[k] = 0;
         }
-    if (bv != 9 && bv != 11 && !keep) op->loc.free_sell();
+    if (bv != 14 && !keep) op->loc.free_sellp2();
+    if (bv == 14 && !keep) {                                      // k_sellp2 keeps the pattern ids and the table; k_sell's / k_sellp's arrays go
+        CsrPart &L = op->loc;
+        L.free_sell_columns();
+        hipFree(L.sl_val); hipFree(L.sl_ptr); L.sl_val = nullptr; L.sl_ptr = nullptr;
+    } else if (bv != 9 && bv != 11 && !keep) op->loc.free_sell();
     else if (bv == 11 && !keep) op->loc.free_sell_columns();    // k_sellp keeps the values and the slice pointers only
     else if (bv == 9 && !keep) op->loc.free_sellp();
     if (bv != 13 && !keep) op->loc.free_rowt();
@@ -2009,7 +2082,7 @@ void finish_plan(sgpu_op *op, int bv) {
         }
 }
 // does the form add a row's products one after the other in column order (the reference's sum, whatever else is tuned)?
-bool sequential_sum(int v, int lanes) { return v == 9 || v == 11 || v == 13 || (lanes == 1 && (v == 0 || v == 1 || v == 3 || v == 4 || v == 7 || v == 8)); }
+bool sequential_sum(int v, int lanes) { return v == 9 || v == 11 || v == 13 || v == 14 || (lanes == 1 && (v == 0 || v == 1 || v == 3 || v == 4 || v == 7 || v == 8)); }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 } // namespace
 
@@ -2061,6 +2134,10 @@ int sgpu_op_autotune(sgpu_op *op) {
             if (!std::getenv("SAENA_NO_SELLP")) {                                                    // rows that repeat a few patterns: no column stream
                 CHK(build_sellp(op->loc));
                 if (op->loc.sp_ok) variants.push_back(11);
+                if (op->loc.sp_ok && !std::getenv("SAENA_NO_SELLP2")) {                                  // ... and a lane per two rows: half the gathers
+                    CHK(build_sellp2(op->loc, op->h_val_all));
+                    if (op->loc.sp2_ok) variants.push_back(14);
+                }
                 if (op->loc.sp_ok && std::getenv("SAENA_ROW_TEMPLATES")) {                               // OPT-IN: rows that also repeat their values
                     CHK(build_rowt(op->loc, op->h_val_all));
                     if (op->loc.rt_ok) variants.push_back(13);
@@ -2119,7 +2196,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     std::vector<std::pair<int, int>> cands;
     for (int v : variants)
         for (int gl : (v == 10 ? lanes_x : lanes)) {
-            if ((v == 9 || v == 11 || v == 12 || v == 13) && gl != lanes.front()) continue;      // a lane per row (piece) whatever the setting
+            if ((v == 9 || v == 11 || v == 12 || v == 13 || v == 14) && gl != lanes.front()) continue;      // a lane per row (piece) whatever the setting
             if (v == 5 && gl != lanes.front()) continue;                   // one wave per dense row likewise
             cands.push_back({v, gl});
         }

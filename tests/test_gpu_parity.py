@@ -131,7 +131,7 @@ def _sellp_eligible(entries, M):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 14])
 def test_kernel_variants(capi, name, variant, monkeypatch):
     """32 KiB tiles / vector CSR / 16-bit compressed columns (16 and 32 KiB tiles; long rows included) / wave-streamed
     long rows / compressed columns with the block's entries in column order (16 and 32 KiB tiles) / sliced ELLPACK /
@@ -155,7 +155,13 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
             assert "sliced-ELLPACK-in-LDS" in str(e)
             return
         assert G.variant()[1] == "k_sellx"
-    if variant == 11 and not _sellp_eligible(entries, M):
+    if variant == 14 and _sellp_eligible(entries, M):      # a lane per two rows: slices of 128 rows, refused where THEY pad more than 12 %
+        try:
+            G.set_variant(variant)
+        except capi.SgpuError as e:
+            assert "row-paired" in str(e)
+            return
+    if variant in (11, 14) and not _sellp_eligible(entries, M):
         with pytest.raises(capi.SgpuError, match="row-pattern"):       # rows that follow no small set of patterns: refused
             G.set_variant(variant)
         return
@@ -170,6 +176,8 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         assert G.variant()[1] == "k_csr_xlds"
     if variant == 11:
         assert G.variant()[1] == "k_sellp"
+    if variant == 14:
+        assert G.variant()[1] == "k_sellp2"
     x, rhs = inputs.v2(M), inputs.rhs2(M)
     bound = abs_bound(entries, M, x)
     dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
@@ -177,7 +185,7 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         G.set_lanes_per_row(lanes)
         G.spmv(dx, dy)
         got, want = dy.download(), A.matvec(x)
-        if (lanes == 1 or variant in (9, 11)) and variant not in (2, 6, 10, 12) and (name != "band3000_1400" or variant in (1, 4, 8)):
+        if (lanes == 1 or variant in (9, 11, 14)) and variant not in (2, 6, 10, 12) and (name != "band3000_1400" or variant in (1, 4, 8)):
             np.testing.assert_array_equal(got, want)          # stream variants keep the sequential row sum
         else:
             assert np.all(np.abs(got - want) <= TOL_SPMV * bound + 1e-300)
@@ -474,7 +482,7 @@ def test_halo_path_column_ordered_kernel(capi, name, nprocs, monkeypatch):
     W = util.EmulatedWorld(A)
     x, rhs = inputs.v2(M), inputs.rhs2(M)
     out = {}
-    for variant in (4, 8) + ((9, 11) if name == "poisson20" else ()):
+    for variant in (4, 8) + ((9, 11, 14) if name == "poisson20" else ()):
         xs, ys, rs, us = W.slices(x, split), W.slices(np.zeros(M), split), W.slices(rhs, split), W.slices(x, split)
         W.exchange(xs); W.exchange(us)
         for r in range(nprocs):
@@ -493,7 +501,7 @@ def test_halo_path_column_ordered_kernel(capi, name, nprocs, monkeypatch):
         W.g[r].jacobi(1, us[r], rs[r])
     assert np.all(np.abs(W.gather(ys) - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
     assert rel(W.gather(us), A.jacobi(1, x, rhs)) <= TOL_SMOOTH
-    for v in (9, 11):                                         # sliced ELLPACK, with column codes and with row patterns: the sequential row sum as well
+    for v in (9, 11, 14):                                     # sliced ELLPACK, with column codes, with row patterns, with a lane per two rows: the sequential row sum as well
         if v in out:
             np.testing.assert_array_equal(out[v][0], out[4][0])
             np.testing.assert_array_equal(out[v][1], out[4][1])
@@ -802,7 +810,7 @@ def test_plan_cache_makes_a_second_operator_take_the_first_one_s_plan(capi, tmp_
     np.testing.assert_array_equal(y1.download(), y2.download())
     # the 7-point level qualifies for the form without a column stream, and the fixed ranking prefers forms with the
     # sequential row sum: the result is the oracle's bit for bit
-    assert G1.variant()[1] in ("k_sellp", "k_sell")
+    assert G1.variant()[1] in ("k_sellp", "k_sellp2", "k_sell")
     np.testing.assert_array_equal(y1.download(), A.matvec(x))
 
 

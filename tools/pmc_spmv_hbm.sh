@@ -18,7 +18,7 @@ d, v = sys.argv[1], int(sys.argv[2])
 rows = []
 for f in sorted(glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True)):
     rows += list(csv.DictReader(open(f)))
-want = {3: "k_csr_cc16<0,", 9: "k_sell<0,", 11: "k_sellp<0,"}[v]
+want = {3: "k_csr_cc16<0,", 9: "k_sell<0,", 11: "k_sellp<0,", 14: "k_sellp2<0,"}[v]
 g = defaultdict(lambda: defaultdict(list))
 for r in rows:
     name = r["Kernel_Name"].replace(", ", ",")
@@ -33,7 +33,7 @@ write = mean["WRITE_SIZE"] * 1024.0
 rd, rd32 = mean["TCC_EA0_RDREQ_sum"], mean["TCC_EA0_RDREQ_32B_sum"]
 nnz, M = 114322352, 16387064
 alg = 12 * nnz + 4 * (M + 1) + 16 * M
-stored = {3: 10 * nnz + 4 * (M + 1) + 16 * M, 9: 10 * nnz + 2 * M + 16 * M, 11: 8 * nnz + 2 * M + 16 * M}[v]      # values + column form + x + y
+stored = {3: 10 * nnz + 4 * (M + 1) + 16 * M, 9: 10 * nnz + 2 * M + 16 * M, 11: 8 * nnz + 2 * M + 16 * M, 14: 8 * nnz + 2 * M + 16 * M}[v]      # values + column form + x + y
 print(json.dumps({"workload": "Poisson 256^3 SpMV (16387064 rows, 114322352 nnz), 1 MI355X", "kernel_filter": want, "workgroups": wg,
                   "launches": {k: len(x) for k, x in c.items()}, "fetch_bytes_corrected": fetch, "write_bytes": write,
                   "cross_check_rdreq_bytes": (rd - rd32) * 128 + rd32 * 32,

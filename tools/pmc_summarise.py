@@ -6,8 +6,8 @@ import sys
 from collections import defaultdict
 
 d, variant = sys.argv[1], int(sys.argv[2])
-want = {3: "k_csr_cc16", 0: "k_csr_stream", 9: "k_sell<", 11: "k_sellp<"}[variant]
-inst = {3: "<0, 1, 2048", 0: "<0, 1, 2048", 9: "k_sell<0, ", 11: "k_sellp<0, "}[variant]     # the SpMV instantiation of the 128^3 fine level
+want = {3: "k_csr_cc16", 0: "k_csr_stream", 9: "k_sell<", 11: "k_sellp<", 14: "k_sellp2<"}[variant]
+inst = {3: "<0, 1, 2048", 0: "<0, 1, 2048", 9: "k_sell<0, ", 11: "k_sellp<0, ", 14: "k_sellp2<0, "}[variant]     # the SpMV instantiation of the 128^3 fine level
 vals = defaultdict(list)
 kernel = None
 for f in sorted(glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True)):
