@@ -815,8 +815,11 @@ __global__ __launch_bounds__(BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
             if (j + u < lenB) sumB += vv[u].y * xb[u];
         }
     }
-    if constexpr (!HALO) {
-        if (rB < nrows) { epilogue2<EPI, NT>(a, rA, sumA, sumB); return; }       // rows 2 l and 2 l + 1: 16-byte loads and stores
+    if (rB < nrows) {                                              // rows 2 l and 2 l + 1: 16-byte loads and stores ...
+        bool both = true;
+        if constexpr (HALO)                                        // ... unless one of them is a boundary row (written by the halo stream's kernel)
+            if (a.skip) both = ((a.skip[rA >> 5] >> (rA & 31)) & 3u) == 0u;      // rA is even: both bits sit in one word
+        if (both) { epilogue2<EPI, NT>(a, rA, sumA, sumB); return; }
     }
     if (rA < nrows) epilogue<EPI, HALO, NT>(a, rA, sumA);
     if (rB < nrows) epilogue<EPI, HALO, NT>(a, rB, sumB);
