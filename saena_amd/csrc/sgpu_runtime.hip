@@ -1564,7 +1564,10 @@ static int calibrate_chain() {
     HIPCHK(hipEventSynchronize(fr.e1));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, fr.e0, fr.e1));
-    double us = (double)ms * 1e3 / reps;
+    // what a real apply adds to this ping-pong: the fork and the join of its two streams (~9 us with the in-kernel flags:
+    // 35.5 us per SpMV with a halo against 26.4-27 us of local kernel, profiles/r01_halo_loopback.md).  With RCCL self
+    // send/recv on one GPU the sum is the 23 us the model's constant was taken from.
+    double us = (double)ms * 1e3 / reps + 9.0;
     // the same number on every rank: the maximum
     HIPCHK(hipMemcpyAsync(g.dscalar, &us, sizeof(double), hipMemcpyHostToDevice, g.cs));
     NCCLCHK(ncclAllReduce(g.dscalar, g.dscalar, 1, ncclDouble, ncclMax, g.comm, g.cs));
@@ -1572,7 +1575,7 @@ static int calibrate_chain() {
     HIPCHK(hipStreamSynchronize(g.cs));
     g.chain_us = us;
     saena_host::g_measured_chain_us = us;
-    if (std::getenv("SAENA_SETUP_TIMING") && g.rank == 0) fprintf(stderr, "[sgpu] exchange chain on this communicator: %.1f us (pack -> send/recv of %d doubles with rank %d -> rows)\n", us, n, peer);
+    if (std::getenv("SAENA_SETUP_TIMING") && g.rank == 0) fprintf(stderr, "[sgpu] exchange chain on this communicator: %.1f us (pack -> send/recv of %d doubles with rank %d -> rows, + 9 us of fork / join)\n", us, n, peer);
     return SGPU_OK;
 }
 
