@@ -33,6 +33,7 @@ CASES = [
     ("poisson12", dict(kind="poisson", m=12), (1, 2, 4)),
     ("poisson16", dict(kind="poisson", m=16), (1, 2, 4)),
     ("plat362", dict(kind="file", path=f"{REFDATA}/old/plat362.mtx"), (1, 2)),
+    ("poisson24", dict(kind="poisson", m=24), (1, 3)),
 ]
 
 

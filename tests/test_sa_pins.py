@@ -18,7 +18,7 @@ import pytest
 from saena_amd import host
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = {"poisson8": dict(m=8), "poisson12": dict(m=12), "poisson16": dict(m=16), "plat362": dict(path=os.path.join(GOLDEN, "matrices", "plat362.mtx"))}
+CASES = {"poisson8": dict(m=8), "poisson12": dict(m=12), "poisson16": dict(m=16), "poisson24": dict(m=24), "plat362": dict(path=os.path.join(GOLDEN, "matrices", "plat362.mtx"))}
 
 
 @pytest.fixture(scope="module")
@@ -42,7 +42,7 @@ def fixtures():
 
 def test_fixture_set_is_complete():
     have = fixtures()
-    for tag, nps in (("poisson8", (1, 2, 4)), ("poisson12", (1, 2, 4)), ("poisson16", (1, 2, 4)), ("plat362", (1, 2))):
+    for tag, nps in (("poisson8", (1, 2, 4)), ("poisson12", (1, 2, 4)), ("poisson16", (1, 2, 4)), ("plat362", (1, 2)), ("poisson24", (1, 3))):
         for p in nps:
             assert f"{tag}.np{p}" in have
 
