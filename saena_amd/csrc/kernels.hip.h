@@ -75,6 +75,7 @@ struct SpmvArgs {
     const int            *ptab;
     int                   pt_w, pt_n;
     int                   nt;        // non-temporal stream loads (k_csr_stream / cc16 / cm / wave / xlds): see ld_stream_*
+    int                   nt_from;   // k_sell: first slice read with non-temporal loads (the slices before it stay in the Infinity Cache)
     // in-kernel fork to the halo stream (multi-rank interior launch only, else nullptr): block 0 stores
     // *flag_x = seq when it starts -- stream order: everything earlier on the compute stream is complete, so
     // the halo stream's pack, which polls the flag, may read x.
@@ -624,6 +625,9 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
     const int P = w >> 1;                              // pairs of positions; an odd last one follows them
     const sk_d2v   *v2 = reinterpret_cast<const sk_d2v *>(a.val + p) + lane;
     const unsigned *c2 = reinterpret_cast<const unsigned *>(a.ccol + p) + lane;
+    // the first nt_from slices of an operator beyond the Infinity Cache are read with plain loads, the rest non-temporal: the
+    // plain part (sized to the cache) allocates there and is found there by the next sweep, the non-temporal part does not evict it
+    const bool nt = NT && s >= a.nt_from;
     constexpr int UP = 4;
     double sum = 0.0;
     // the odd last position is fetched FIRST (its product is added last): behind the loop it was a second round trip of
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
 #pragma unroll
         for (int u = 0; u < UP; ++u) {                 // all stream loads first; pairs past the slice's width re-read its last one
             const int qq = q + u < P ? q + u : P - 1;
-            if constexpr (NT) { vv[u] = __builtin_nontemporal_load(v2 + qq * 64); cc[u] = __builtin_nontemporal_load(c2 + qq * 64); }
+            if (nt) { vv[u] = __builtin_nontemporal_load(v2 + qq * 64); cc[u] = __builtin_nontemporal_load(c2 + qq * 64); }
             else { vv[u] = v2[qq * 64]; cc[u] = c2[qq * 64]; }
         }
 #pragma unroll
@@ -700,6 +704,7 @@ __global__ __launch_bounds__(BLOCK) void k_sellp(const SpmvArgs a, int nrows) {
     // past the row's length read x[0] and are never added
     const int wmax = a.pt_w - 1;
     auto colof = [&](int j) { const int c = r + pt[j < wmax ? j : wmax]; return j < len ? c : 0; };
+    const bool ntv = NT && s >= a.nt_from;                 // (k_sell: the first nt_from slices stay in the Infinity Cache)
     double sum = 0.0;
     if constexpr (!PAIR) {
         const double *v = a.val + p + lane;
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(BLOCK) void k_sellp(const SpmvArgs a, int nrows) {
 #pragma unroll
             for (int u = 0; u < UP; ++u) {
                 const sk_d2v *vp = v2 + (q + u < P ? q + u : P - 1) * 64;
-                if constexpr (NT) vv[u] = __builtin_nontemporal_load(vp); else vv[u] = *vp;
+                if (ntv) vv[u] = __builtin_nontemporal_load(vp); else vv[u] = *vp;
             }
 #pragma unroll
             for (int u = 0; u < UP; ++u) {
@@ -785,6 +790,7 @@ __global__ __launch_bounds__(BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
     const bool same = pidA == pidB && rB < nrows;                 // the two rows read adjacent columns at every position
     const int wmax = a.pt_w - 1;
     const sk_d2v *v2 = reinterpret_cast<const sk_d2v *>(a.val + p) + lane;
+    const bool ntv = NT && s >= a.nt_from;                 // (k_sell: the first nt_from slices stay in the Infinity Cache)
     double sumA = 0.0, sumB = 0.0;
     for (int j = 0; j < w; j += 8) {
         sk_d2v vv[8];
@@ -792,7 +798,7 @@ __global__ __launch_bounds__(BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const sk_d2v *vp = v2 + (j + u < w ? j + u : w - 1) * 64;
-            if constexpr (NT) vv[u] = __builtin_nontemporal_load(vp); else vv[u] = *vp;
+            if (ntv) vv[u] = __builtin_nontemporal_load(vp); else vv[u] = *vp;
         }
         if (same) {
 #pragma unroll

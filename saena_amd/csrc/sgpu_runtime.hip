@@ -237,6 +237,15 @@ struct CsrPart {
     }
 };
 
+// How many leading slices of a sliced-ELLPACK operator beyond the 256 MiB Infinity Cache are read with plain loads (they
+// allocate in the cache and the next sweep over the operator finds them there), the rest being non-temporal (they do not
+// evict the resident part).  192 MiB of the 256: the level's vectors want their share.  SAENA_SELL_RESIDENT_MB overrides.
+int resident_slices(int nslices, double bytes_per_slice) {
+    static const double res_mb = std::getenv("SAENA_SELL_RESIDENT_MB") ? atof(std::getenv("SAENA_SELL_RESIDENT_MB")) : 192.0;
+    if (res_mb <= 0 || nslices <= 0 || bytes_per_slice <= 0) return 0;
+    return (int)std::min<double>((double)nslices, res_mb * 1048576.0 / bytes_per_slice);
+}
+
 int pow2floor(int x) { int p = 1; while (2 * p <= x) p *= 2; return p; }
 
 // Row-block plan: consecutive rows while the block holds <= CAP products and
@@ -1076,7 +1085,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d; a.y2 = e.y2;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12; a.dst = nullptr; a.cmptr = nullptr;
-    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0;
+    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0; a.nt_from = 0;
     static const int nt_rt = std::getenv("SAENA_STREAM_NT") ? std::atoi(std::getenv("SAENA_STREAM_NT")) : 0;
     a.nt = nt_rt == 1 || (nt_rt == 2 && 12 * P.nnz > (int64_t)256 * 1024 * 1024) ? 1 : 0;
     const bool halo = skip != nullptr || seq != 0;
@@ -1095,6 +1104,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         a.val = P.sp2_val; a.cmptr = P.sp2_ptr; a.dst = P.sp_pat; a.ptab = P.sp_tab; a.pt_w = P.sp_w; a.pt_n = P.sp_n;
         static const int nt_env2 = std::getenv("SAENA_SELLP_NT") ? std::atoi(std::getenv("SAENA_SELLP_NT")) : -1;
         const bool nt = nt_env2 >= 0 ? nt_env2 != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
+        a.nt_from = nt ? resident_slices(P.sp2_nslices, 8.0 * (double)P.nnz / (double)std::max(1, P.sp2_nslices)) : 0;
         SellKernelFn k = halo ? (nt ? pick_sellp2_h<true, true>(epi) : pick_sellp2_h<true, false>(epi)) : (nt ? pick_sellp2_h<false, true>(epi) : pick_sellp2_h<false, false>(epi));
         SGPU_LAUNCH(k, dim3((P.sp2_nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
     } else if (P.variant == 13) {                                 // row templates: a thread per row, no operator stream at all
@@ -1125,6 +1135,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         // non-temporal streams once the stored operator (values, pattern ids, x, y) is beyond the 256 MiB Infinity Cache
         static const int nt_env = std::getenv("SAENA_SELLP_NT") ? std::atoi(std::getenv("SAENA_SELLP_NT")) : -1;
         const bool nt = nt_env >= 0 ? nt_env != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
+        a.nt_from = nt ? resident_slices(P.nslices, 8.0 * (double)P.nnz / (double)std::max(1, P.nslices)) : 0;
         SGPU_LAUNCH(pick_sellp(epi, halo, P.sl_pair, nt), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
     } else if (P.variant == 9) {                                  // sliced ELLPACK, a lane per row
         if (!P.sl_ok) return fail(SGPU_ERR_STATE, "the sliced-ELLPACK form was not built");
@@ -1134,6 +1145,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         // 843 MB: 127 -> 121 us, profiles/r03_sell_nt.log)
         static const int nt_env = std::getenv("SAENA_SELL_NT") ? std::atoi(std::getenv("SAENA_SELL_NT")) : -1;
         const bool nt = nt_env >= 0 ? nt_env != 0 : 10 * P.nnz + 18 * (int64_t)P.nrows > (int64_t)256 * 1024 * 1024;
+        a.nt_from = nt ? resident_slices(P.nslices, 10.0 * (double)P.nnz / (double)std::max(1, P.nslices)) : 0;
         SGPU_LAUNCH(pick_sell(epi, halo, P.sl_pair, nt), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
     } else if (P.variant == 7 || P.variant == 8) {                       // compressed columns, entries in column order inside a block
         const int k = P.variant - 7;
