@@ -6,15 +6,17 @@
 // into a new vector ran at -- several times slower than the copies and the PCIe transfers the setup is made of.  With
 // madvise(MADV_HUGEPAGE) a fault maps 2 MiB and touching from a few threads reaches 20-40 GB/s.
 //
-// operator new / delete are replaced for this library only (hidden visibility: other modules keep theirs).  Memory still
-// comes from malloc and goes back through free, so a pointer may cross module boundaries either way.
-// SAENA_NO_BIGALLOC=1 switches the treatment of large blocks off.
+// operator new is wrapped for this library only (kept out of the dynamic symbol table by host/exports.map: other modules keep
+// theirs): the wrapper asks the NEXT operator new in the process for the memory (libstdc++'s, or a sanitizer's) and then makes a
+// large block resident, so every block is still released by the operator delete that matches its allocation, whichever module
+// frees it.  SAENA_NO_BIGALLOC=1 switches the treatment of large blocks off.
 #include <cstdlib>
 #include <cstdint>
 #include <new>
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
 #include <sys/mman.h>
 
 namespace {
@@ -49,35 +51,27 @@ void make_resident(void *p, size_t n) {
     for (auto &x : th) x.join();
 }
 
-void *get(size_t n) {
-    void *p = std::malloc(n ? n : 1);
-    if (!p) throw std::bad_alloc();
-    if (n >= BIG) make_resident(p, n);
-    return p;
-}
-void *get_aligned(size_t n, size_t al) {
-    void *p = nullptr;
-    if (posix_memalign(&p, al < sizeof(void *) ? sizeof(void *) : al, n ? n : 1) != 0) throw std::bad_alloc();
-    if (n >= BIG) make_resident(p, n);
+// the operator new that would have served this library without the wrapper
+template <class F>
+F next_symbol(const char *name) { return reinterpret_cast<F>(dlsym(RTLD_NEXT, name)); }
+using new_fn = void *(*)(size_t);
+using new_al_fn = void *(*)(size_t, std::align_val_t);
+new_fn next_new() { static const new_fn f = next_symbol<new_fn>("_Znwm"); return f; }
+new_fn next_new_arr() { static const new_fn f = next_symbol<new_fn>("_Znam"); return f; }
+new_al_fn next_new_al() { static const new_al_fn f = next_symbol<new_al_fn>("_ZnwmSt11align_val_t"); return f; }
+new_al_fn next_new_arr_al() { static const new_al_fn f = next_symbol<new_al_fn>("_ZnamSt11align_val_t"); return f; }
+
+void *resident(void *p, size_t n) {
+    if (p && n >= BIG) make_resident(p, n);
     return p;
 }
 
 } // namespace
 
-#define SAENA_HIDDEN      /* kept out of the dynamic symbol table by host/exports.map (the declarations of <new> fix default visibility) */
-SAENA_HIDDEN void *operator new(size_t n) { return get(n); }
-SAENA_HIDDEN void *operator new[](size_t n) { return get(n); }
-SAENA_HIDDEN void *operator new(size_t n, const std::nothrow_t &) noexcept { try { return get(n); } catch (...) { return nullptr; } }
-SAENA_HIDDEN void *operator new[](size_t n, const std::nothrow_t &) noexcept { try { return get(n); } catch (...) { return nullptr; } }
-SAENA_HIDDEN void *operator new(size_t n, std::align_val_t a) { return get_aligned(n, (size_t)a); }
-SAENA_HIDDEN void *operator new[](size_t n, std::align_val_t a) { return get_aligned(n, (size_t)a); }
-SAENA_HIDDEN void operator delete(void *p) noexcept { std::free(p); }
-SAENA_HIDDEN void operator delete[](void *p) noexcept { std::free(p); }
-SAENA_HIDDEN void operator delete(void *p, size_t) noexcept { std::free(p); }
-SAENA_HIDDEN void operator delete[](void *p, size_t) noexcept { std::free(p); }
-SAENA_HIDDEN void operator delete(void *p, std::align_val_t) noexcept { std::free(p); }
-SAENA_HIDDEN void operator delete[](void *p, std::align_val_t) noexcept { std::free(p); }
-SAENA_HIDDEN void operator delete(void *p, size_t, std::align_val_t) noexcept { std::free(p); }
-SAENA_HIDDEN void operator delete[](void *p, size_t, std::align_val_t) noexcept { std::free(p); }
-SAENA_HIDDEN void operator delete(void *p, const std::nothrow_t &) noexcept { std::free(p); }
-SAENA_HIDDEN void operator delete[](void *p, const std::nothrow_t &) noexcept { std::free(p); }
+// (no operator delete here: the memory comes from the next operator new, so the process's own operator delete is its match)
+void *operator new(size_t n) { new_fn f = next_new(); if (!f) throw std::bad_alloc(); return resident(f(n), n); }
+void *operator new[](size_t n) { new_fn f = next_new_arr(); if (!f) throw std::bad_alloc(); return resident(f(n), n); }
+void *operator new(size_t n, const std::nothrow_t &) noexcept { try { return operator new(n); } catch (...) { return nullptr; } }
+void *operator new[](size_t n, const std::nothrow_t &) noexcept { try { return operator new[](n); } catch (...) { return nullptr; } }
+void *operator new(size_t n, std::align_val_t a) { new_al_fn f = next_new_al(); if (!f) throw std::bad_alloc(); return resident(f(n, a), n); }
+void *operator new[](size_t n, std::align_val_t a) { new_al_fn f = next_new_arr_al(); if (!f) throw std::bad_alloc(); return resident(f(n, a), n); }
