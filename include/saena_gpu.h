@@ -132,7 +132,10 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
  * ELLPACK inside the (row chunk, column window) blocks of the x-in-LDS plan, a lane per row piece (rows of a few hundred
  * entries; at most 25 % padding); 13 k_rowt: row templates -- rows that repeat (length, relative columns, values) served
  * from a table in LDS, a 16-bit template id per row and nothing else of the operator (constant-coefficient stencils; never
- * chosen by the autotune unless SAENA_ROW_TEMPLATES=1).  7, 8, 9, 11, 12 and 13 are
+ * chosen by the autotune unless SAENA_ROW_TEMPLATES=1); 14 k_sellp2: k_sellp with a lane per TWO adjacent rows in
+ * slices of 128 rows -- the input vector is read, and the output written, 16 B at a time (operators that qualify for 11
+ * and whose row pairs share a length; what the autotune keeps on fine levels larger than the Infinity Cache).
+ * 7, 8, 9 and 11 to 14 are
  * built from a host copy of the values that the library keeps only until the plan-time autotune (SGPU_ERR_ARG
  * afterwards, and where the form does not apply) */
 int sgpu_op_set_variant(sgpu_op *op, int variant);
