@@ -74,6 +74,8 @@ struct SpmvArgs {
     // dst holds the pattern id of every row
     const int            *ptab;
     int                   pt_w, pt_n;
+    int                   gpw;       // k_sellp<WIDE> / k_sellp2<WIDE>: groups of slices per workgroup
+    int                   ncols;     // k_sellp2: columns of x (its 16-byte loads stay inside the vector)
     int                   nt;        // non-temporal stream loads (k_csr_stream / cc16 / cm / wave / xlds): see ld_stream_*
     int                   nt_from;   // k_sell: first slice read with non-temporal loads (the slices before it stay in the Infinity Cache)
     // in-kernel fork to the halo stream (multi-rank interior launch only, else nullptr): block 0 stores
@@ -679,30 +681,43 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
 // the stores of y) are non-temporal, x is not.  Measured on Poisson 256^3 (1.2 GB stored, profiles/r03_sellp_nt.log):
 // 257 -> 220 us back to back; on the cache-resident 128^3 operator it loses (22.5 -> 30 us), so the launch picks by size.
 // Two slices per wave (twice the loads in flight per lane) changed nothing, four were slower (profiles/r03_sellp_ns.log).
-template <int EPI, bool HALO, bool PAIR, bool NT>
-__global__ __launch_bounds__(BLOCK) void k_sellp(const SpmvArgs a, int nrows) {
-    extern __shared__ int ptab_lds[];
+// WIDE: the table of an operator whose rows follow a few HUNDRED patterns of several dozen entries -- the first smoothed-
+// aggregation level of a structured grid: Poisson 128^3 / 256^3 level 1 has 321 patterns, 14 469 offsets in all, whatever the
+// size (two of them cover 85 % of the rows).  The table is stored compactly (a.ptab: pt_n start offsets, then per pattern its
+// length and that many offsets; a.pt_w ints in all, <= SPW_MAX_TABLE = 72 KiB), a workgroup of 1024 threads shares one copy
+// (two workgroups per CU: full occupancy at <= 64 VGPRs) and works through a.gpw groups of 16 slices with it.
+constexpr int SPW_MAX_TABLE = 18432;
+constexpr int SPW_BLOCK     = 1024;
+template <int EPI, bool HALO, bool PAIR, bool NT, bool WIDE = false>
+__global__ __launch_bounds__(WIDE ? SPW_BLOCK : BLOCK) void k_sellp(const SpmvArgs a, int nrows) {
+    constexpr int BS = WIDE ? SPW_BLOCK : BLOCK;
+    extern __shared__ int ptab_dyn[];
+    int *ptab_lds;
+    if constexpr (WIDE) { __shared__ int ptab_wide[SPW_MAX_TABLE]; ptab_lds = ptab_wide; } else ptab_lds = ptab_dyn;
     if constexpr (HALO) fork_signal(a);
     {
-        const int tn = a.pt_n * (a.pt_w + 1);
-        for (int i = threadIdx.x; i < tn; i += BLOCK) ptab_lds[i] = a.ptab[i];
+        const int tn = WIDE ? a.pt_w : a.pt_n * (a.pt_w + 1);
+        for (int i = threadIdx.x; i < tn; i += BS) ptab_lds[i] = a.ptab[i];
     }
     __syncthreads();
-    constexpr int SPB = BLOCK / 64;
-    const int b = xcd_remap(blockIdx.x, (a.nblk + SPB - 1) / SPB);
-    const int s = __builtin_amdgcn_readfirstlane(b * SPB + ((int)threadIdx.x >> 6));
-    if (s >= a.nblk) return;
+    constexpr int SPB = BS / 64;
     const int lane = threadIdx.x & 63;
+    const int ngrp = (a.nblk + SPB - 1) / SPB;
+    const int gpw = WIDE ? a.gpw : 1;
+    const int b0 = xcd_remap(blockIdx.x, (ngrp + gpw - 1) / gpw) * gpw;
+    for (int g = 0; g < gpw; ++g) {
+    const int s = __builtin_amdgcn_readfirstlane((b0 + g) * SPB + ((int)threadIdx.x >> 6));
+    if (s >= a.nblk) return;
     const int r = s * 64 + lane;
     const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 6;
     int pid = 0;
     if (r < nrows) { if constexpr (NT) pid = __builtin_nontemporal_load(a.dst + r); else pid = a.dst[r]; }
-    const int *pt = ptab_lds + pid * (a.pt_w + 1);
+    const int *pt = WIDE ? ptab_lds + ptab_lds[pid] : ptab_lds + pid * (a.pt_w + 1);
     const int len = r < nrows ? pt[0] : 0;
     ++pt;
     // column of position j of this lane's row: the table is read at a clamped position (no branch per position), positions
     // past the row's length read x[0] and are never added
-    const int wmax = a.pt_w - 1;
+    const int wmax = WIDE ? (len > 0 ? len - 1 : 0) : a.pt_w - 1;
     auto colof = [&](int j) { const int c = r + pt[j < wmax ? j : wmax]; return j < len ? c : 0; };
     const bool ntv = NT && s >= a.nt_from;                 // (k_sell: the first nt_from slices stay in the Infinity Cache)
     double sum = 0.0;
@@ -749,6 +764,7 @@ __global__ __launch_bounds__(BLOCK) void k_sellp(const SpmvArgs a, int nrows) {
         if ((w & 1) && w - 1 < len) sum += vt * xt;
     }
     if (r < nrows) epilogue<EPI, HALO, NT>(a, r, sum);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -758,24 +774,39 @@ __global__ __launch_bounds__(BLOCK) void k_sellp(const SpmvArgs a, int nrows) {
 // r + 1 of a stencil follow the same pattern almost always (a grid line ends every 254 rows), so their columns r + o and r + 1 + o
 // are adjacent: ONE 16-byte load serves both, and the values of the two rows at position j sit side by side for one 16-byte
 // load as well (slices of 128 rows, position-major: [j][lane][row 2 lane, row 2 lane + 1]).  Half the gather instructions, the
-// same bytes, the same sequential sum per row: bit-identical to k_sellp.  Lanes whose two rows differ in pattern (1 % of them)
-// take two 8-byte gathers.
+// same bytes, the same sequential sum per row: bit-identical to k_sellp.
 // a.val: the row-paired values, a.cmptr: slice starts (multiples of 128), a.dst: pattern ids, a.ptab / pt_w / pt_n: the table,
 // a.nblk: slices of 128 rows.
-template <int EPI, bool HALO, bool NT>
-__global__ __launch_bounds__(BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
-    extern __shared__ int ptab_lds[];
+// Lanes whose two rows differ in pattern (1 % of them on the 7-point level) take two 8-byte gathers.
+// WIDE: the compact table of k_sellp<WIDE> (a few hundred patterns of several dozen entries: level 1 of a structured grid),
+// 512 threads around one copy -- two workgroups per CU at <= 128 VGPRs -- each serving a.gpw groups of 8 slices.  There a lane
+// whose two rows differ in pattern still takes the 16-byte load for its first row and ONE 8-byte gather for the second: a wave
+// with such lanes issues two gather instructions per position instead of three (on level 1 of the Poisson cube the pattern
+// changes at the end of every grid line -- 63 rows at 128^3 -- so nearly every slice of 128 rows holds such a lane).  Measured
+// on that level it ties with k_sellp<WIDE> (957 / 962 us at 256^3, 124 / 123 us at 128^3: neither bytes nor gather instructions
+// bound it there), so the autotune does not build it; sgpu_op_set_variant does.
+constexpr int SPW2_BLOCK = 512;
+template <int EPI, bool HALO, bool NT, bool WIDE = false>
+__global__ __launch_bounds__(WIDE ? SPW2_BLOCK : BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
+    constexpr int BS = WIDE ? SPW2_BLOCK : BLOCK;
+    extern __shared__ int ptab_dyn[];
+    int *ptab_lds;
+    if constexpr (WIDE) { __shared__ int ptab_wide[SPW_MAX_TABLE]; ptab_lds = ptab_wide; } else ptab_lds = ptab_dyn;
     if constexpr (HALO) fork_signal(a);
     {
-        const int tn = a.pt_n * (a.pt_w + 1);
-        for (int i = threadIdx.x; i < tn; i += BLOCK) ptab_lds[i] = a.ptab[i];
+        const int tn = WIDE ? a.pt_w : a.pt_n * (a.pt_w + 1);
+        for (int i = threadIdx.x; i < tn; i += BS) ptab_lds[i] = a.ptab[i];
     }
     __syncthreads();
-    constexpr int SPB = BLOCK / 64;
-    const int b = xcd_remap(blockIdx.x, (a.nblk + SPB - 1) / SPB);
-    const int s = __builtin_amdgcn_readfirstlane(b * SPB + ((int)threadIdx.x >> 6));
-    if (s >= a.nblk) return;
+    constexpr int SPB = BS / 64;
     const int lane = threadIdx.x & 63;
+    const int ngrp = (a.nblk + SPB - 1) / SPB;
+    const int gpw = WIDE ? a.gpw : 1;
+    const int b0 = xcd_remap(blockIdx.x, (ngrp + gpw - 1) / gpw) * gpw;
+    const int xlast = a.ncols - 1;
+    for (int g = 0; g < gpw; ++g) {
+    const int s = __builtin_amdgcn_readfirstlane((b0 + g) * SPB + ((int)threadIdx.x >> 6));
+    if (s >= a.nblk) return;
     const int rA = s * 128 + 2 * lane, rB = rA + 1;
     const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 7;
     unsigned ids = 0;
@@ -784,11 +815,12 @@ __global__ __launch_bounds__(BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
         if constexpr (NT) ids = __builtin_nontemporal_load(ip); else ids = *ip;
     }
     const int pidA = (int)(ids & 0xffffu), pidB = (int)(ids >> 16);
-    const int *ptA = ptab_lds + pidA * (a.pt_w + 1), *ptB = ptab_lds + pidB * (a.pt_w + 1);
+    const int *ptA = WIDE ? ptab_lds + ptab_lds[pidA] : ptab_lds + pidA * (a.pt_w + 1);
+    const int *ptB = WIDE ? ptab_lds + ptab_lds[pidB] : ptab_lds + pidB * (a.pt_w + 1);
     const int lenA = rA < nrows ? ptA[0] : 0, lenB = rB < nrows ? ptB[0] : 0;
     ++ptA; ++ptB;
     const bool same = pidA == pidB && rB < nrows;                 // the two rows read adjacent columns at every position
-    const int wmax = a.pt_w - 1;
+    const int wmaxA = WIDE ? (lenA > 0 ? lenA - 1 : 0) : a.pt_w - 1, wmaxB = WIDE ? (lenB > 0 ? lenB - 1 : 0) : a.pt_w - 1;
     const sk_d2v *v2 = reinterpret_cast<const sk_d2v *>(a.val + p) + lane;
     const bool ntv = NT && s >= a.nt_from;                 // (k_sell: the first nt_from slices stay in the Infinity Cache)
     double sumA = 0.0, sumB = 0.0;
@@ -800,17 +832,29 @@ __global__ __launch_bounds__(BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
             const sk_d2v *vp = v2 + (j + u < w ? j + u : w - 1) * 64;
             if (ntv) vv[u] = __builtin_nontemporal_load(vp); else vv[u] = *vp;
         }
-        if (same) {
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {              // x[c], x[c + 1] in one 16-byte load at an 8-byte aligned address; the last column: x[c - 1], x[c]
+                const int c = j + u < lenA ? rA + ptA[j + u < wmaxA ? j + u : wmaxA] : 0;
+                const bool last = c >= xlast;          // (only a lane whose rows differ in pattern can sit there)
+                const sk_d2v8 xx = *reinterpret_cast<const sk_d2v8 *>(a.x + (last ? xlast - 1 : c));
+                xa[u] = last ? xx.y : xx.x; xb[u] = xx.y;
+            }
+            if (!same) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xb[u] = a.x[j + u < lenB ? rB + ptB[j + u < wmaxB ? j + u : wmaxB] : 0];
+            }
+        } else if (same) {                             // (the 7-point level: 1 % of the lanes hold two patterns; this form needs 82 VGPRs, the one above 93)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int c = rA + ptA[j + u < wmax ? j + u : wmax];
+                const int c = rA + ptA[j + u < wmaxA ? j + u : wmaxA];
                 const sk_d2v8 xx = *reinterpret_cast<const sk_d2v8 *>(a.x + (j + u < lenA ? c : 0));     // a 16-byte load at an 8-byte aligned address
                 xa[u] = xx.x; xb[u] = xx.y;
             }
         } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int jj = j + u < wmax ? j + u : wmax;
+                const int jj = j + u < wmaxA ? j + u : wmaxA;
                 xa[u] = a.x[j + u < lenA ? rA + ptA[jj] : 0];
                 xb[u] = a.x[j + u < lenB ? rB + ptB[jj] : 0];
             }
@@ -825,10 +869,11 @@ __global__ __launch_bounds__(BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
         bool both = true;
         if constexpr (HALO)                                        // ... unless one of them is a boundary row (written by the halo stream's kernel)
             if (a.skip) both = ((a.skip[rA >> 5] >> (rA & 31)) & 3u) == 0u;      // rA is even: both bits sit in one word
-        if (both) { epilogue2<EPI, NT>(a, rA, sumA, sumB); return; }
+        if (both) { epilogue2<EPI, NT>(a, rA, sumA, sumB); continue; }
     }
     if (rA < nrows) epilogue<EPI, HALO, NT>(a, rA, sumA);
     if (rB < nrows) epilogue<EPI, HALO, NT>(a, rB, sumB);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -162,11 +162,11 @@ struct CsrPart {
     // patterns (sp_n rows of sp_w + 1 ints: length, then the columns relative to the row); shares sl_val / sl_ptr
     unsigned short *sp_pat = nullptr;
     int            *sp_tab = nullptr;
-    int             sp_w = 0, sp_n = 0;
+    int             sp_w = 0, sp_n = 0, sp_gpw = 1;
     int64_t         sp_bytes = 0;      // values + pattern ids + x + y as this form stores them
-    bool            sp_ok = false;
+    bool            sp_ok = false, sp_wide = false;   // sp_wide: the compact table of k_sellp<WIDE> (sp_w = its ints)
     char            sp_tried = 0;
-    void free_sellp() { hipFree(sp_pat); hipFree(sp_tab); sp_pat = nullptr; sp_tab = nullptr; sp_ok = false; sp_tried = 0; }
+    void free_sellp() { hipFree(sp_pat); hipFree(sp_tab); sp_pat = nullptr; sp_tab = nullptr; sp_ok = false; sp_wide = false; sp_tried = 0; }
     // the column codes of k_sell alone (k_sellp keeps the values and the slice pointers)
     void free_sell_columns() {
         hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr);
@@ -602,8 +602,12 @@ int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
 }
 
 // Row patterns of the local part (k_sellp) on top of build_sell's values: every row is (length, columns relative to the
-// row index); the operator qualifies when its rows follow at most 65 535 distinct patterns whose table fits 16 KiB of LDS
-// (4096 ints) -- stencils on structured grids (the boundary-stripped 7-point Laplacian: 27 patterns), band matrices.
+// row index); the operator qualifies when its rows follow at most 65 535 distinct patterns whose table fits LDS:
+//   * 4096 ints at a fixed width of (longest row + 1) -- stencils on structured grids (the boundary-stripped 7-point Laplacian:
+//     27 patterns), band matrices: the table of k_sellp / k_sellp2 with 256 threads per workgroup;
+//   * else 18 432 ints stored compactly (start offsets, then length + offsets per pattern) -- the first smoothed-aggregation
+//     level of a structured grid (Poisson level 1: 321 patterns, 14 469 offsets at every size): k_sellp<WIDE>, 1024 threads
+//     around one table (sp_wide).
 // Ids are dealt in order of first appearance, so the table does not depend on threads or hashing.
 constexpr int SP_MAX_TABLE = 4096;
 int build_sellp(CsrPart &P) {
@@ -612,17 +616,16 @@ int build_sellp(CsrPart &P) {
     const int M = P.nrows;
     int W = 1;
     for (int r = 0; r < M; ++r) W = std::max(W, P.h_rp[r + 1] - P.h_rp[r]);
-    if (W + 1 > SP_MAX_TABLE) return SGPU_OK;
-    const int max_pat = std::min(65535, SP_MAX_TABLE / (W + 1));
-    std::vector<int> tab;                                      // patterns back to back, W + 1 ints each
+    if (W + 3 > sk::SPW_MAX_TABLE) return SGPU_OK;
+    std::vector<int> ctab, cstart;                             // patterns back to back: length, then that many offsets
     std::vector<unsigned short> pat(((size_t)M + 127) / 128 * 128, 0);
     std::unordered_map<std::string, int> ids;
     std::string key;
     int prev = -1, npat = 0;
     for (int r = 0; r < M; ++r) {
         const int p0 = P.h_rp[r], n = P.h_rp[r + 1] - p0;
-        if (prev >= 0 && tab[(size_t)prev * (W + 1)] == n) {   // most rows repeat the row before
-            const int *t = &tab[(size_t)prev * (W + 1) + 1];
+        if (prev >= 0 && ctab[(size_t)cstart[(size_t)prev]] == n) {   // most rows repeat the row before
+            const int *t = &ctab[(size_t)cstart[(size_t)prev] + 1];
             int j = 0;
             while (j < n && P.h_col[(size_t)p0 + j] - r == t[j]) ++j;
             if (j == n) { pat[(size_t)r] = (unsigned short)prev; continue; }
@@ -631,19 +634,40 @@ int build_sellp(CsrPart &P) {
         for (int j = 0; j < n; ++j) { const int o = P.h_col[(size_t)p0 + j] - r; key.append(reinterpret_cast<const char *>(&o), sizeof o); }
         auto it = ids.find(key);
         if (it == ids.end()) {
-            if (npat == max_pat) return SGPU_OK;               // too many patterns: not this kind of operator
+            if (npat == 65535 || (size_t)npat + 1 + ctab.size() + (size_t)n + 1 + 1 > (size_t)sk::SPW_MAX_TABLE) return SGPU_OK;   // not this kind of operator
             it = ids.emplace(key, npat++).first;
-            tab.push_back(n);
-            for (int j = 0; j < W; ++j) tab.push_back(j < n ? P.h_col[(size_t)p0 + j] - r : 0);
+            cstart.push_back((int)ctab.size());
+            ctab.push_back(n);
+            for (int j = 0; j < n; ++j) ctab.push_back(P.h_col[(size_t)p0 + j] - r);
         }
         prev = it->second;
         pat[(size_t)r] = (unsigned short)prev;
     }
     if (npat == 0) return SGPU_OK;
-    if (std::getenv("SAENA_SETUP_TIMING")) fprintf(stderr, "[sgpu] row patterns: %d rows follow %d patterns of <= %d entries\n", M, npat, W);
+    std::vector<int> tab;
+    const bool wide = (size_t)npat * (W + 1) > (size_t)SP_MAX_TABLE;
+    if (!wide) {                                               // fixed width: W + 1 ints per pattern
+        tab.assign((size_t)npat * (W + 1), 0);
+        for (int i = 0; i < npat; ++i) {
+            const int *c = &ctab[(size_t)cstart[(size_t)i]];
+            for (int j = 0; j <= c[0]; ++j) tab[(size_t)i * (W + 1) + j] = c[j];
+        }
+    } else {                                                   // compact: [start of pattern i in this array] [patterns] [one spare int]
+        tab.reserve((size_t)npat + ctab.size() + 1);
+        for (int i = 0; i < npat; ++i) tab.push_back(npat + cstart[(size_t)i]);
+        tab.insert(tab.end(), ctab.begin(), ctab.end());
+        tab.push_back(0);
+    }
+    if (std::getenv("SAENA_SETUP_TIMING"))
+        fprintf(stderr, "[sgpu] row patterns: %d rows follow %d patterns of <= %d entries (%zu ints, %s table)\n", M, npat, W, tab.size(), wide ? "compact" : "fixed-width");
     CHK(dev_upload(&P.sp_pat, pat.data(), pat.size()));
     CHK(dev_upload(&P.sp_tab, tab.data(), tab.size()));
-    P.sp_w = W; P.sp_n = npat;
+    P.sp_w = wide ? (int)tab.size() : W; P.sp_n = npat; P.sp_wide = wide;
+    {                                                          // groups of 16 slices per workgroup of the wide form: the table load is paid once per workgroup
+        const int ngrp = (P.nslices + 15) / 16, env = std::getenv("SAENA_SELLPW_GROUPS") ? std::atoi(std::getenv("SAENA_SELLPW_GROUPS")) : 0;
+        (void)ngrp;                                            // measured on Poisson level 1: 1 group 123 / 960 us (128^3 / 256^3), 2 groups 128 / 962, 4 groups - / 995
+        P.sp_gpw = env > 0 ? std::min(env, 64) : 1;
+    }
     P.sp_bytes = 8 * (int64_t)P.h_rp.back() + 2 * (int64_t)M + 8 * (int64_t)P.ncols + 8 * (int64_t)M;
     P.sp_ok = true;
     return SGPU_OK;
@@ -655,7 +679,7 @@ int build_sellp2(CsrPart &P, const std::vector<double> &h_val_all) {
     if (P.sp2_ok || P.sp2_tried || !P.sp_ok || P.h_rp.empty()) return SGPU_OK;
     P.sp2_tried = 1;
     const int M = P.nrows;
-    if (M < 2 || h_val_all.size() != P.h_col.size()) return SGPU_OK;
+    if (M < 2 || P.ncols < 2 || h_val_all.size() != P.h_col.size()) return SGPU_OK;      // (the kernel reads x 16 bytes at a time)
     const int ns = (M + 127) / 128;
     std::vector<int> ptr((size_t)ns + 1, 0);
     int64_t tot = 0;
@@ -1003,23 +1027,26 @@ SellKernelFn pick_sell_n(int epi, bool halo, bool pair) {
     return halo ? (pair ? pick_sell_h<true, true, NT>(epi) : pick_sell_h<true, false, NT>(epi)) : (pair ? pick_sell_h<false, true, NT>(epi) : pick_sell_h<false, false, NT>(epi));
 }
 SellKernelFn pick_sell(int epi, bool halo, bool pair, bool nt) { return nt ? pick_sell_n<true>(epi, halo, pair) : pick_sell_n<false>(epi, halo, pair); }
-template <bool HALO, bool PAIR, bool NT>
+template <bool HALO, bool PAIR, bool NT, bool WIDE>
 SellKernelFn pick_sellp_h(int epi) {
     switch (epi) {
-        case sk::EPI_SPMV:     return sk::k_sellp<sk::EPI_SPMV, HALO, PAIR, NT>;
-        case sk::EPI_RESIDUAL: return sk::k_sellp<sk::EPI_RESIDUAL, HALO, PAIR, NT>;
-        case sk::EPI_JACOBI:   return sk::k_sellp<sk::EPI_JACOBI, HALO, PAIR, NT>;
-        case sk::EPI_CHEBY0:   return sk::k_sellp<sk::EPI_CHEBY0, HALO, PAIR, NT>;
-        case sk::EPI_CHEBYK:   return sk::k_sellp<sk::EPI_CHEBYK, HALO, PAIR, NT>;
-        case sk::EPI_RSWEEP:   return sk::k_sellp<sk::EPI_RSWEEP, HALO, PAIR, NT>;
-        default:               return sk::k_sellp<sk::EPI_SUB, HALO, PAIR, NT>;
+        case sk::EPI_SPMV:     return sk::k_sellp<sk::EPI_SPMV, HALO, PAIR, NT, WIDE>;
+        case sk::EPI_RESIDUAL: return sk::k_sellp<sk::EPI_RESIDUAL, HALO, PAIR, NT, WIDE>;
+        case sk::EPI_JACOBI:   return sk::k_sellp<sk::EPI_JACOBI, HALO, PAIR, NT, WIDE>;
+        case sk::EPI_CHEBY0:   return sk::k_sellp<sk::EPI_CHEBY0, HALO, PAIR, NT, WIDE>;
+        case sk::EPI_CHEBYK:   return sk::k_sellp<sk::EPI_CHEBYK, HALO, PAIR, NT, WIDE>;
+        case sk::EPI_RSWEEP:   return sk::k_sellp<sk::EPI_RSWEEP, HALO, PAIR, NT, WIDE>;
+        default:               return sk::k_sellp<sk::EPI_SUB, HALO, PAIR, NT, WIDE>;
     }
 }
-template <bool NT>
+template <bool NT, bool WIDE>
 SellKernelFn pick_sellp_n(int epi, bool halo, bool pair) {
-    return halo ? (pair ? pick_sellp_h<true, true, NT>(epi) : pick_sellp_h<true, false, NT>(epi)) : (pair ? pick_sellp_h<false, true, NT>(epi) : pick_sellp_h<false, false, NT>(epi));
+    return halo ? (pair ? pick_sellp_h<true, true, NT, WIDE>(epi) : pick_sellp_h<true, false, NT, WIDE>(epi)) : (pair ? pick_sellp_h<false, true, NT, WIDE>(epi) : pick_sellp_h<false, false, NT, WIDE>(epi));
 }
-SellKernelFn pick_sellp(int epi, bool halo, bool pair, bool nt) { return nt ? pick_sellp_n<true>(epi, halo, pair) : pick_sellp_n<false>(epi, halo, pair); }
+SellKernelFn pick_sellp(int epi, bool halo, bool pair, bool nt, bool wide) {
+    if (wide) return nt ? pick_sellp_n<true, true>(epi, halo, pair) : pick_sellp_n<false, true>(epi, halo, pair);
+    return nt ? pick_sellp_n<true, false>(epi, halo, pair) : pick_sellp_n<false, false>(epi, halo, pair);
+}
 using XldsKernelFn = void (*)(const sk::SpmvArgs, const sk::XldsArgs);
 template <int EPI, bool HALO>
 XldsKernelFn pick_xlds_g(int lanes) {
@@ -1038,17 +1065,21 @@ XldsKernelFn pick_xlds_h(int epi, int lanes) {
         default:               return pick_xlds_g<sk::EPI_SUB, HALO>(lanes);
     }
 }
-template <bool HALO, bool NT>
+template <bool HALO, bool NT, bool WIDE>
 SellKernelFn pick_sellp2_h(int epi) {
     switch (epi) {
-        case sk::EPI_SPMV:     return sk::k_sellp2<sk::EPI_SPMV, HALO, NT>;
-        case sk::EPI_RESIDUAL: return sk::k_sellp2<sk::EPI_RESIDUAL, HALO, NT>;
-        case sk::EPI_JACOBI:   return sk::k_sellp2<sk::EPI_JACOBI, HALO, NT>;
-        case sk::EPI_CHEBY0:   return sk::k_sellp2<sk::EPI_CHEBY0, HALO, NT>;
-        case sk::EPI_CHEBYK:   return sk::k_sellp2<sk::EPI_CHEBYK, HALO, NT>;
-        case sk::EPI_RSWEEP:   return sk::k_sellp2<sk::EPI_RSWEEP, HALO, NT>;
-        default:               return sk::k_sellp2<sk::EPI_SUB, HALO, NT>;
+        case sk::EPI_SPMV:     return sk::k_sellp2<sk::EPI_SPMV, HALO, NT, WIDE>;
+        case sk::EPI_RESIDUAL: return sk::k_sellp2<sk::EPI_RESIDUAL, HALO, NT, WIDE>;
+        case sk::EPI_JACOBI:   return sk::k_sellp2<sk::EPI_JACOBI, HALO, NT, WIDE>;
+        case sk::EPI_CHEBY0:   return sk::k_sellp2<sk::EPI_CHEBY0, HALO, NT, WIDE>;
+        case sk::EPI_CHEBYK:   return sk::k_sellp2<sk::EPI_CHEBYK, HALO, NT, WIDE>;
+        case sk::EPI_RSWEEP:   return sk::k_sellp2<sk::EPI_RSWEEP, HALO, NT, WIDE>;
+        default:               return sk::k_sellp2<sk::EPI_SUB, HALO, NT, WIDE>;
     }
+}
+template <bool WIDE>
+SellKernelFn pick_sellp2(int epi, bool halo, bool nt) {
+    return halo ? (nt ? pick_sellp2_h<true, true, WIDE>(epi) : pick_sellp2_h<true, false, WIDE>(epi)) : (nt ? pick_sellp2_h<false, true, WIDE>(epi) : pick_sellp2_h<false, false, WIDE>(epi));
 }
 template <bool HALO, bool NT>
 SellKernelFn pick_rowt_h(int epi) {
@@ -1085,7 +1116,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d; a.y2 = e.y2;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12; a.dst = nullptr; a.cmptr = nullptr;
-    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0; a.nt_from = 0;
+    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0; a.gpw = 1; a.ncols = P.ncols; a.nt_from = 0;
     static const int nt_rt = std::getenv("SAENA_STREAM_NT") ? std::atoi(std::getenv("SAENA_STREAM_NT")) : 0;
     a.nt = nt_rt == 1 || (nt_rt == 2 && 12 * P.nnz > (int64_t)256 * 1024 * 1024) ? 1 : 0;
     const bool halo = skip != nullptr || seq != 0;
@@ -1105,8 +1136,13 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         static const int nt_env2 = std::getenv("SAENA_SELLP_NT") ? std::atoi(std::getenv("SAENA_SELLP_NT")) : -1;
         const bool nt = nt_env2 >= 0 ? nt_env2 != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
         a.nt_from = nt ? resident_slices(P.sp2_nslices, 8.0 * (double)P.nnz / (double)std::max(1, P.sp2_nslices)) : 0;
-        SellKernelFn k = halo ? (nt ? pick_sellp2_h<true, true>(epi) : pick_sellp2_h<true, false>(epi)) : (nt ? pick_sellp2_h<false, true>(epi) : pick_sellp2_h<false, false>(epi));
-        SGPU_LAUNCH(k, dim3((P.sp2_nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
+        a.ncols = P.ncols;
+        if (P.sp_wide) {                                          // compact table shared by 512 threads, gpw groups of 8 slices per workgroup
+            const int ngrp = (P.sp2_nslices + 7) / 8;
+            a.gpw = P.sp_gpw;
+            SGPU_LAUNCH(pick_sellp2<true>(epi, halo, nt), dim3((ngrp + a.gpw - 1) / a.gpw), dim3(sk::SPW2_BLOCK), 0, g.cs, a, P.nrows);
+        } else
+        SGPU_LAUNCH(pick_sellp2<false>(epi, halo, nt), dim3((P.sp2_nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
     } else if (P.variant == 13) {                                 // row templates: a thread per row, no operator stream at all
         if (!P.rt_ok) return fail(SGPU_ERR_STATE, "the row-template form was not built");
         a.blk_row = nullptr; a.nblk = 0;
@@ -1136,7 +1172,12 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         static const int nt_env = std::getenv("SAENA_SELLP_NT") ? std::atoi(std::getenv("SAENA_SELLP_NT")) : -1;
         const bool nt = nt_env >= 0 ? nt_env != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
         a.nt_from = nt ? resident_slices(P.nslices, 8.0 * (double)P.nnz / (double)std::max(1, P.nslices)) : 0;
-        SGPU_LAUNCH(pick_sellp(epi, halo, P.sl_pair, nt), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
+        if (P.sp_wide) {                                          // compact table shared by 1024 threads, gpw groups of 16 slices per workgroup
+            const int ngrp = (P.nslices + 15) / 16;
+            a.gpw = P.sp_gpw;
+            SGPU_LAUNCH(pick_sellp(epi, halo, P.sl_pair, nt, true), dim3((ngrp + a.gpw - 1) / a.gpw), dim3(sk::SPW_BLOCK), 0, g.cs, a, P.nrows);
+        } else
+        SGPU_LAUNCH(pick_sellp(epi, halo, P.sl_pair, nt, false), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
     } else if (P.variant == 9) {                                  // sliced ELLPACK, a lane per row
         if (!P.sl_ok) return fail(SGPU_ERR_STATE, "the sliced-ELLPACK form was not built");
         a.blk_row = nullptr; a.nblk = P.nslices;
@@ -1932,7 +1973,7 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
             const_cast<sgpu_op *>(op)->vname = buf;
             *kernel_name = op->vname.c_str();
         } else {
-            *kernel_name = names[v];
+            *kernel_name = (v == 11 && op->loc.sp_wide) ? "k_sellp<wide>" : (v == 14 && op->loc.sp_wide) ? "k_sellp2<wide>" : names[v];      // the compact table around 1024 threads
         }
     }
     return SGPU_OK;
@@ -1966,7 +2007,7 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
         CHK(build_sellp(op->loc));
         if (!op->loc.sp_ok)
             return fail(SGPU_ERR_ARG, "the row-pattern form needs what the sliced-ELLPACK form needs and rows that follow at most %d-int's worth of "
-                                      "(length, relative columns) patterns", SP_MAX_TABLE);
+                                      "(length, relative columns) patterns", sk::SPW_MAX_TABLE);
     }
     if (variant == 10) {
         CHK(build_xlds(op->loc));
@@ -2149,7 +2190,8 @@ int sgpu_op_autotune(sgpu_op *op) {
             if (!std::getenv("SAENA_NO_SELLP")) {                                                    // rows that repeat a few patterns: no column stream
                 CHK(build_sellp(op->loc));
                 if (op->loc.sp_ok) variants.push_back(11);
-                if (op->loc.sp_ok && !std::getenv("SAENA_NO_SELLP2")) {                                  // ... and a lane per two rows: half the gathers
+                if (op->loc.sp_ok && !op->loc.sp_wide && !std::getenv("SAENA_NO_SELLP2")) {               // ... and a lane per two rows: half the gathers (with the
+                                                                                                         // wide table it ties with k_sellp: 957 / 962 us on 256^3 level 1, 124 / 123 on 128^3)
                     CHK(build_sellp2(op->loc, op->h_val_all));
                     if (op->loc.sp2_ok) variants.push_back(14);
                 }

@@ -49,7 +49,7 @@ def main():
             us_p = opP.time_kernel(0, xc, None, y, 50) * 1e3
             us_t = opR.time_kernel(0, x, None, yc, 50) * 1e3
             Bp, Bt = opP.algorithmic_bytes(0), opR.algorithmic_bytes(0)
-            line += (f" | P {us_p:7.1f} us {Bp / us_p / 1e3:7.1f} GB/s (G={opP.info()['lanes_per_row']}) | R {us_t:7.1f} us {Bt / us_t / 1e3:7.1f} GB/s (G={opR.info()['lanes_per_row']})")
+            line += (f" | P {us_p:7.1f} us {Bp / us_p / 1e3:7.1f} GB/s (G={opP.info()['lanes_per_row']} v{opP.variant()[0]}, {opP.info()['nnz_local'] / opP.M:.1f}/row) | R {us_t:7.1f} us {Bt / us_t / 1e3:7.1f} GB/s (G={opR.info()['lanes_per_row']} v{opR.variant()[0]}, {opR.info()['nnz_local'] / opR.M:.1f}/row)")
             # (3,3) sweeps; on every coarse level the first pre-smoothing sweep starts from u = 0 and needs no pass over
             # the matrix (k_zero_sweep, 24 B/row), which is what sgpu_vcycle runs
             full = 6 if l == 0 else 5

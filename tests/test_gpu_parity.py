@@ -116,18 +116,26 @@ def _sell_eligible(entries, M):
     return padded <= 1.12 * len(entries)
 
 
-def _sellp_eligible(entries, M):
-    """the library's rule for the row-pattern form: sliced-ELLPACK eligible, and the distinct (length, columns relative
-    to the row) patterns fit a table of 4096 ints (each pattern takes longest-row + 1 of them)"""
+def _sellp_table(entries, M):
+    """the library's rule for the row-pattern form: sliced-ELLPACK eligible, and the distinct (length, columns relative to
+    the row) patterns fit a table in LDS -- "narrow": 4096 ints at longest-row + 1 ints per pattern (k_sellp / k_sellp2 with
+    256 threads); else "wide": 18 432 ints stored compactly -- a start offset, the length and the offsets per pattern, one
+    spare int (k_sellp<wide>, 1024 threads around one table); else None"""
     if not _sell_eligible(entries, M):
-        return False
+        return None
     row, col = np.asarray(entries["row"]), np.asarray(entries["col"])
     order = np.lexsort((col, row))
     row, col = row[order], col[order]
     n = np.bincount(row, minlength=M)
     ptr = np.concatenate([[0], np.cumsum(n)])
     pats = {tuple(col[ptr[r]:ptr[r + 1]] - r) for r in range(M)}
-    return len(pats) * (int(n.max()) + 1) <= 4096
+    if len(pats) * (int(n.max()) + 1) <= 4096:
+        return "narrow"
+    return "wide" if len(pats) < 65536 and sum(len(p) + 2 for p in pats) + 1 <= 18432 else None
+
+
+def _sellp_eligible(entries, M):
+    return _sellp_table(entries, M) == "narrow"
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -155,13 +163,14 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
             assert "sliced-ELLPACK-in-LDS" in str(e)
             return
         assert G.variant()[1] == "k_sellx"
-    if variant == 14 and _sellp_eligible(entries, M):      # a lane per two rows: slices of 128 rows, refused where THEY pad more than 12 %
+    if variant == 14 and _sellp_table(entries, M) is not None:      # a lane per two rows: slices of 128 rows, refused where THEY pad more than 12 %
         try:
             G.set_variant(variant)
         except capi.SgpuError as e:
             assert "row-paired" in str(e)
             return
-    if variant in (11, 14) and not _sellp_eligible(entries, M):
+    table = _sellp_table(entries, M)
+    if variant in (11, 14) and table is None:
         with pytest.raises(capi.SgpuError, match="row-pattern"):       # rows that follow no small set of patterns: refused
             G.set_variant(variant)
         return
@@ -175,9 +184,9 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
     if variant == 10:
         assert G.variant()[1] == "k_csr_xlds"
     if variant == 11:
-        assert G.variant()[1] == "k_sellp"
+        assert G.variant()[1] == ("k_sellp" if table == "narrow" else "k_sellp<wide>")
     if variant == 14:
-        assert G.variant()[1] == "k_sellp2"
+        assert G.variant()[1] == ("k_sellp2" if table == "narrow" else "k_sellp2<wide>")
     x, rhs = inputs.v2(M), inputs.rhs2(M)
     bound = abs_bound(entries, M, x)
     dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
@@ -783,6 +792,68 @@ def test_row_templates(capi, name, monkeypatch):
     du = capi.DeviceVector(M, rhs)
     G.prolong_correct(dx, du)
     np.testing.assert_array_equal(du.download(), rhs - A.matvec(x))
+
+
+def _patterned_operator(M, npat, length, reach, seed, run=1):
+    """square operator whose row r follows pattern (r // run) % npat: `length` (+ 0..2) distinct offsets within +-reach of the row,
+    the diagonal among them; near the two ends the offsets that leave the matrix are dropped (more patterns there)"""
+    rng = np.random.default_rng(seed)
+    pats = []
+    for k in range(npat):
+        o = rng.choice(np.setdiff1d(np.arange(-reach, reach + 1), [0]), size=length - 1 + k % 3, replace=False)
+        pats.append(np.sort(np.concatenate([o, [0]])))
+    rows, cols = [], []
+    for r in range(M):
+        c = r + pats[(r // run) % npat]
+        c = c[(c >= 0) & (c < M)]
+        rows.append(np.full(len(c), r)); cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    vals = np.cos(0.37 * rows - 0.11 * cols) + 1.25
+    return orc.coo_from_arrays(rows.astype(np.int32), cols.astype(np.int32), vals)
+
+
+@pytest.mark.parametrize("groups", [0, 3])
+@pytest.mark.parametrize("variant", [11, 14])
+def test_row_patterns_wide_table(capi, variant, groups, monkeypatch):
+    """k_sellp<wide> / k_sellp2<wide>: an operator whose rows follow a few HUNDRED patterns of several dozen entries (the first smoothed-
+    aggregation level of a structured grid: 321 patterns, 14 469 offsets at every size of the Poisson cube) keeps the table
+    compactly in 72 KiB of LDS shared by 1024 threads, each workgroup serving `groups` groups of 16 slices (0: the library's
+    choice).  No column stream, the reference's sequential row sum: bit-identical to the CSR loop for every epilogue; with too
+    many patterns the form is refused.  The row-paired kernel meets every case of a lane's two rows here: same pattern (16-byte
+    loads of x), different patterns (the pattern changes every row: a 16-byte load and an 8-byte gather), the last column of x in
+    the first row of a pair, the ragged last slice."""
+    monkeypatch.setenv("SAENA_KEEP_HOST_VALUES", "1")
+    if groups:
+        monkeypatch.setenv("SAENA_SELLPW_GROUPS", str(groups))
+    M = 40000 + 37                                            # 626 slices (the last one ragged), 40 groups of 16
+    entries = _patterned_operator(M, 240, 40, 50, 11, run=5)         # runs of 5 rows: row pairs with one pattern and with two
+    assert _sellp_table(entries, M) == "wide"
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    G.set_variant(variant)
+    assert G.variant()[1] == ("k_sellp<wide>" if variant == 11 else "k_sellp2<wide>")
+    x, rhs = inputs.v2(M), inputs.rhs2(M)
+    dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
+    G.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), A.matvec(x))
+    G.residual(dx, dr, dy)
+    np.testing.assert_array_equal(dy.download(), A.residual(x, rhs))
+    du = capi.DeviceVector(M, x)
+    G.jacobi(3, du, dr)
+    np.testing.assert_array_equal(du.download(), A.jacobi(3, x, rhs))
+    A.set_eig(1.9371)
+    du = capi.DeviceVector(M, x)
+    G.chebyshev(3, 1.9371, du, dr)
+    assert rel(du.download(), A.chebyshev(3, x, rhs)) <= TOL_SMOOTH
+    du = capi.DeviceVector(M, rhs)
+    G.prolong_correct(dx, du)
+    np.testing.assert_array_equal(du.download(), rhs - A.matvec(x))
+    if not groups:
+        many = _patterned_operator(30000, 600, 40, 50, 12)    # 600 patterns x 41 ints: beyond the table
+        assert _sellp_table(many, 30000) is None
+        G2 = util.gpu_operator(orc.OracleOp(many, 30000, 30000, orc.split_even(30000, 1)))
+        with pytest.raises(capi.SgpuError, match="row-pattern"):
+            G2.set_variant(variant)
 
 
 def test_plan_cache_makes_a_second_operator_take_the_first_one_s_plan(capi, tmp_path, monkeypatch):
