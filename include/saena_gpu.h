@@ -136,7 +136,10 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
  * chosen by the autotune unless SAENA_ROW_TEMPLATES=1); 14 k_sellp2: k_sellp with a lane per TWO adjacent rows in
  * slices of 128 rows -- the input vector is read, and the output written, 16 B at a time (operators that qualify for 11
  * and whose row pairs share a length; what the autotune keeps on fine levels larger than the Infinity Cache).
- * 7, 8, 9 and 11 to 14 are
+ * 15 k_sellpx: k_sellp with the windows of x that a workgroup of 512 rows reaches staged in LDS and a 16-bit table per
+ * workgroup (operators that qualify for 11 and whose pattern offsets fall into at most 16 clusters that fit 80 KiB of LDS
+ * together with the table).
+ * 7, 8, 9 and 11 to 15 are
  * built from a host copy of the values that the library keeps only until the plan-time autotune (SGPU_ERR_ARG
  * afterwards, and where the form does not apply) */
 int sgpu_op_set_variant(sgpu_op *op, int variant);

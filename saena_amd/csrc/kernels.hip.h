@@ -768,6 +768,109 @@ __global__ __launch_bounds__(WIDE ? SPW_BLOCK : BLOCK) void k_sellp(const SpmvAr
 }
 
 // ---------------------------------------------------------------------------
+// K1x: k_sellp with THE INPUT VECTOR IN LDS.  On the first smoothed-aggregation level (68 entries per row) k_sellp<WIDE> is bound
+// by the load path, not by bytes: for every 8 B of the value stream it gathers 8 B of x, and the two together pass the CU's
+// vector-memory unit at ~16 B per clock (4.7 TB/s of values on 256^3 L1; half the gather instructions -- k_sellp2<WIDE> --
+// change nothing).  But the offsets of a pattern operator come in a few CLUSTERS (level 1: the 5 x 5 grid lines around the
+// row in 5 planes -- five clusters of a few hundred columns): a workgroup of SPX_ROWS consecutive rows reads x only inside
+// nwin windows [r0 + omin_c, r0 + SPX_ROWS + omax_c), 41-70 KiB in all, which it loads ONCE with coalesced loads (a ninth of
+// the bytes the gathers moved) and then gathers from LDS (a ds_read_b64 of 64 consecutive doubles: 4 clocks).
+// The pattern table moves to 16 bits: entry j of a pattern is the LDS position of its column for the workgroup's first row
+// (window base + offset inside the window), a lane adds its row's index in the workgroup.  And it becomes PER WORKGROUP: the 512
+// rows of a workgroup follow a dozen of the operator's patterns, so the host stores, per workgroup, just those (2-3 KiB next to
+// 278 KiB of values) and numbers the rows' pattern ids within them -- the whole table (31 KiB on level 1) would leave room for one
+// workgroup per CU only, which measured 147 against k_sellp<WIDE>'s 111 us.
+// a.val / a.cmptr: k_sell's values and slice starts; a.dst: workgroup-local pattern ids; a.ptab: the workgroups' tables as 16-bit
+// words (n starts, then per pattern its length and positions), workgroup b owns words [a.segptr[b], a.segptr[b + 1]); a.segtab:
+// nwin, then (omin, LDS base, size) per window.
+// Same products, same sequential row sum: bit-identical to k_sellp.
+constexpr int SPX_BLOCK = 512;
+constexpr int SPX_ROWS  = 512;                 // rows per workgroup: 8 slices of 64 (256 rows, 3-4 workgroups per CU: 127.5 against 119.7 us of k_sellp<WIDE>)
+constexpr int SPX_MAXWIN = 16;
+constexpr int SPX_LDS_BYTES = 80 * 1024;       // windows + table: two workgroups per CU
+template <int EPI, bool HALO, bool PAIR, bool NT>
+__global__ __launch_bounds__(SPX_BLOCK) void k_sellpx(const SpmvArgs a, int nrows) {
+    __shared__ double spx_lds[SPX_LDS_BYTES / 8];
+    if constexpr (HALO) fork_signal(a);
+    constexpr int SPW = SPX_ROWS / 64;                            // slices per workgroup
+    const int ngrp = (a.nblk + SPW - 1) / SPW;
+    const int b = xcd_remap(blockIdx.x, ngrp);
+    const int r0 = b * SPX_ROWS;
+    const int nwin = a.segtab[0];
+    int xtot = 0;
+    for (int c = 0; c < nwin; ++c) {                              // the windows of x, zero where they leave the vector
+        const int omin = a.segtab[1 + 3 * c], base = a.segtab[2 + 3 * c], size = a.segtab[3 + 3 * c];
+        const int c0 = r0 + omin;
+        for (int i = threadIdx.x; i < size; i += SPX_BLOCK) {     // (a flat loop over all windows with 5 or 20 loads in flight per thread
+            const int col = c0 + i;                               //  measured slower: 126 / 134 against 114 us on 128^3 level 1)
+            spx_lds[base + i] = (col >= 0 && col < a.ncols) ? a.x[col] : 0.0;
+        }
+        xtot = base + size;
+    }
+    unsigned short *tab = reinterpret_cast<unsigned short *>(spx_lds + xtot);
+    {                                                             // this workgroup's patterns (a multiple of four 16-bit words)
+        const int w0 = a.segptr[b], nw = a.segptr[b + 1] - w0;
+        const uint2 *gt = reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(a.ptab) + w0);
+        uint2 *lt = reinterpret_cast<uint2 *>(tab);
+        for (int i = threadIdx.x; i < (nw >> 2); i += SPX_BLOCK) lt[i] = gt[i];
+    }
+    __syncthreads();
+    const int s = __builtin_amdgcn_readfirstlane(b * SPW + ((int)threadIdx.x >> 6));
+    if (s >= a.nblk) return;
+    const int lane = threadIdx.x & 63;
+    const int r = s * 64 + lane;
+    const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 6;
+    int pid = 0;
+    if (r < nrows) { if constexpr (NT) pid = __builtin_nontemporal_load(a.dst + r); else pid = a.dst[r]; }
+    const unsigned short *pt = tab + tab[pid];
+    const int len = r < nrows ? (int)pt[0] : 0;
+    ++pt;
+    const int wmax = len > 0 ? len - 1 : 0;
+    const double *xr = spx_lds + (r - r0);                        // position j of this lane's row: xr[pt[j]]
+    auto xof = [&](int j) { return xr[pt[j < wmax ? j : wmax]]; };      // (positions past the row's length re-read its last column and are never added)
+    const bool ntv = NT && s >= a.nt_from;
+    double sum = 0.0;
+    if constexpr (!PAIR) {
+        const double *v = a.val + p + lane;
+        for (int j = 0; j < w; j += 8) {
+            double vv[8], xx[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = ld_once<NT>(v + (j + u < w ? j + u : w - 1) * 64);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xx[u] = xof(j + u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j + u < len) sum += vv[u] * xx[u];
+        }
+    } else {
+        const int P = w >> 1;
+        const sk_d2v *v2 = reinterpret_cast<const sk_d2v *>(a.val + p) + lane;
+        constexpr int UP = 8;
+        double vt = 0.0, xt = 0.0;
+        if (w & 1) {                                   // the odd last position first, as in k_sell
+            vt = ld_once<NT>(a.val + p + P * 128 + lane);
+            xt = xof(w - 1);
+        }
+        for (int q = 0; q < P; q += UP) {
+            sk_d2v vv[UP];
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                const sk_d2v *vp = v2 + (q + u < P ? q + u : P - 1) * 64;
+                if (ntv) vv[u] = __builtin_nontemporal_load(vp); else vv[u] = *vp;
+            }
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                const double x0 = xof(2 * (q + u)), x1 = xof(2 * (q + u) + 1);
+                if (q + u < P && 2 * (q + u) < len) sum += vv[u].x * x0;
+                if (q + u < P && 2 * (q + u) + 1 < len) sum += vv[u].y * x1;
+            }
+        }
+        if ((w & 1) && w - 1 < len) sum += vt * xt;
+    }
+    if (r < nrows) epilogue<EPI, HALO, NT>(a, r, sum);
+}
+
+// ---------------------------------------------------------------------------
 // K1q: k_sellp with a lane owning TWO consecutive rows.  On the 7-point level a gather instruction of k_sellp moves 64
 // consecutive doubles, and its cost is per INSTRUCTION (~20 ns per instruction and CU whatever the 64 addresses are,
 // profiles/r02_gather_bench.log): 7 gathers per 64 rows are ~17 us of the cache-resident 128^3 operator's 23 us.  Rows r and

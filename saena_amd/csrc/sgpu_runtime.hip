@@ -166,7 +166,7 @@ struct CsrPart {
     int64_t         sp_bytes = 0;      // values + pattern ids + x + y as this form stores them
     bool            sp_ok = false, sp_wide = false;   // sp_wide: the compact table of k_sellp<WIDE> (sp_w = its ints)
     char            sp_tried = 0;
-    void free_sellp() { hipFree(sp_pat); hipFree(sp_tab); sp_pat = nullptr; sp_tab = nullptr; sp_ok = false; sp_wide = false; sp_tried = 0; }
+    void free_sellp() { hipFree(sp_pat); hipFree(sp_tab); sp_pat = nullptr; sp_tab = nullptr; sp_ok = false; sp_wide = false; sp_tried = 0; }      // (and k_sellpx with it: free_sell)
     // the column codes of k_sell alone (k_sellp keeps the values and the slice pointers)
     void free_sell_columns() {
         hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr);
@@ -175,6 +175,8 @@ struct CsrPart {
     }
     void free_sell() {
         free_sellp();
+        hipFree(spx_tab); hipFree(spx_pat); hipFree(spx_win); hipFree(spx_wgptr);                                 // (free_sellpx, declared below)
+        spx_tab = spx_pat = nullptr; spx_win = spx_wgptr = nullptr; spx_ok = false; spx_tried = 0;
         hipFree(sl_val); hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr); hipFree(sl_ptr);
         sl_val = nullptr; sl_col = sl_len = nullptr; sl_base = sl_segptr = sl_ptr = nullptr; sl_ok = false; sl_tried = 0;
     }
@@ -200,6 +202,19 @@ struct CsrPart {
     bool            sp2_ok = false;
     char            sp2_tried = 0;
     void free_sellp2() { hipFree(sp2_val); hipFree(sp2_ptr); sp2_val = nullptr; sp2_ptr = nullptr; sp2_ok = false; sp2_tried = 0; }
+    // k_sellp with x in LDS windows (variant 15, k_sellpx): the table as 16-bit LDS positions, the windows of x per workgroup;
+    // shares sl_val / sl_ptr / sp_pat.  h_pstart / h_ptab: host copy of the patterns (start of each, then length + offsets), kept
+    // until the plan settles
+    std::vector<int> h_pstart, h_ptab;
+    std::vector<unsigned short> h_pat;     // ... and of the rows' pattern ids
+    unsigned short *spx_tab = nullptr, *spx_pat = nullptr;       // the workgroups' tables back to back; workgroup-local pattern ids per row
+    int            *spx_win = nullptr, *spx_wgptr = nullptr;     // windows (count, then omin / LDS base / size each); table of workgroup g: words [spx_wgptr[g], spx_wgptr[g + 1])
+    bool            spx_ok = false;
+    char            spx_tried = 0;
+    void free_sellpx() {
+        hipFree(spx_tab); hipFree(spx_pat); hipFree(spx_win); hipFree(spx_wgptr);
+        spx_tab = spx_pat = nullptr; spx_win = spx_wgptr = nullptr; spx_ok = false; spx_tried = 0;
+    }
     // row templates (variant 13, k_rowt, opt-in): a template id per row; tables of (length, relative columns) and of values
     unsigned short *rt_pat = nullptr;
     int            *rt_itab = nullptr;
@@ -234,6 +249,7 @@ struct CsrPart {
         free_sellx();
         free_rowt();
         free_sellp2();
+        free_sellpx();
     }
 };
 
@@ -663,6 +679,7 @@ int build_sellp(CsrPart &P) {
     CHK(dev_upload(&P.sp_pat, pat.data(), pat.size()));
     CHK(dev_upload(&P.sp_tab, tab.data(), tab.size()));
     P.sp_w = wide ? (int)tab.size() : W; P.sp_n = npat; P.sp_wide = wide;
+    P.h_pstart = std::move(cstart); P.h_ptab = std::move(ctab); P.h_pat = std::move(pat);      // (for build_sellpx; dropped when the plan settles)
     {                                                          // groups of 16 slices per workgroup of the wide form: the table load is paid once per workgroup
         const int ngrp = (P.nslices + 15) / 16, env = std::getenv("SAENA_SELLPW_GROUPS") ? std::atoi(std::getenv("SAENA_SELLPW_GROUPS")) : 0;
         (void)ngrp;                                            // measured on Poisson level 1: 1 group 123 / 960 us (128^3 / 256^3), 2 groups 128 / 962, 4 groups - / 995
@@ -670,6 +687,94 @@ int build_sellp(CsrPart &P) {
     }
     P.sp_bytes = 8 * (int64_t)P.h_rp.back() + 2 * (int64_t)M + 8 * (int64_t)P.ncols + 8 * (int64_t)M;
     P.sp_ok = true;
+    return SGPU_OK;
+}
+
+// k_sellpx on top of build_sellp's patterns: the offsets of all patterns fall into clusters (gaps of more than SPX_ROWS columns
+// separate them); a workgroup of SPX_ROWS rows starting at r0 needs x inside the windows [r0 + omin_c, r0 + SPX_ROWS + omax_c), laid
+// out one after the other in LDS.  A pattern's entry becomes the LDS position of its column for the workgroup's FIRST row: window
+// base + (offset - omin_c).  Every workgroup gets its own small table -- the patterns its rows follow, in order of first
+// appearance -- and its rows' ids count within it.  The form applies when windows and the largest of these tables fit
+// SPX_LDS_BYTES (two workgroups per CU).
+int build_sellpx(CsrPart &P) {
+    if (P.spx_ok || P.spx_tried || !P.sp_ok || !P.sl_val || P.h_ptab.empty() || P.h_pat.empty()) return SGPU_OK;
+    P.spx_tried = 1;
+    const int npat = (int)P.h_pstart.size(), M = P.nrows;
+    std::vector<int> offs;
+    for (int i = 0; i < npat; ++i) {
+        const int *c = &P.h_ptab[(size_t)P.h_pstart[(size_t)i]];
+        offs.insert(offs.end(), c + 1, c + 1 + c[0]);
+    }
+    std::sort(offs.begin(), offs.end());
+    offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+    if (offs.empty()) return SGPU_OK;
+    std::vector<int> omin, omax, base;
+    for (size_t i = 0; i < offs.size(); ++i) {
+        if (i == 0 || (int64_t)offs[i] - offs[i - 1] > sk::SPX_ROWS) { omin.push_back(offs[i]); omax.push_back(offs[i]); }
+        else omax.back() = offs[i];
+    }
+    const int nwin = (int)omin.size();
+    if (nwin > sk::SPX_MAXWIN) return SGPU_OK;
+    int64_t S = 0;
+    for (int c = 0; c < nwin; ++c) { base.push_back((int)S); S += (int64_t)sk::SPX_ROWS + ((int64_t)omax[(size_t)c] - omin[(size_t)c]); if (S > 65535) return SGPU_OK; }
+    if (S * 8 >= (int64_t)sk::SPX_LDS_BYTES) return SGPU_OK;
+    const int64_t room = ((int64_t)sk::SPX_LDS_BYTES - S * 8) / 2;           // 16-bit words left for a workgroup's table
+    // every pattern once as (length, LDS positions)
+    std::vector<unsigned short> pos16;
+    std::vector<int> pstart16((size_t)npat + 1, 0);
+    for (int i = 0; i < npat; ++i) {
+        const int *c = &P.h_ptab[(size_t)P.h_pstart[(size_t)i]];
+        pstart16[(size_t)i] = (int)pos16.size();
+        pos16.push_back((unsigned short)c[0]);
+        for (int j = 0; j < c[0]; ++j) {
+            const int w = (int)(std::upper_bound(omin.begin(), omin.end(), c[1 + j]) - omin.begin()) - 1;      // the window that holds the offset
+            pos16.push_back((unsigned short)(base[(size_t)w] + (c[1 + j] - omin[(size_t)w])));
+        }
+        if (c[0] == 0) pos16.push_back(0);                        // (an empty row reads position 0 and adds nothing)
+    }
+    pstart16[(size_t)npat] = (int)pos16.size();
+    const int ngrp = (M + sk::SPX_ROWS - 1) / sk::SPX_ROWS;
+    std::vector<int> wgptr((size_t)ngrp + 1, 0);
+    std::vector<unsigned short> tab, lpat(P.h_pat.size(), 0);
+    std::vector<int> local((size_t)npat, -1), used;
+    int64_t max_words = 0;
+    for (int g = 0; g < ngrp; ++g) {
+        used.clear();
+        const int r1 = std::min(M, (g + 1) * sk::SPX_ROWS);
+        for (int r = g * sk::SPX_ROWS; r < r1; ++r) {
+            const int id = P.h_pat[(size_t)r];
+            if (local[(size_t)id] < 0) { local[(size_t)id] = (int)used.size(); used.push_back(id); }
+            lpat[(size_t)r] = (unsigned short)local[(size_t)id];
+        }
+        if (used.empty()) { used.push_back(0); }
+        int64_t words = (int64_t)used.size();
+        for (int id : used) words += pstart16[(size_t)id + 1] - pstart16[(size_t)id];
+        words = (words + 3) / 4 * 4;
+        max_words = std::max(max_words, words);
+        if (words > room || words > 65535 || (int64_t)tab.size() + words > (int64_t)INT32_MAX - 8) { P.h_pat.shrink_to_fit(); return SGPU_OK; }
+        const size_t t0 = tab.size();
+        tab.resize(t0 + (size_t)words, 0);
+        size_t at = t0 + used.size();
+        for (size_t k = 0; k < used.size(); ++k) {
+            const int id = used[k];
+            tab[t0 + k] = (unsigned short)(at - t0);
+            for (int q = pstart16[(size_t)id]; q < pstart16[(size_t)id + 1]; ++q) tab[at++] = pos16[(size_t)q];
+            local[(size_t)id] = -1;
+        }
+        wgptr[(size_t)g + 1] = (int)tab.size();
+    }
+    if (std::getenv("SAENA_SETUP_TIMING"))
+        fprintf(stderr, "[sgpu] x in LDS for the row patterns: %d windows, %lld doubles of x + at most %lld table words per workgroup of %d rows (%.1f KiB); tables %.1f MB\n", nwin,
+                (long long)S, (long long)max_words, sk::SPX_ROWS, (double)(S * 8 + max_words * 2) / 1024.0, (double)tab.size() * 2e-6);
+    std::vector<int> win(1 + 3 * (size_t)nwin);
+    win[0] = nwin;
+    for (int c = 0; c < nwin; ++c) { win[1 + 3 * (size_t)c] = omin[(size_t)c]; win[2 + 3 * (size_t)c] = base[(size_t)c]; win[3 + 3 * (size_t)c] = sk::SPX_ROWS + (omax[(size_t)c] - omin[(size_t)c]); }
+    tab.resize(tab.size() + 8, 0);
+    CHK(dev_upload(&P.spx_tab, tab.data(), tab.size()));
+    CHK(dev_upload(&P.spx_wgptr, wgptr.data(), wgptr.size()));
+    CHK(dev_upload(&P.spx_pat, lpat.data(), lpat.size()));
+    CHK(dev_upload(&P.spx_win, win.data(), win.size()));
+    P.spx_ok = true;
     return SGPU_OK;
 }
 
@@ -1047,6 +1152,23 @@ SellKernelFn pick_sellp(int epi, bool halo, bool pair, bool nt, bool wide) {
     if (wide) return nt ? pick_sellp_n<true, true>(epi, halo, pair) : pick_sellp_n<false, true>(epi, halo, pair);
     return nt ? pick_sellp_n<true, false>(epi, halo, pair) : pick_sellp_n<false, false>(epi, halo, pair);
 }
+template <bool HALO, bool PAIR, bool NT>
+SellKernelFn pick_sellpx_h(int epi) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return sk::k_sellpx<sk::EPI_SPMV, HALO, PAIR, NT>;
+        case sk::EPI_RESIDUAL: return sk::k_sellpx<sk::EPI_RESIDUAL, HALO, PAIR, NT>;
+        case sk::EPI_JACOBI:   return sk::k_sellpx<sk::EPI_JACOBI, HALO, PAIR, NT>;
+        case sk::EPI_CHEBY0:   return sk::k_sellpx<sk::EPI_CHEBY0, HALO, PAIR, NT>;
+        case sk::EPI_CHEBYK:   return sk::k_sellpx<sk::EPI_CHEBYK, HALO, PAIR, NT>;
+        case sk::EPI_RSWEEP:   return sk::k_sellpx<sk::EPI_RSWEEP, HALO, PAIR, NT>;
+        default:               return sk::k_sellpx<sk::EPI_SUB, HALO, PAIR, NT>;
+    }
+}
+template <bool NT>
+SellKernelFn pick_sellpx_n(int epi, bool halo, bool pair) {
+    return halo ? (pair ? pick_sellpx_h<true, true, NT>(epi) : pick_sellpx_h<true, false, NT>(epi)) : (pair ? pick_sellpx_h<false, true, NT>(epi) : pick_sellpx_h<false, false, NT>(epi));
+}
+SellKernelFn pick_sellpx(int epi, bool halo, bool pair, bool nt) { return nt ? pick_sellpx_n<true>(epi, halo, pair) : pick_sellpx_n<false>(epi, halo, pair); }
 using XldsKernelFn = void (*)(const sk::SpmvArgs, const sk::XldsArgs);
 template <int EPI, bool HALO>
 XldsKernelFn pick_xlds_g(int lanes) {
@@ -1129,6 +1251,15 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
             : epi == sk::EPI_JACOBI ? sk::k_dense_rows<sk::EPI_JACOBI> : epi == sk::EPI_CHEBY0 ? sk::k_dense_rows<sk::EPI_CHEBY0>
             : epi == sk::EPI_CHEBYK ? sk::k_dense_rows<sk::EPI_CHEBYK> : epi == sk::EPI_RSWEEP ? sk::k_dense_rows<sk::EPI_RSWEEP> : sk::k_dense_rows<sk::EPI_SUB>;
         SGPU_LAUNCH(kd, dim3((P.nrows + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, (const double *)P.dense, P.nrows, P.ncols);
+    } else if (P.variant == 15) {                                 // k_sellp with x in LDS windows
+        if (!P.spx_ok || !P.sp_ok || !P.sl_val) return fail(SGPU_ERR_STATE, "the row-pattern form with x in LDS was not built");
+        a.blk_row = nullptr; a.nblk = P.nslices;
+        a.val = P.sl_val; a.cmptr = P.sl_ptr; a.dst = P.spx_pat; a.ptab = reinterpret_cast<const int *>(P.spx_tab); a.pt_w = 0; a.pt_n = P.sp_n;
+        a.segtab = P.spx_win; a.segptr = P.spx_wgptr; a.ncols = P.ncols;
+        static const int nt_envx = std::getenv("SAENA_SELLP_NT") ? std::atoi(std::getenv("SAENA_SELLP_NT")) : -1;
+        const bool nt = nt_envx >= 0 ? nt_envx != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
+        a.nt_from = nt ? resident_slices(P.nslices, 8.0 * (double)P.nnz / (double)std::max(1, P.nslices)) : 0;
+        SGPU_LAUNCH(pick_sellpx(epi, halo, P.sl_pair, nt), dim3((P.nslices + sk::SPX_ROWS / 64 - 1) / (sk::SPX_ROWS / 64)), dim3(sk::SPX_BLOCK), 0, g.cs, a, P.nrows);
     } else if (P.variant == 14) {                                 // k_sellp with a lane per two rows
         if (!P.sp2_ok || !P.sp_ok) return fail(SGPU_ERR_STATE, "the row-paired row-pattern form was not built");
         a.blk_row = nullptr; a.nblk = P.sp2_nslices;
@@ -1962,7 +2093,7 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx", "k_rowt", "k_sellp2"};   // (3, 4, 7, 8 are named with their slot/offset split below)
+    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx", "k_rowt", "k_sellp2", "k_sellpx"};   // (3, 4, 7, 8 are named with their slot/offset split below)
     if (variant) *variant = op->loc.variant;
     if (kernel_name) {
         const int v = op->loc.variant;
@@ -1981,7 +2112,15 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 14) return fail(SGPU_ERR_ARG, "variant must be 0..14");
+    if (variant < 0 || variant > 15) return fail(SGPU_ERR_ARG, "variant must be 0..15");
+    if (variant == 15) {
+        CHK(build_sell(op->loc, op->h_val_all));
+        CHK(build_sellp(op->loc));
+        CHK(build_sellpx(op->loc));
+        if (!op->loc.spx_ok)
+            return fail(SGPU_ERR_ARG, "the row-pattern form with x in LDS needs what the row-pattern form needs (k_sellp) and pattern offsets that fall into at most %d "
+                                      "windows of x which fit %d KiB of LDS together with the table", sk::SPX_MAXWIN, sk::SPX_LDS_BYTES / 1024);
+    }
     if (variant == 14) {
         CHK(build_sell(op->loc, op->h_val_all));
         CHK(build_sellp(op->loc));
@@ -2040,6 +2179,7 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
 // ---- plan cache: what the autotune chose for an operator of this shape on this device, so that a second process picks the
 // same kernel (same summation order: bit-identical solves across processes) and skips the sweep.  One line per operator in
 // $SAENA_PLAN_CACHE, default $XDG_CACHE_HOME or ~/.cache + /saena_amd/plans-v1.tsv; SAENA_PLAN_CACHE=off disables it.
+extern "C++" {                                              // (helpers with C++ types inside the extern "C" block)
 namespace {
 uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
     const unsigned char *b = static_cast<const unsigned char *>(p);
@@ -2123,9 +2263,11 @@ void finish_plan(sgpu_op *op, int bv) {
         CsrPart &L = op->loc;
         L.free_sell_columns();
         hipFree(L.sl_val); hipFree(L.sl_ptr); L.sl_val = nullptr; L.sl_ptr = nullptr;
-    } else if (bv != 9 && bv != 11 && !keep) op->loc.free_sell();
-    else if (bv == 11 && !keep) op->loc.free_sell_columns();    // k_sellp keeps the values and the slice pointers only
+    } else if (bv != 9 && bv != 11 && bv != 15 && !keep) op->loc.free_sell();
+    else if ((bv == 11 || bv == 15) && !keep) op->loc.free_sell_columns();    // k_sellp / k_sellpx keep the values and the slice pointers only
     else if (bv == 9 && !keep) op->loc.free_sellp();
+    if (bv != 15 && !keep) op->loc.free_sellpx();
+    if (!keep) { std::vector<int>().swap(op->loc.h_pstart); std::vector<int>().swap(op->loc.h_ptab); std::vector<unsigned short>().swap(op->loc.h_pat); }
     if (bv != 13 && !keep) op->loc.free_rowt();
     if (bv != 12 && !keep) op->loc.free_sellx();
     if (bv != 10 && bv != 12 && !keep) op->loc.free_xlds();
@@ -2138,9 +2280,10 @@ void finish_plan(sgpu_op *op, int bv) {
         }
 }
 // does the form add a row's products one after the other in column order (the reference's sum, whatever else is tuned)?
-bool sequential_sum(int v, int lanes) { return v == 9 || v == 11 || v == 13 || v == 14 || (lanes == 1 && (v == 0 || v == 1 || v == 3 || v == 4 || v == 7 || v == 8)); }
+bool sequential_sum(int v, int lanes) { return v == 9 || v == 11 || v == 13 || v == 14 || v == 15 || (lanes == 1 && (v == 0 || v == 1 || v == 3 || v == 4 || v == 7 || v == 8)); }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 } // namespace
+} // extern "C++"
 
 // Plan-time autotune of the local kernel: time the (variant, lanes) candidates that the operator's row lengths leave in
 // play on the operator itself and keep the fastest.  Summation order inside a row depends on the choice, so results may
@@ -2194,6 +2337,10 @@ int sgpu_op_autotune(sgpu_op *op) {
                                                                                                          // wide table it ties with k_sellp: 957 / 962 us on 256^3 level 1, 124 / 123 on 128^3)
                     CHK(build_sellp2(op->loc, op->h_val_all));
                     if (op->loc.sp2_ok) variants.push_back(14);
+                }
+                if (op->loc.sp_ok && avg_row >= 16.0 && !std::getenv("SAENA_NO_SELLPX")) {                 // ... with x in LDS windows: where a row gathers dozens of entries
+                    CHK(build_sellpx(op->loc));
+                    if (op->loc.spx_ok) variants.push_back(15);
                 }
                 if (op->loc.sp_ok && std::getenv("SAENA_ROW_TEMPLATES")) {                               // OPT-IN: rows that also repeat their values
                     CHK(build_rowt(op->loc, op->h_val_all));
@@ -2253,7 +2400,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     std::vector<std::pair<int, int>> cands;
     for (int v : variants)
         for (int gl : (v == 10 ? lanes_x : lanes)) {
-            if ((v == 9 || v == 11 || v == 12 || v == 13 || v == 14) && gl != lanes.front()) continue;      // a lane per row (piece) whatever the setting
+            if ((v == 9 || v == 11 || v == 12 || v == 13 || v == 14 || v == 15) && gl != lanes.front()) continue;      // a lane per row (piece) whatever the setting
             if (v == 5 && gl != lanes.front()) continue;                   // one wave per dense row likewise
             cands.push_back({v, gl});
         }

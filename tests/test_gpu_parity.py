@@ -139,7 +139,7 @@ def _sellp_eligible(entries, M):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 14])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 14, 15])
 def test_kernel_variants(capi, name, variant, monkeypatch):
     """32 KiB tiles / vector CSR / 16-bit compressed columns (16 and 32 KiB tiles; long rows included) / wave-streamed
     long rows / compressed columns with the block's entries in column order (16 and 32 KiB tiles) / sliced ELLPACK /
@@ -170,7 +170,14 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
             assert "row-paired" in str(e)
             return
     table = _sellp_table(entries, M)
-    if variant in (11, 14) and table is None:
+    if variant == 15 and table is not None:                # the row patterns with x in LDS: refused where windows and table do not fit (the library's own count)
+        try:
+            G.set_variant(variant)
+        except capi.SgpuError as e:
+            assert "x in LDS" in str(e)
+            return
+        assert G.variant()[1] == "k_sellpx"
+    if variant in (11, 14, 15) and table is None:
         with pytest.raises(capi.SgpuError, match="row-pattern"):       # rows that follow no small set of patterns: refused
             G.set_variant(variant)
         return
@@ -194,7 +201,7 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         G.set_lanes_per_row(lanes)
         G.spmv(dx, dy)
         got, want = dy.download(), A.matvec(x)
-        if (lanes == 1 or variant in (9, 11, 14)) and variant not in (2, 6, 10, 12) and (name != "band3000_1400" or variant in (1, 4, 8)):
+        if (lanes == 1 or variant in (9, 11, 14, 15)) and variant not in (2, 6, 10, 12) and (name != "band3000_1400" or variant in (1, 4, 8)):
             np.testing.assert_array_equal(got, want)          # stream variants keep the sequential row sum
         else:
             assert np.all(np.abs(got - want) <= TOL_SPMV * bound + 1e-300)
@@ -813,9 +820,9 @@ def _patterned_operator(M, npat, length, reach, seed, run=1):
 
 
 @pytest.mark.parametrize("groups", [0, 3])
-@pytest.mark.parametrize("variant", [11, 14])
+@pytest.mark.parametrize("variant", [11, 14, 15])
 def test_row_patterns_wide_table(capi, variant, groups, monkeypatch):
-    """k_sellp<wide> / k_sellp2<wide>: an operator whose rows follow a few HUNDRED patterns of several dozen entries (the first smoothed-
+    """k_sellp<wide> / k_sellp2<wide> / k_sellpx (the same patterns with the windows of x they reach in LDS): an operator whose rows follow a few HUNDRED patterns of several dozen entries (the first smoothed-
     aggregation level of a structured grid: 321 patterns, 14 469 offsets at every size of the Poisson cube) keeps the table
     compactly in 72 KiB of LDS shared by 1024 threads, each workgroup serving `groups` groups of 16 slices (0: the library's
     choice).  No column stream, the reference's sequential row sum: bit-identical to the CSR loop for every epilogue; with too
@@ -831,7 +838,7 @@ def test_row_patterns_wide_table(capi, variant, groups, monkeypatch):
     A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
     G = util.gpu_operator(A)
     G.set_variant(variant)
-    assert G.variant()[1] == ("k_sellp<wide>" if variant == 11 else "k_sellp2<wide>")
+    assert G.variant()[1] == {11: "k_sellp<wide>", 14: "k_sellp2<wide>", 15: "k_sellpx"}[variant]
     x, rhs = inputs.v2(M), inputs.rhs2(M)
     dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
     G.spmv(dx, dy)
@@ -854,6 +861,52 @@ def test_row_patterns_wide_table(capi, variant, groups, monkeypatch):
         G2 = util.gpu_operator(orc.OracleOp(many, 30000, 30000, orc.split_even(30000, 1)))
         with pytest.raises(capi.SgpuError, match="row-pattern"):
             G2.set_variant(variant)
+
+
+def test_row_patterns_with_x_in_lds_windows(capi, monkeypatch):
+    """k_sellpx: the offsets of the patterns fall into five clusters 1000-2000 columns apart (the shape of a smoothed-aggregation
+    level on a structured grid: a few grid lines in a few planes), so a workgroup of 512 rows reads x inside five windows, which it
+    stages in LDS; windows that leave the vector at its two ends are zero-filled and never read.  Bit-identical to the CSR loop
+    for every epilogue; offsets spread over more than 16 windows are refused."""
+    monkeypatch.setenv("SAENA_KEEP_HOST_VALUES", "1")
+    rng = np.random.default_rng(21)
+    M = 23000 + 19
+    pool = np.concatenate([c + np.arange(-15, 16) for c in (-3000, -1000, 0, 1000, 3000)])
+    pats = [np.sort(np.unique(np.concatenate([rng.choice(pool, size=29 + k % 2, replace=False), [0]]))) for k in range(60)]
+    rows, cols = [], []
+    for r in range(M):
+        c = r + pats[(r // 7) % 60]
+        c = c[(c >= 0) & (c < M)]
+        rows.append(np.full(len(c), r)); cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    entries = orc.coo_from_arrays(rows.astype(np.int32), cols.astype(np.int32), np.cos(0.37 * rows - 0.11 * cols) + 1.25)
+    assert _sellp_table(entries, M) == "wide"
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    G.set_variant(15)
+    assert G.variant()[1] == "k_sellpx"
+    x, rhs = inputs.v2(M), inputs.rhs2(M)
+    dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
+    G.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), A.matvec(x))
+    G.residual(dx, dr, dy)
+    np.testing.assert_array_equal(dy.download(), A.residual(x, rhs))
+    du = capi.DeviceVector(M, x)
+    G.jacobi(3, du, dr)
+    np.testing.assert_array_equal(du.download(), A.jacobi(3, x, rhs))
+    du = capi.DeviceVector(M, rhs)
+    G.prolong_correct(dx, du)
+    np.testing.assert_array_equal(du.download(), rhs - A.matvec(x))
+    # 20 clusters: more windows than the kernel takes
+    far = np.concatenate([[0], 700 * np.arange(1, 11), -700 * np.arange(1, 11)])
+    M2 = 16000
+    rows = np.repeat(np.arange(M2), len(far)); cols = rows + np.tile(np.sort(far), M2)
+    ok = (cols >= 0) & (cols < M2)
+    e2 = orc.coo_from_arrays(rows[ok].astype(np.int32), cols[ok].astype(np.int32), np.ones(int(ok.sum())))
+    G2 = util.gpu_operator(orc.OracleOp(e2, M2, M2, orc.split_even(M2, 1)))
+    if _sellp_table(e2, M2) is not None:
+        with pytest.raises(capi.SgpuError, match="x in LDS"):
+            G2.set_variant(15)
 
 
 def test_plan_cache_makes_a_second_operator_take_the_first_one_s_plan(capi, tmp_path, monkeypatch):
