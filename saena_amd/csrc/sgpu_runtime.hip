@@ -2352,7 +2352,8 @@ int sgpu_op_autotune(sgpu_op *op) {
     const double t_sell = now_s();
     const bool short_rows = sell_like && avg_row <= 128.0 && !all;
     for (int k = 0; k < 2; ++k) {
-        if (k == 1 && (short_rows || avg_row < 32.0) && !all) continue;                              // 32 KiB tiles never won on short rows
+        if (k == 1 && (short_rows || avg_row < 16.0) && !all) continue;                              // 32 KiB tiles never won on the shortest rows (at 18 entries per
+                                                                                                     // row -- P1 of 256^3 -- they do: 361 against 385 us, profiles/r03_transfers_sell_padding.log)
         CHK(build_cc16(op->loc, k));
         if (op->loc.cc_ok[k]) variants.push_back(3 + k);
     }
