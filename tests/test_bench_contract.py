@@ -40,14 +40,22 @@ def test_committed_kernel_trace_agrees_with_the_bench_line():
     the average duration of the bench kernel on the 128^3 operator agrees with the line's HIP-event figure, in the
     profiled run itself and in the committed unprofiled line"""
     import csv
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_bench_n1_kernel_stats_by_grid.csv"))))
-    for name in ("r02_bench_n1_under_rocprof.json", "r02_bench_n1.json"):
-        d = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
-        kernel = d["roofline"]["kernel"].split(",")[0].split("<")[0]           # "k_sell" | "k_csr_cc16"
-        rows_per_wg = 256                                                      # k_sell: 4 slices of 64 rows per workgroup
-        cand = [r for r in rows if f"sk::{kernel}<0," in r["Name"] and int(r["Calls"]) >= 100]
-        if kernel == "k_sell":
-            cand = [r for r in cand if int(r["Workgroups"]) == (2000376 + rows_per_wg - 1) // rows_per_wg]
-        assert cand, (kernel, [r["Name"] for r in rows[:5]])
-        avg_us = float(max(cand, key=lambda r: int(r["Calls"]))["AverageNs"]) / 1e3
-        assert abs(avg_us - d["roofline"]["us_per_launch"]) <= 0.05 * avg_us, (name, avg_us, d["roofline"]["us_per_launch"])
+    for rnd in ("r02", "r03"):
+        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_n1_kernel_stats_by_grid.csv"))))
+        for name in (f"{rnd}_bench_n1_under_rocprof.json", f"{rnd}_bench_n1.json"):
+            d = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
+            kernel = d["roofline"]["kernel"].split(",")[0].split("<")[0]           # "k_sell" | "k_csr_cc16" | "k_sellp" (round 3)
+            rows_per_wg = 256                                                      # k_sell / k_sellp: 4 slices of 64 rows per workgroup
+            cand = [r for r in rows if f"sk::{kernel}<0," in r["Name"] and int(r["Calls"]) >= 100]
+            if kernel in ("k_sell", "k_sellp"):
+                cand = [r for r in cand if int(r["Workgroups"]) == (2000376 + rows_per_wg - 1) // rows_per_wg]
+            assert cand, (kernel, [r["Name"] for r in rows[:5]])
+            avg_us = float(max(cand, key=lambda r: int(r["Calls"]))["AverageNs"]) / 1e3
+            assert abs(avg_us - d["roofline"]["us_per_launch"]) <= 0.05 * avg_us, (name, avg_us, d["roofline"]["us_per_launch"])
+        if rnd == "r03":                                                           # ... and the HBM-resident 256^3 figure with its kernel
+            h = d["spmv_hbm_resident"]
+            hk = h["kernel"].split(",")[0]
+            cand = [r for r in rows if f"sk::{hk}<0," in r["Name"] and int(r["Workgroups"]) > 30000]
+            assert cand, hk
+            avg_us = float(max(cand, key=lambda r: int(r["Calls"]))["AverageNs"]) / 1e3
+            assert abs(avg_us - h["us_per_launch"]) <= 0.05 * avg_us, (avg_us, h["us_per_launch"])

@@ -6,6 +6,7 @@ set -e
 LV=${1:-1}; KIND=${2:-1}; V=${3:-4}; G=${4:-4}; OUT=${5:-gpurun_out/pmc_level.json}
 D=gpurun_out/pmc_L$LV; rm -rf $D; mkdir -p $D
 cd /tmp; export TMPDIR=/tmp; cd "$OLDPWD"
+export SAENA_KEEP_HOST_VALUES=1      # the variant is switched after the plan-time autotune
 i=0
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum; do
     i=$((i+1))
@@ -22,7 +23,7 @@ rows = []
 for f in sorted(glob.glob(d + "/pass*/**/*counter_collection.csv", recursive=True)):
     rows += list(csv.DictReader(open(f)))
 for r in rows:
-    if "k_csr" in r["Kernel_Name"]:
+    if "k_csr" in r["Kernel_Name"] or "k_sell" in r["Kernel_Name"]:
         names[r["Kernel_Name"]] += 1
 # the timed kernel = the k_csr_* kernel with the most launches in a pass (3 warm-up + 40 timed of the same instantiation)
 kernel = max(names, key=names.get)
