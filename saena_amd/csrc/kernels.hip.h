@@ -1125,6 +1125,8 @@ __global__ __launch_bounds__(BLOCK) void k_csr_wave(const SpmvArgs a, int nrows)
 constexpr int XL_MAX   = 20224;            // doubles of x in LDS: 161 792 B of the CU's 163 840
 constexpr int XL_MAXT  = 8;
 constexpr int XL_BLOCK = 1024;
+constexpr int XL_PER_CU = 1;              // (half windows around 512 threads, two workgroups per CU: slower on every level that uses them --
+                                           //  256^3 L2 451 against 441 us, L3 324 / 313, L4 103 / 100, profiles/r03_xlds_half_windows.log)
 struct XldsArgs {
     const int4 *info;      // per workgroup: first column, windows, offset of its table in `tab`, -
     const int  *tab;

@@ -479,7 +479,7 @@ int build_xlds(CsrPart &P) {
     P.xl_tried = 1;
     const int M = P.nrows;
     if (M == 0 || P.nnz == 0) return SGPU_OK;
-    const int nb = std::min(std::max(1, g.ncu), M);
+    const int nb = std::min(std::max(1, sk::XL_PER_CU * g.ncu), M);
     std::vector<int> blk((size_t)nb + 1, 0);
     for (int b = 1; b < nb; ++b) {                                 // row whose prefix reaches b/nb of the entries
         const int64_t target = (int64_t)P.nnz * b / nb;
