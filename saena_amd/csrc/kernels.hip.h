@@ -1147,7 +1147,14 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
         if (t > 0) __syncthreads();                               // everyone is done with the previous window
         const int base = inf.x + t * XL_MAX;
         const int n = w.ncols - base < XL_MAX ? w.ncols - base : XL_MAX;
-        for (int i = tid; i < n; i += XL_BLOCK) xs[i] = a.x[base + i];
+        for (int i0 = tid; i0 < n; i0 += 8 * XL_BLOCK) {           // eight loads of a thread in flight before their stores
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i0 + u * XL_BLOCK < n ? a.x[base + i0 + u * XL_BLOCK] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * XL_BLOCK < n) xs[i0 + u * XL_BLOCK] = v[u];
+        }
         if (tid == 0) next_row = NG;                              // the first NG rows go to the groups in order
         __syncthreads();
         const int *ts = w.tab + inf.z + t * nr, *te = ts + nr;
@@ -1234,7 +1241,14 @@ __global__ __launch_bounds__(XL_BLOCK) void k_sellx(const SpmvArgs a, const Sell
         if (t > 0) __syncthreads();                               // everyone is done with the previous window
         const int base = inf.x + t * XL_MAX;
         const int n = w.ncols - base < XL_MAX ? w.ncols - base : XL_MAX;
-        for (int i = tid; i < n; i += XL_BLOCK) xs[i] = a.x[base + i];
+        for (int i0 = tid; i0 < n; i0 += 8 * XL_BLOCK) {           // eight loads of a thread in flight before their stores
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i0 + u * XL_BLOCK < n ? a.x[base + i0 + u * XL_BLOCK] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * XL_BLOCK < n) xs[i0 + u * XL_BLOCK] = v[u];
+        }
         __syncthreads();
         const int s0 = w.bptr[blockIdx.x * (XL_MAXT + 1) + t], s1 = w.bptr[blockIdx.x * (XL_MAXT + 1) + t + 1];
         for (int s = s0 + wave; s < s1; s += NW) {
