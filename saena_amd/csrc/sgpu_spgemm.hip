@@ -21,6 +21,7 @@
 // the diagonal, saena_object_setup_matmat.cpp:2423,2442) get the key INT_MAX; one segmented radix sort per chunk of rows
 // orders every segment by column, and the kept prefix of each segment is copied out.
 #include "../../include/saena_gpu.h"
+#include "host/par.h"
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -313,18 +314,23 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
     static_assert(sizeof(long) == sizeof(long long), "nnz_t is 64-bit");
     const long a_nnz = a_ptr[a_rows], b_nnz = b_ptr[b_rows];
     // products and upper bounds per row (host, O(nnz of A))
-    std::vector<long long> ub((size_t)a_rows);
-    long long products_total = 0;
-    for (int i = 0; i < a_rows; ++i) {
-        long long w = 0;
-        for (long ka = a_ptr[i]; ka < a_ptr[i + 1]; ++ka) w += b_ptr[a_col[ka] + 1] - b_ptr[a_col[ka]];
-        products_total += w;
-        ub[(size_t)i] = std::min<long long>(w, b_cols);
-    }
     const bool timing = std::getenv("SAENA_SETUP_TIMING") != nullptr;
     double t_up = 0, t_kern = 0, t_sort = 0, t_down = 0, t_host = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    auto Tb = now();
+    std::vector<long long> ub((size_t)a_rows), prod((size_t)a_rows);
+    saena_host::parallel_chunks<int>(a_rows, 4096, [&](int, int i0, int i1) {      // (a random read of b_ptr per entry of A: seconds on one thread at 5e8 entries)
+        for (int i = i0; i < i1; ++i) {
+            long long w = 0;
+            for (long ka = a_ptr[i]; ka < a_ptr[i + 1]; ++ka) w += b_ptr[a_col[ka] + 1] - b_ptr[a_col[ka]];
+            prod[(size_t)i] = w;
+            ub[(size_t)i] = std::min<long long>(w, b_cols);
+        }
+    });
+    long long products_total = 0;
+    for (int i = 0; i < a_rows; ++i) products_total += prod[(size_t)i];
+    const double t_bounds = secs(Tb, now());
     auto T0 = now();
     SP_CHK(hipSetDevice(sgpu_context_device()));            // the setup may be driven from a thread that never selected this context's device
     Dev D;
@@ -477,6 +483,14 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
                            (const double *)sval, tcol, tval, n);
         SP_CHK(hipGetLastError());
         const size_t base = c_col.size();
+        if (c == 0 && chunk_start.size() > 2) {                                 // room for the whole result at the first chunk's density (+ 15 %): a vector
+            long long p0 = 0;                                                   // that grows chunk by chunk is re-allocated and copied again and again
+            for (int i = r0; i < r1; ++i) p0 += prod[(size_t)i];
+            if (p0 > 0) {
+                const double est = 1.15 * (double)out_n / (double)p0 * (double)products_total;
+                if (est < 3.0e9) { c_col.reserve((size_t)est); c_val.reserve((size_t)est); }
+            }
+        }
         c_col.resize(base + (size_t)out_n);
         c_val.resize(base + (size_t)out_n);
         if (out_n) {
@@ -487,8 +501,8 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
         t_down += secs(Tc, now());
     }
     if (std::getenv("SAENA_SETUP_TIMING"))
-        fprintf(stderr, "[spgemm gpu] %d x %d, %lld products -> %zu entries, %zu chunk(s): upload %.2f, row kernels %.2f, sort %.2f, copy-out+download %.2f, host %.2f, total %.2f s\n",
-                a_rows, b_cols, products_total, c_col.size(), chunk_start.size() - 1, t_up, t_kern, t_sort, t_down, t_host, secs(T0, now()));
+        fprintf(stderr, "[spgemm gpu] %d x %d, %lld products -> %zu entries, %zu chunk(s): bounds %.2f, upload %.2f, row kernels %.2f, sort %.2f, copy-out+download %.2f, host %.2f, total %.2f s\n",
+                a_rows, b_cols, products_total, c_col.size(), chunk_start.size() - 1, t_bounds, t_up, t_kern, t_sort, t_down, t_host, secs(Tb, now()));
     return 0;
 }
 
