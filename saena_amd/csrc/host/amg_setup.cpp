@@ -176,7 +176,7 @@ Csr spgemm(const CsrRef &A, const Csr &B, index_t row_offset = 0) {
     Csr C;
     C.nrows = A.nrows; C.ncols = B.ncols;
     if (g_spgemm_hook && A.nrows > 0 && B.nrows > 0 && ((size_t)A.ptr[A.nrows] + B.col.size()) >= 200000) {
-        if (g_spgemm_hook(A.nrows, B.nrows, B.ncols, A.ptr, A.col, A.val, B.ptr.data(), B.col.data(), B.val.data(),
+        if (g_spgemm_hook(A.nrows, B.nrows, B.ncols, A.ptr, A.col, A.val, B.ptr.data(), B.col.data(), B.val.data(), 0, nullptr, nullptr,
                           row_offset, C.ptr, C.col, C.val) == 0)
             return C;
         C.ptr.clear(); C.col.clear(); C.val.clear();       // the GPU declined (memory): the host kernel below
@@ -926,6 +926,33 @@ Csr stack_rows(const Csr &local, const Csr &halo) {
     std::copy(halo.val.begin(), halo.val.end(), B.val.begin() + base);
     return B;
 }
+// C = A [local; halo] without stacking the two pieces of B on the host when the GPU kernel takes them (it copies each piece to
+// its place in device memory; only the row pointers are stacked here): at 16 M rows per rank a stacked copy of level 1's
+// operator is 6.8 GB to allocate, fill and free for every product
+Csr spgemm_stacked(const CsrRef &A, const Csr &local, const Csr &halo, index_t row_offset) {
+    const nnz_t base = local.ptr[(size_t)local.nrows];
+    if (g_spgemm_hook && A.nrows > 0 && local.nrows + halo.nrows > 0 && ((size_t)A.ptr[A.nrows] + (size_t)base + halo.col.size()) >= 200000) {
+        Csr C;
+        C.nrows = A.nrows; C.ncols = local.ncols;
+        std::vector<nnz_t> ptr((size_t)local.nrows + (size_t)halo.nrows + 1);
+        parallel_copy(ptr.data(), local.ptr.data(), (size_t)local.nrows + 1);
+        for (index_t i = 0; i < halo.nrows; ++i) ptr[(size_t)local.nrows + 1 + i] = base + halo.ptr[(size_t)i + 1];
+        if (g_spgemm_hook(A.nrows, local.nrows + halo.nrows, local.ncols, A.ptr, A.col, A.val, ptr.data(), local.col.data(), local.val.data(), base,
+                          halo.col.empty() ? local.col.data() : halo.col.data(), halo.val.empty() ? local.val.data() : halo.val.data(),
+                          row_offset, C.ptr, C.col, C.val) == 0)
+            return C;
+    }
+    return spgemm(A, stack_rows(local, halo), row_offset);
+}
+// multi-gigabyte temporaries are handed to a detached thread to be freed (unmapping them took 2.8 s per rank of the 323^3
+// setup, between the phases that need the cores): SAENA_NO_ASYNC_FREE=1 frees in place
+template <class T>
+void drop_async(T &&x) {
+    static const bool off = std::getenv("SAENA_NO_ASYNC_FREE") != nullptr;
+    if (off) { T gone(std::move(x)); return; }
+    T *p = new T(std::move(x));
+    try { std::thread([p] { delete p; }).detach(); } catch (...) { delete p; }
+}
 std::vector<index_t> relabel_cols(const Csr &M, index_t lo, index_t hi, const FetchPlan &plan) {
     std::vector<index_t> out(M.col.size());
     const index_t nloc = hi - lo;
@@ -1353,21 +1380,27 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         {
             FetchPlan pl;
             pl.build(c, split, outside_cols(R, lo, hi));
-            const Csr Aext = stack_rows(A, pl.rows(c, A));
-            const std::vector<index_t> rcol = relabel_cols(R, lo, hi, pl);
-            RA = spgemm(CsrRef(R, rcol), Aext, clo);
+            Csr Ahalo = pl.rows(c, A);
+            std::vector<index_t> rcol = relabel_cols(R, lo, hi, pl);
+            pt.lap("R*A: fetch, relabel");
+            RA = spgemm_stacked(CsrRef(R, rcol), A, Ahalo, clo);
+            pt.lap("R*A: product");
+            drop_async(std::move(Ahalo)); drop_async(std::move(rcol));
         }
-        pt.lap("R*A");
+        pt.lap("R*A: free");
         Csr AcN;
         {
             FetchPlan pl;
             pl.build(c, split, outside_cols(RA, lo, hi));
-            const Csr Pext = stack_rows(P, pl.rows(c, P));
-            const std::vector<index_t> rcol = relabel_cols(RA, lo, hi, pl);
-            AcN = spgemm(CsrRef(RA, rcol), Pext, clo);
+            Csr Phalo = pl.rows(c, P);
+            std::vector<index_t> rcol = relabel_cols(RA, lo, hi, pl);
+            pt.lap("(RA)*P: fetch, relabel");
+            AcN = spgemm_stacked(CsrRef(RA, rcol), P, Phalo, clo);
+            pt.lap("(RA)*P: product");
+            drop_async(std::move(RA)); drop_async(std::move(Phalo)); drop_async(std::move(rcol));
             RA = Csr();
         }
-        pt.lap("(RA)*P");
+        pt.lap("(RA)*P: free");
         if (++filter_it >= opts.filter_start) {
             if (filter_thre_cur > opts.filter_max) filter_thre_cur = opts.filter_max;
             filter_csr(AcN, filter_thre_cur, clo);

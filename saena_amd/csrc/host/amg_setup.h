@@ -16,9 +16,12 @@ namespace saena_host {
 // Optional accelerator for the setup's sparse products C = A B (CSR in, CSR out, rows sorted by column, the drop rule of
 // the host kernel).  libsaena_amd.so installs its GPU kernel here when a device context exists; returns 0 on success,
 // non-zero to decline (the host kernel then runs).  nullptr in libsaena_host.so.
+// B's entries may come in TWO pieces (the rank's own rows, then the halo rows fetched for this product): entries [0, b_split) sit
+// at b_col / b_val, entries [b_split, b_ptr[b_rows]) at b_col1 / b_val1 (b_col1 == nullptr: one piece) -- the caller then stacks
+// the row pointers only, not the gigabytes of columns and values.
 typedef int (*spgemm_hook_fn)(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int *a_col, const double *a_val,
-                              const long *b_ptr, const int *b_col, const double *b_val, int row_offset,
-                              std::vector<long> &c_ptr, std::vector<int> &c_col, std::vector<double> &c_val);
+                              const long *b_ptr, const int *b_col, const double *b_val, long b_split, const int *b_col1, const double *b_val1,
+                              int row_offset, std::vector<long> &c_ptr, std::vector<int> &c_col, std::vector<double> &c_val);
 extern spgemm_hook_fn g_spgemm_hook;
 // The exchange chain of one multi-rank apply in microseconds (pack -> RCCL send/recv -> boundary rows), as the GPU runtime
 // MEASURED it on this job's communicator at sgpu_init (a ping-pong with the neighbouring rank; the maximum over the

@@ -35,8 +35,8 @@
 
 namespace saena_host {
 typedef int (*spgemm_hook_fn)(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int *a_col, const double *a_val,
-                              const long *b_ptr, const int *b_col, const double *b_val, int row_offset,
-                              std::vector<long> &c_ptr, std::vector<int> &c_col, std::vector<double> &c_val);
+                              const long *b_ptr, const int *b_col, const double *b_val, long b_split, const int *b_col1, const double *b_val1,
+                              int row_offset, std::vector<long> &c_ptr, std::vector<int> &c_col, std::vector<double> &c_val);
 extern spgemm_hook_fn g_spgemm_hook;
 }
 
@@ -309,8 +309,8 @@ extern "C" int sgpu_context_device();      // sgpu_runtime.hip: the device of th
 #define SP_CHK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return 1; } } while (0)
 
 int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int *a_col, const double *a_val,
-               const long *b_ptr, const int *b_col, const double *b_val, int row_offset,
-               std::vector<long> &c_ptr, std::vector<int> &c_col, std::vector<double> &c_val) {
+               const long *b_ptr, const int *b_col, const double *b_val, long b_split, const int *b_col1, const double *b_val1,
+               int row_offset, std::vector<long> &c_ptr, std::vector<int> &c_col, std::vector<double> &c_val) {
     static_assert(sizeof(long) == sizeof(long long), "nnz_t is 64-bit");
     const long a_nnz = a_ptr[a_rows], b_nnz = b_ptr[b_rows];
     // products and upper bounds per row (host, O(nnz of A))
@@ -342,9 +342,14 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
     SP_CHK(hipMemcpy(dap, a_ptr, ((size_t)a_rows + 1) * 8, hipMemcpyHostToDevice));
     SP_CHK(hipMemcpy(dbp, b_ptr, ((size_t)b_rows + 1) * 8, hipMemcpyHostToDevice));
     SP_CHK(hipMemcpy(dac, a_col, (size_t)a_nnz * 4, hipMemcpyHostToDevice));
-    SP_CHK(hipMemcpy(dbc, b_col, (size_t)b_nnz * 4, hipMemcpyHostToDevice));
+    const long b_n0 = b_col1 ? b_split : b_nnz;                  // B in one piece, or its own rows followed by the fetched halo rows
+    SP_CHK(hipMemcpy(dbc, b_col, (size_t)b_n0 * 4, hipMemcpyHostToDevice));
     SP_CHK(hipMemcpy(dav, a_val, (size_t)a_nnz * 8, hipMemcpyHostToDevice));
-    SP_CHK(hipMemcpy(dbv, b_val, (size_t)b_nnz * 8, hipMemcpyHostToDevice));
+    SP_CHK(hipMemcpy(dbv, b_val, (size_t)b_n0 * 8, hipMemcpyHostToDevice));
+    if (b_nnz > b_n0) {
+        SP_CHK(hipMemcpy(dbc + b_n0, b_col1, (size_t)(b_nnz - b_n0) * 4, hipMemcpyHostToDevice));
+        SP_CHK(hipMemcpy(dbv + b_n0, b_val1, (size_t)(b_nnz - b_n0) * 8, hipMemcpyHostToDevice));
+    }
     m.a_ptr = dap; m.a_col = dac; m.a_val = dav; m.b_ptr = dbp; m.b_col = dbc; m.b_val = dbv;
     t_up = secs(T0, now());
 
