@@ -366,13 +366,17 @@ index_t amg_hierarchy::aggregate(const saena_matrix &A, const std::vector<nnz_t>
     // its evaluation, which reads nothing but its neighbours' (agg, decided, is_root), would repeat the previous
     // result and leave it undecided again.  Identical aggregates, ~3 visits per row.  Both sweeps of a round read
     // only the previous round's state and write only row i's own entries, so the work list is dealt to threads.
+    // Which neighbour matters: an undecided row waits for ONE row, the eligible neighbour with the smallest id (`blocker`): ids
+    // of eligible rows (undecided, or roots) never change, a row that joins an aggregate leaves the eligible set for good, and a
+    // smaller eligible id cannot appear -- so the row's evaluation gives the same result until its blocker itself changes state,
+    // and only then is it evaluated again (6 -> ~2.5 visits per row on the 68-entry rows of Poisson level 1).
     const int T = n_threads();
     std::vector<nnz_t> tptr((size_t)size + 1, 0);                 // who looks at row j: the transposed pattern
     std::vector<index_t> tcol(col.size());
     transpose_pattern(size, size, ptr, col, tptr, tcol);
     std::vector<std::vector<index_t>> troots((size_t)T), tnext((size_t)T), tdone((size_t)T);
     std::vector<char> queued((size_t)size, 0);
-    std::vector<index_t> work((size_t)size);
+    std::vector<index_t> work((size_t)size), blocker((size_t)size, -1);
     for (index_t i = 0; i < size; ++i) work[i] = i;
     long rounds = 0, visited = 0, undecided = size;
     while (!work.empty()) {
@@ -385,14 +389,17 @@ index_t amg_hierarchy::aggregate(const saena_matrix &A, const std::vector<nnz_t>
                 aggregate2[i] = agg[i];
                 dec_nei[i] = 1;
                 is_root_nei[i] = 0;
+                index_t who = -1;
                 for (nnz_t it = ptr[i]; it < ptr[i + 1]; ++it) {
                     const index_t c = col[it];
                     if (agg[c] < aggregate2[i] && (!decided[c] || is_root[c])) {
                         aggregate2[i] = agg[c];
                         dec_nei[i] = decided[c];
                         is_root_nei[i] = is_root[c];
+                        who = c;
                     }
                 }
+                blocker[i] = who;
             }
         });
         for (auto &v : tdone) v.clear();
@@ -417,7 +424,7 @@ index_t amg_hierarchy::aggregate(const saena_matrix &A, const std::vector<nnz_t>
                 const index_t j = done[q];
                 for (nnz_t it = tptr[j]; it < tptr[j + 1]; ++it) {
                     const index_t c = tcol[it];
-                    if (!decided[c] && !__atomic_exchange_n(&queued[c], (char)1, __ATOMIC_RELAXED)) tnext[t].push_back(c);
+                    if (!decided[c] && blocker[c] == j && !__atomic_exchange_n(&queued[c], (char)1, __ATOMIC_RELAXED)) tnext[t].push_back(c);
                 }
             }
         });
@@ -1169,7 +1176,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         std::vector<nnz_t> tptr((size_t)next + 1, 0);               // who looks at ext position e: the transposed pattern
         std::vector<index_t> tcol(scol.size());
         transpose_pattern(nloc, next, sptr, scol, tptr, tcol);
-        std::vector<index_t> aggregate2((size_t)nloc);
+        std::vector<index_t> aggregate2((size_t)nloc), blocker((size_t)nloc, -1);       // blocker: the ext position a waiting row waits for (aggregate())
         std::vector<char> dec_nei((size_t)nloc, 0), is_root_nei((size_t)nloc, 0), queued((size_t)nloc, 1);
         std::vector<index_t> work((size_t)nloc);
         for (index_t i = 0; i < nloc; ++i) work[i] = i;
@@ -1200,7 +1207,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                         st[(size_t)nloc + j] = in[at].s;
                         for (nnz_t it = tptr[(size_t)nloc + j]; it < tptr[(size_t)nloc + j + 1]; ++it) {
                             const index_t r = tcol[it];
-                            if (!st[r].decided && !queued[r]) { queued[r] = 1; work.push_back(r); }
+                            if (!st[r].decided && blocker[r] == (index_t)(nloc + j) && !queued[r]) { queued[r] = 1; work.push_back(r); }
                         }
                     }
                     base += (size_t)planA.scount[(size_t)p];
@@ -1213,10 +1220,12 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                     const index_t i = work[q];
                     queued[i] = 0;
                     aggregate2[i] = st[i].agg; dec_nei[i] = 1; is_root_nei[i] = 0;
+                    index_t who = -1;
                     for (nnz_t it = sptr[i]; it < sptr[i + 1]; ++it) {
                         const AggState &n = st[(size_t)scol[it]];
-                        if (n.agg < aggregate2[i] && (!n.decided || n.is_root)) { aggregate2[i] = n.agg; dec_nei[i] = n.decided; is_root_nei[i] = n.is_root; }
+                        if (n.agg < aggregate2[i] && (!n.decided || n.is_root)) { aggregate2[i] = n.agg; dec_nei[i] = n.decided; is_root_nei[i] = n.is_root; who = scol[it]; }
                     }
+                    blocker[i] = who;
                 }
             });
             for (auto &v : tdone) v.clear();
@@ -1239,7 +1248,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                 for (index_t q = a0; q < a1; ++q)
                     for (nnz_t it = tptr[done[q]]; it < tptr[done[q] + 1]; ++it) {
                         const index_t r = tcol[it];
-                        if (!st[r].decided && !__atomic_exchange_n(&queued[r], (char)1, __ATOMIC_RELAXED)) tnext[t].push_back(r);
+                        if (!st[r].decided && blocker[r] == done[q] && !__atomic_exchange_n(&queued[r], (char)1, __ATOMIC_RELAXED)) tnext[t].push_back(r);
                     }
             });
             work.clear();
