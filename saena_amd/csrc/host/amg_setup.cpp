@@ -88,6 +88,13 @@ void parallel_rows(index_t n, const std::vector<nnz_t> *weight_ptr, F f) {
     ThreadPool::get().run(T, [&](int t) { f(t, cut[(size_t)t], cut[(size_t)t + 1]); });
 }
 
+// the aggregation's rounds: most of them touch a few thousand rows for a few reads each -- waking the pool costs more than the work
+template <class F>
+void parallel_rows_if_large(index_t n, F f) {
+    if (n < 32768) { if (n > 0) f(0, 0, n); return; }
+    parallel_rows(n, nullptr, f);
+}
+
 // A row of (coarse column, value) pairs ordered by column, equal columns in their original order -- std::stable_sort's result
 // without the buffer it allocates per call (one call per fine row: 16 M of them per level): insertion sort for the short
 // rows of the stencil levels, else a sort of (column, position) keys.
@@ -106,23 +113,6 @@ void stable_sort_by_first(std::vector<std::pair<index_t, value_t>> &row, std::ve
     for (size_t i = 0; i < n; ++i) scratch[i] = {((long)row[i].first << 32) | (long)i, row[i].second};
     std::sort(scratch.begin(), scratch.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
     for (size_t i = 0; i < n; ++i) row[i] = {(index_t)(scratch[i].first >> 32), scratch[i].second};
-}
-
-// who looks at whom: tcol[tptr[j] .. tptr[j+1]) = the rows whose pattern holds column j.  Counted and filled on threads with
-// atomic counters (a level holds 0.3 G strong connections per rank); the ORDER inside a list depends on the threads and does
-// not matter: the lists only queue rows for re-evaluation, and the queue is sorted before use.
-void transpose_pattern(index_t nrows, index_t ncols, const std::vector<nnz_t> &ptr, const std::vector<index_t> &col,
-                       std::vector<nnz_t> &tptr, std::vector<index_t> &tcol) {
-    tptr.assign((size_t)ncols + 1, 0);
-    parallel_chunks<size_t>(col.size(), (size_t)1 << 20, [&](int, size_t a, size_t b) {
-        for (size_t k = a; k < b; ++k) __atomic_fetch_add(&tptr[(size_t)col[k] + 1], (nnz_t)1, __ATOMIC_RELAXED);
-    });
-    for (index_t j = 0; j < ncols; ++j) tptr[(size_t)j + 1] += tptr[(size_t)j];
-    std::vector<nnz_t> fill(tptr.begin(), tptr.end() - 1);
-    parallel_rows(nrows, &ptr, [&](int, index_t r0, index_t r1) {
-        for (index_t i = r0; i < r1; ++i)
-            for (nnz_t it = ptr[(size_t)i]; it < ptr[(size_t)i + 1]; ++it) tcol[(size_t)__atomic_fetch_add(&fill[(size_t)col[(size_t)it]], (nnz_t)1, __ATOMIC_RELAXED)] = i;
-    });
 }
 
 // the assembled one-rank operator as CSR (its layout arrays are row-major, columns ascending)
@@ -362,48 +352,47 @@ index_t amg_hierarchy::aggregate(const saena_matrix &A, const std::vector<nnz_t>
     for (index_t i = 0; i < size; ++i) agg[i] = i;
     // The reference runs synchronous rounds over all undecided rows (setup1:760-960); 280 rounds for a 94^3 grid,
     // ~140 visits per row, because the priority wave crosses the grid one node per round.  The same rounds are run
-    // here, but a row is re-evaluated only when a row it looks at changed state in the previous round -- otherwise
-    // its evaluation, which reads nothing but its neighbours' (agg, decided, is_root), would repeat the previous
-    // result and leave it undecided again.  Identical aggregates, ~3 visits per row.  Both sweeps of a round read
-    // only the previous round's state and write only row i's own entries, so the work list is dealt to threads.
-    // Which neighbour matters: an undecided row waits for ONE row, the eligible neighbour with the smallest id (`blocker`): ids
-    // of eligible rows (undecided, or roots) never change, a row that joins an aggregate leaves the eligible set for good, and a
-    // smaller eligible id cannot appear -- so the row's evaluation gives the same result until its blocker itself changes state,
-    // and only then is it evaluated again (6 -> ~2.5 visits per row on the 68-entry rows of Poisson level 1).
+    // here, but a row is evaluated again only when its evaluation can come out differently.  An evaluation looks for the
+    // eligible neighbour (undecided, or a root) with the smallest id below the row's own; an eligible row carries its OWN id,
+    // ids of eligible rows never change, a row that joins an aggregate leaves the eligible set for good, and a row's columns
+    // ascend -- so that neighbour is the FIRST eligible column below the diagonal, the columns passed over on the way stay
+    // ineligible (the next evaluation resumes at `cursor`), and the result cannot change until that one neighbour, the row's
+    // `blocker`, changes state.  A waiting row therefore hangs itself on its blocker's chain (head / next), and a row that
+    // decides wakes its chain: identical aggregates (pinned bit for bit against the compiled reference, tests/test_sa_pins.py),
+    // 2-4 visits per row of a few reads each, no transposed pattern.  Both sweeps of a round read only the previous round's
+    // state and write only row i's own entries (and push onto chains with an atomic exchange), so the work list is dealt to
+    // threads.
     const int T = n_threads();
-    std::vector<nnz_t> tptr((size_t)size + 1, 0);                 // who looks at row j: the transposed pattern
-    std::vector<index_t> tcol(col.size());
-    transpose_pattern(size, size, ptr, col, tptr, tcol);
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<std::vector<index_t>> troots((size_t)T), tnext((size_t)T), tdone((size_t)T);
-    std::vector<char> queued((size_t)size, 0);
-    std::vector<index_t> work((size_t)size), blocker((size_t)size, -1);
+    std::vector<index_t> work((size_t)size), cursor((size_t)size, 0), head((size_t)size, -1), next((size_t)size, -1);
     for (index_t i = 0; i < size; ++i) work[i] = i;
     long rounds = 0, visited = 0, undecided = size;
     while (!work.empty()) {
         const index_t nw = (index_t)work.size();
         ++rounds; visited += nw;
-        parallel_rows(nw, nullptr, [&](int, index_t lo, index_t hi) {
+        parallel_rows_if_large(nw, [&](int, index_t lo, index_t hi) {
             for (index_t q = lo; q < hi; ++q) {
                 const index_t i = work[q];
-                queued[i] = 0;
                 aggregate2[i] = agg[i];
                 dec_nei[i] = 1;
                 is_root_nei[i] = 0;
-                index_t who = -1;
-                for (nnz_t it = ptr[i]; it < ptr[i + 1]; ++it) {
+                nnz_t it = ptr[i] + cursor[i];
+                for (; it < ptr[i + 1] && col[it] < i; ++it) {
                     const index_t c = col[it];
-                    if (agg[c] < aggregate2[i] && (!decided[c] || is_root[c])) {
+                    if (!decided[c] || is_root[c]) {
                         aggregate2[i] = agg[c];
                         dec_nei[i] = decided[c];
                         is_root_nei[i] = is_root[c];
-                        who = c;
+                        if (!decided[c]) next[i] = __atomic_exchange_n(&head[c], i, __ATOMIC_ACQ_REL);      // wait for c
+                        break;
                     }
                 }
-                blocker[i] = who;
+                cursor[i] = (index_t)(it - ptr[i]);
             }
         });
         for (auto &v : tdone) v.clear();
-        parallel_rows(nw, nullptr, [&](int t, index_t lo, index_t hi) {
+        parallel_rows_if_large(nw, [&](int t, index_t lo, index_t hi) {
             for (index_t q = lo; q < hi; ++q) {
                 const index_t i = work[q];
                 if (dec_nei[i]) {
@@ -414,26 +403,25 @@ index_t amg_hierarchy::aggregate(const saena_matrix &A, const std::vector<nnz_t>
                 }
             }
         });
-        // next round: the undecided rows that look at a row decided in this one
+        // next round: the rows that waited for a row decided in this one
         for (auto &v : tnext) v.clear();
         std::vector<index_t> done;
         for (auto &v : tdone) done.insert(done.end(), v.begin(), v.end());
         undecided -= (long)done.size();
-        parallel_rows((index_t)done.size(), nullptr, [&](int t, index_t lo, index_t hi) {
+        parallel_rows_if_large((index_t)done.size(), [&](int t, index_t lo, index_t hi) {
             for (index_t q = lo; q < hi; ++q) {
                 const index_t j = done[q];
-                for (nnz_t it = tptr[j]; it < tptr[j + 1]; ++it) {
-                    const index_t c = tcol[it];
-                    if (!decided[c] && blocker[c] == j && !__atomic_exchange_n(&queued[c], (char)1, __ATOMIC_RELAXED)) tnext[t].push_back(c);
-                }
+                for (index_t c = head[j]; c >= 0; c = next[c]) tnext[t].push_back(c);
+                head[j] = -1;
             }
         });
         work.clear();
         for (auto &v : tnext) work.insert(work.end(), v.begin(), v.end());
-        std::sort(work.begin(), work.end());
     }
     if (undecided != 0) throw std::runtime_error("aggregation did not terminate: " + std::to_string(undecided) + " undecided rows");
-    if (std::getenv("SAENA_SETUP_TIMING")) fprintf(stderr, "[aggregate] %ld rounds, %ld row visits for %d rows\n", rounds, visited, size);
+    if (std::getenv("SAENA_SETUP_TIMING"))
+        fprintf(stderr, "[aggregate] %ld rounds, %ld row visits for %d rows, %.3f s\n", rounds, visited, size,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     for (auto &tr : troots) aggArray.insert(aggArray.end(), tr.begin(), tr.end());
     std::sort(aggArray.begin(), aggArray.end());
     for (index_t i = 0; i < size; ++i)
@@ -1169,15 +1157,13 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
         pt.lap("strength graph");
 
         // ---- aggregation: the synchronous rounds of aggregate() above.  A round starts by refreshing the state of the
-        //      halo rows; as there, a row is re-evaluated only when a row it looks at -- local or halo -- changed state ----
+        //      halo rows; as there, a waiting row hangs on the chain of the one row it waits for -- local or halo -- and is
+        //      evaluated again when that row changes state ----
         std::vector<AggState> st((size_t)next);
         for (index_t i = 0; i < nloc; ++i) st[i] = AggState{i + lo, 0, 0, {0, 0}};
         for (index_t j = nloc; j < next; ++j) st[j] = AggState{planA.wanted[(size_t)(j - nloc)], 0, 0, {0, 0}};
-        std::vector<nnz_t> tptr((size_t)next + 1, 0);               // who looks at ext position e: the transposed pattern
-        std::vector<index_t> tcol(scol.size());
-        transpose_pattern(nloc, next, sptr, scol, tptr, tcol);
-        std::vector<index_t> aggregate2((size_t)nloc), blocker((size_t)nloc, -1);       // blocker: the ext position a waiting row waits for (aggregate())
-        std::vector<char> dec_nei((size_t)nloc, 0), is_root_nei((size_t)nloc, 0), queued((size_t)nloc, 1);
+        std::vector<index_t> aggregate2((size_t)nloc), cursor((size_t)nloc, 0), whead((size_t)next, -1), wnext((size_t)nloc, -1);
+        std::vector<char> dec_nei((size_t)nloc, 0), is_root_nei((size_t)nloc, 0);
         std::vector<index_t> work((size_t)nloc);
         for (index_t i = 0; i < nloc; ++i) work[i] = i;
         const int T = n_threads();
@@ -1205,31 +1191,37 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                     for (int k = 0; k < ic[(size_t)p]; ++k, ++at) {
                         const size_t j = base + (size_t)in[at].slot;
                         st[(size_t)nloc + j] = in[at].s;
-                        for (nnz_t it = tptr[(size_t)nloc + j]; it < tptr[(size_t)nloc + j + 1]; ++it) {
-                            const index_t r = tcol[it];
-                            if (!st[r].decided && blocker[r] == (index_t)(nloc + j) && !queued[r]) { queued[r] = 1; work.push_back(r); }
-                        }
+                        for (index_t r = whead[(size_t)nloc + j]; r >= 0; r = wnext[(size_t)r]) work.push_back(r);      // the rows that waited for it
+                        whead[(size_t)nloc + j] = -1;
                     }
                     base += (size_t)planA.scount[(size_t)p];
                 }
-                std::sort(work.begin(), work.end());
             }
             const index_t nw = (index_t)work.size();
-            parallel_rows(nw, nullptr, [&](int, index_t a0, index_t a1) {
+            parallel_rows_if_large(nw, [&](int, index_t a0, index_t a1) {
                 for (index_t q = a0; q < a1; ++q) {
                     const index_t i = work[q];
-                    queued[i] = 0;
                     aggregate2[i] = st[i].agg; dec_nei[i] = 1; is_root_nei[i] = 0;
-                    index_t who = -1;
-                    for (nnz_t it = sptr[i]; it < sptr[i + 1]; ++it) {
-                        const AggState &n = st[(size_t)scol[it]];
-                        if (n.agg < aggregate2[i] && (!n.decided || n.is_root)) { aggregate2[i] = n.agg; dec_nei[i] = n.decided; is_root_nei[i] = n.is_root; who = scol[it]; }
+                    // (aggregate(): the first eligible column below the diagonal, resuming where the last evaluation stopped; a
+                    //  row's columns ascend in GLOBAL id -- halo rows below this block, the block, halo rows above it)
+                    const index_t own = i + lo;
+                    nnz_t it = sptr[i] + cursor[i];
+                    for (; it < sptr[i + 1]; ++it) {
+                        const index_t e = scol[it];
+                        const index_t gid = e < nloc ? e + lo : planA.wanted[(size_t)(e - nloc)];
+                        if (gid >= own) break;
+                        const AggState &n = st[(size_t)e];
+                        if (!n.decided || n.is_root) {
+                            aggregate2[i] = n.agg; dec_nei[i] = n.decided; is_root_nei[i] = n.is_root;
+                            if (!n.decided) wnext[(size_t)i] = __atomic_exchange_n(&whead[(size_t)e], i, __ATOMIC_ACQ_REL);      // wait for e
+                            break;
+                        }
                     }
-                    blocker[i] = who;
+                    cursor[i] = (index_t)(it - sptr[i]);
                 }
             });
             for (auto &v : tdone) v.clear();
-            parallel_rows(nw, nullptr, [&](int t, index_t a0, index_t a1) {
+            parallel_rows_if_large(nw, [&](int t, index_t a0, index_t a1) {
                 for (index_t q = a0; q < a1; ++q) {
                     const index_t i = work[q];
                     if (dec_nei[i]) {
@@ -1244,12 +1236,11 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             std::vector<index_t> done;
             for (auto &v : tdone) done.insert(done.end(), v.begin(), v.end());
             my_undecided -= (long)done.size();
-            parallel_rows((index_t)done.size(), nullptr, [&](int t, index_t a0, index_t a1) {
-                for (index_t q = a0; q < a1; ++q)
-                    for (nnz_t it = tptr[done[q]]; it < tptr[done[q] + 1]; ++it) {
-                        const index_t r = tcol[it];
-                        if (!st[r].decided && blocker[r] == done[q] && !__atomic_exchange_n(&queued[r], (char)1, __ATOMIC_RELAXED)) tnext[t].push_back(r);
-                    }
+            parallel_rows_if_large((index_t)done.size(), [&](int t, index_t a0, index_t a1) {
+                for (index_t q = a0; q < a1; ++q) {
+                    for (index_t r = whead[(size_t)done[q]]; r >= 0; r = wnext[(size_t)r]) tnext[t].push_back(r);
+                    whead[(size_t)done[q]] = -1;
+                }
             });
             work.clear();
             for (auto &v : tnext) work.insert(work.end(), v.begin(), v.end());
