@@ -964,11 +964,12 @@ Csr route_rows(Comm &c, const Csr &X, index_t row_lo, const std::vector<index_t>
     const int np = c.nranks;
     std::vector<int> scr((size_t)np, 0), sce((size_t)np, 0);
     std::vector<nnz_t> len((size_t)X.nrows);
-    for (index_t i = 0; i < X.nrows; ++i) {
-        len[i] = X.ptr[i + 1] - X.ptr[i];
-        const int d = owner_of_id(split_to, row_lo + i);
-        scr[(size_t)d]++;
-        sce[(size_t)d] += (int)len[i];
+    parallel_chunks<index_t>(X.nrows, 1 << 16, [&](int, index_t a, index_t b) { for (index_t i = a; i < b; ++i) len[(size_t)i] = X.ptr[(size_t)i + 1] - X.ptr[(size_t)i]; });
+    for (int d = 0; d < np; ++d) {                                   // owners are contiguous row ranges: counts from the range ends, not row by row
+        const index_t a = d == 0 ? 0 : std::min(std::max(split_to[(size_t)d] - row_lo, (index_t)0), X.nrows);          // (ids outside the partition go to its
+        const index_t b = d == np - 1 ? X.nrows : std::min(std::max(split_to[(size_t)d + 1] - row_lo, (index_t)0), X.nrows);   //  first / last owner, as owner_of_id has it)
+        scr[(size_t)d] = (int)(b - a);
+        sce[(size_t)d] = (int)(X.ptr[(size_t)b] - X.ptr[(size_t)a]);
     }
     const std::vector<nnz_t> rlen = c.alltoallv_records(len, scr);
     Csr Y;
@@ -1002,11 +1003,13 @@ double dist_find_eig(Comm &c, const Csr &A, const std::vector<index_t> &split, c
     auto matvec = [&](const std::vector<double> &x, std::vector<double> &y) {
         std::vector<double> xE = x;
         { const std::vector<double> h = planA.values(c, x); xE.insert(xE.end(), h.begin(), h.end()); }
-        for (index_t i = 0; i < n; ++i) {
-            double s_ = 0;
-            for (nnz_t k = Ar.ptr[i]; k < Ar.ptr[i + 1]; ++k) s_ += Ar.val[k] * isdE[(size_t)Ar.col[k]] * xE[(size_t)Ar.col[k]];
-            y[i] = s_ * isd[i];
-        }
+        parallel_rows(n, &Ar.ptr, [&](int, index_t r0, index_t r1) {        // (rows are independent: the same sums on any number of threads)
+            for (index_t i = r0; i < r1; ++i) {
+                double s_ = 0;
+                for (nnz_t k = Ar.ptr[i]; k < Ar.ptr[i + 1]; ++k) s_ += Ar.val[k] * isdE[(size_t)Ar.col[k]] * xE[(size_t)Ar.col[k]];
+                y[i] = s_ * isd[i];
+            }
+        });
     };
     const int m = (int)std::min<index_t>(20, Mbig);
     std::vector<double> v((size_t)n), vprev((size_t)n, 0.0), w((size_t)n), alpha, beta;
@@ -1322,11 +1325,12 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             });
             for (index_t i = 0; i < nloc; ++i) P.ptr[i + 1] = P.ptr[i] + rowlen[(size_t)i];
             P.col.resize((size_t)P.ptr[nloc]); P.val.resize((size_t)P.ptr[nloc]);
-            for (int t = 0; t < T; ++t) {
-                if (thi[(size_t)t] <= tlo[(size_t)t]) continue;
+            ThreadPool::get().run(T, [&](int t) {                            // every thread brings its own piece home
+                if (thi[(size_t)t] <= tlo[(size_t)t]) return;
                 std::copy(tcol[(size_t)t].begin(), tcol[(size_t)t].end(), P.col.begin() + P.ptr[tlo[(size_t)t]]);
                 std::copy(tval[(size_t)t].begin(), tval[(size_t)t].end(), P.val.begin() + P.ptr[tlo[(size_t)t]]);
-            }
+                std::vector<index_t>().swap(tcol[(size_t)t]); std::vector<value_t>().swap(tval[(size_t)t]);
+            });
         }
         pt.lap("smoothed P");
 
@@ -1465,6 +1469,8 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                         invd[(size_t)i] = 1.0 / AcN.val[k];
                     }
         });
+        drop_async(std::move(A));                                         // (this level's operator, transfers and graph: gigabytes on the fine levels)
+        drop_async(std::move(P)); drop_async(std::move(R)); drop_async(std::move(aext)); drop_async(std::move(scol));
         A = std::move(AcN);
         A.ncols = new_size;
         inv_diag.swap(invd);
