@@ -100,15 +100,20 @@ void parallel_rows_if_large(index_t n, F f) {
 // rows of the stencil levels, else a sort of (column, position) keys.
 void stable_sort_by_first(std::vector<std::pair<index_t, value_t>> &row, std::vector<std::pair<long, value_t>> &scratch) {
     const size_t n = row.size();
-    if (n <= 16) {
-        for (size_t i = 1; i < n; ++i) {
-            const auto x = row[i];
-            size_t j = i;
-            while (j > 0 && row[j - 1].first > x.first) { row[j] = row[j - 1]; --j; }
-            row[j] = x;
-        }
-        return;
+    // insertion sort: all of a short row; of a longer one as long as it stays cheap -- the coarse ids of a fine row's neighbours
+    // arrive nearly sorted (aggregates are numbered in the order of their roots, the row's columns ascend), a few shifts per entry
+    size_t i = 1, shifts = 0;
+    const size_t budget = n <= 16 ? (size_t)-1 : 6 * n;
+    for (; i < n && shifts <= budget; ++i) {
+        const auto x = row[i];
+        size_t j = i;
+        while (j > 0 && row[j - 1].first > x.first) { row[j] = row[j - 1]; --j; }
+        shifts += i - j;
+        row[j] = x;
     }
+    if (i == n) return;
+    // (a stable sort of the whole row gives the same order whatever prefix is already sorted: equal keys keep their positions' order,
+    //  and the insertion above kept it as well)
     scratch.resize(n);
     for (size_t i = 0; i < n; ++i) scratch[i] = {((long)row[i].first << 32) | (long)i, row[i].second};
     std::sort(scratch.begin(), scratch.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
@@ -1345,7 +1350,18 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             auto is_local = [&](index_t cidx) { return own_any && cidx >= clo && cidx < chi; };
             index_t cmin = new_size, cmax = -1;
             nnz_t nfar = 0;
-            for (index_t cidx : P.col) if (!is_local(cidx)) { cmin = std::min(cmin, cidx); cmax = std::max(cmax, cidx); ++nfar; }
+            {
+                const int Tn = n_threads();
+                std::vector<index_t> tmin((size_t)Tn, new_size), tmax((size_t)Tn, -1);
+                std::vector<nnz_t> tfar((size_t)Tn, 0);
+                parallel_chunks<size_t>(P.col.size(), (size_t)1 << 20, [&](int t, size_t a, size_t b) {
+                    index_t mn = tmin[(size_t)t], mx = tmax[(size_t)t];
+                    nnz_t nf = 0;
+                    for (size_t k = a; k < b; ++k) { const index_t cidx = P.col[k]; if (!is_local(cidx)) { mn = std::min(mn, cidx); mx = std::max(mx, cidx); ++nf; } }
+                    tmin[(size_t)t] = mn; tmax[(size_t)t] = mx; tfar[(size_t)t] += nf;
+                });
+                for (int t = 0; t < Tn; ++t) { cmin = std::min(cmin, tmin[(size_t)t]); cmax = std::max(cmax, tmax[(size_t)t]); nfar += tfar[(size_t)t]; }
+            }
             std::vector<cooEntry> send((size_t)nfar);
             std::vector<int> sc((size_t)np, 0), rcnt;
             if (nfar) {
@@ -1365,16 +1381,31 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
             for (int p = 0; p < me; ++p) nlow += (size_t)rcnt[(size_t)p];
             R.nrows = chi - clo; R.ncols = Mbig; R.ptr.assign((size_t)R.nrows + 1, 0);
             for (const auto &x : got) R.ptr[(size_t)(x.row - clo) + 1]++;
-            for (index_t cidx : P.col) if (is_local(cidx)) R.ptr[(size_t)(cidx - clo) + 1]++;
+            // the local entries on threads: every thread OWNS a range of coarse rows and walks the fine rows whose columns reach into
+            // it (a row of P ascends: its first and last column say so), so counts and cursors need no atomics and every coarse row
+            // is filled by ascending fine row, as the sequential loop filled it
+            const int Tr = own_any ? std::max(1, std::min<int>(n_threads(), (chi - clo) / 4096 + 1)) : 1;
+            auto own_range = [&](int t, index_t &c0, index_t &c1) { c0 = clo + (index_t)((long)(chi - clo) * t / Tr); c1 = clo + (index_t)((long)(chi - clo) * (t + 1) / Tr); };
+            auto over_local = [&](int t, auto &&f) {
+                index_t c0, c1;
+                own_range(t, c0, c1);
+                if (c1 <= c0) return;
+                for (index_t i = 0; i < nloc; ++i) {
+                    const nnz_t k0 = P.ptr[i], k1 = P.ptr[i + 1];
+                    if (k1 == k0 || P.col[(size_t)k1 - 1] < c0 || P.col[(size_t)k0] >= c1) continue;
+                    for (nnz_t k = k0; k < k1; ++k) { const index_t cidx = P.col[(size_t)k]; if (cidx >= c0 && cidx < c1) f(i, k, cidx); }
+                }
+            };
+            if (own_any) ThreadPool::get().run(Tr, [&](int t) { over_local(t, [&](index_t, nnz_t, index_t cidx) { R.ptr[(size_t)(cidx - clo) + 1]++; }); });
             for (index_t i = 0; i < R.nrows; ++i) R.ptr[i + 1] += R.ptr[i];
             const size_t tot = (size_t)R.ptr[(size_t)R.nrows];
             R.col.resize(tot); R.val.resize(tot);
             std::vector<nnz_t> at(R.ptr.begin(), R.ptr.end() - 1);
             auto put = [&](const cooEntry &x) { const nnz_t q = at[(size_t)(x.row - clo)]++; R.col[(size_t)q] = x.col; R.val[(size_t)q] = x.val; };
             for (size_t j = 0; j < nlow; ++j) put(got[j]);
-            for (index_t i = 0; i < nloc; ++i)
-                for (nnz_t k = P.ptr[i]; k < P.ptr[i + 1]; ++k)
-                    if (is_local(P.col[k])) { const nnz_t q = at[(size_t)(P.col[k] - clo)]++; R.col[(size_t)q] = i + lo; R.val[(size_t)q] = P.val[k]; }
+            if (own_any) ThreadPool::get().run(Tr, [&](int t) {
+                over_local(t, [&](index_t i, nnz_t k, index_t cidx) { const nnz_t q = at[(size_t)(cidx - clo)]++; R.col[(size_t)q] = i + lo; R.val[(size_t)q] = P.val[(size_t)k]; });
+            });
             for (size_t j = nlow; j < got.size(); ++j) put(got[j]);
         }
         pt.lap("R = P^T");
