@@ -1131,19 +1131,22 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
 
         // ---- strength graph (strength_graph above), columns as ext positions ----
         std::vector<value_t> maxPerRow((size_t)nloc, -DBL_MAX);
-        for (index_t i = 0; i < nloc; ++i)
-            for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k)
-                if (A.col[k] != i + lo) maxPerRow[i] = std::max(maxPerRow[i], -A.val[k]);
+        parallel_rows(nloc, &A.ptr, [&](int, index_t r0, index_t r1) {
+            for (index_t i = r0; i < r1; ++i)
+                for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k)
+                    if (A.col[k] != i + lo) maxPerRow[i] = std::max(maxPerRow[i], -A.val[k]);
+        });
         std::vector<value_t> maxExt = maxPerRow;
         { const std::vector<value_t> h = planA.values(c, maxPerRow); maxExt.insert(maxExt.end(), h.begin(), h.end()); }
         std::vector<nnz_t> sptr((size_t)nloc + 1, 0);
         std::vector<index_t> scol;                       // ext positions
-        {   // two passes over the rows on threads: count the strong connections per row, then fill
+        {   // two passes over the rows on threads: count the strong connections per row, then fill.  Only the connections BELOW
+            // the diagonal are kept: they are all the aggregation looks at (a row joins, or waits for, the eligible neighbour with
+            // the smallest id below its own -- aggregate()), and half of the graph
             auto strong = [&](index_t i, nnz_t k) {
                 const index_t j = A.col[k];
-                value_t s_, st;
-                if (i + lo == j) { s_ = 1; st = 1; }
-                else { s_ = -A.val[k] / maxPerRow[i]; st = -A.val[k] / maxExt[(size_t)aext[(size_t)k]]; }
+                if (j >= i + lo) return false;
+                const value_t s_ = -A.val[k] / maxPerRow[i], st = -A.val[k] / maxExt[(size_t)aext[(size_t)k]];
                 return s_ > opts.connStrength || st > opts.connStrength;
             };
             parallel_rows(nloc, &A.ptr, [&](int, index_t r0, index_t r1) {
