@@ -1312,9 +1312,15 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                 std::vector<std::pair<long, value_t>> sort_scratch;
                 auto &oc = tcol[(size_t)t];
                 auto &ov = tval[(size_t)t];
-                oc.reserve((size_t)(A.ptr[r1] - A.ptr[r0]) / 2 + 16);      // (P holds at most A's entries; growing by doubling re-touches gigabytes)
-                ov.reserve(oc.capacity());
+                // room for this thread's piece of P from the density of its first rows (P holds 6/7 of A's entries on the stencil
+                // level, 1/4 on the next: half of A's, the earlier guess, made the vectors of the fine level grow -- and a vector
+                // that grows re-touches gigabytes)
+                const index_t probe = std::min<index_t>(r1, r0 + 4096);
                 for (index_t i = r0; i < r1; ++i) {
+                    if (i == probe && A.ptr[i] > A.ptr[r0]) {
+                        const size_t est = (size_t)(1.1 * (double)oc.size() / (double)(A.ptr[i] - A.ptr[r0]) * (double)(A.ptr[r1] - A.ptr[r0])) + 4096;
+                        oc.reserve(est); ov.reserve(est);
+                    }
                     row.clear();
                     for (nnz_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
                         value_t vtmp = -om * inv_diag[i] * A.val[k];
