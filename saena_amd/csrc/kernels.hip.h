@@ -684,9 +684,9 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
 // WIDE: the table of an operator whose rows follow a few HUNDRED patterns of several dozen entries -- the first smoothed-
 // aggregation level of a structured grid: Poisson 128^3 / 256^3 level 1 has 321 patterns, 14 469 offsets in all, whatever the
 // size (two of them cover 85 % of the rows).  The table is stored compactly (a.ptab: pt_n start offsets, then per pattern its
-// length and that many offsets; a.pt_w ints in all, <= SPW_MAX_TABLE = 72 KiB), a workgroup of 1024 threads shares one copy
+// length and that many offsets; a.pt_w ints in all, <= SPW_MAX_TABLE = 78 KiB), a workgroup of 1024 threads shares one copy
 // (two workgroups per CU: full occupancy at <= 64 VGPRs) and works through a.gpw groups of 16 slices with it.
-constexpr int SPW_MAX_TABLE = 18432;
+constexpr int SPW_MAX_TABLE = 19968;      // 78 KiB: two workgroups per CU (the local part of a rank between two neighbours follows ~420 patterns)
 constexpr int SPW_BLOCK     = 1024;
 template <int EPI, bool HALO, bool PAIR, bool NT, bool WIDE = false>
 __global__ __launch_bounds__(WIDE ? SPW_BLOCK : BLOCK) void k_sellp(const SpmvArgs a, int nrows) {

@@ -621,7 +621,7 @@ int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
 // row index); the operator qualifies when its rows follow at most 65 535 distinct patterns whose table fits LDS:
 //   * 4096 ints at a fixed width of (longest row + 1) -- stencils on structured grids (the boundary-stripped 7-point Laplacian:
 //     27 patterns), band matrices: the table of k_sellp / k_sellp2 with 256 threads per workgroup;
-//   * else 18 432 ints stored compactly (start offsets, then length + offsets per pattern) -- the first smoothed-aggregation
+//   * else 19 968 ints stored compactly (start offsets, then length + offsets per pattern) -- the first smoothed-aggregation
 //     level of a structured grid (Poisson level 1: 321 patterns, 14 469 offsets at every size): k_sellp<WIDE>, 1024 threads
 //     around one table (sp_wide).
 // Ids are dealt in order of first appearance, so the table does not depend on threads or hashing.

@@ -119,7 +119,7 @@ def _sell_eligible(entries, M):
 def _sellp_table(entries, M):
     """the library's rule for the row-pattern form: sliced-ELLPACK eligible, and the distinct (length, columns relative to
     the row) patterns fit a table in LDS -- "narrow": 4096 ints at longest-row + 1 ints per pattern (k_sellp / k_sellp2 with
-    256 threads); else "wide": 18 432 ints stored compactly -- a start offset, the length and the offsets per pattern, one
+    256 threads); else "wide": 19 968 ints stored compactly -- a start offset, the length and the offsets per pattern, one
     spare int (k_sellp<wide>, 1024 threads around one table); else None"""
     if not _sell_eligible(entries, M):
         return None
@@ -131,7 +131,7 @@ def _sellp_table(entries, M):
     pats = {tuple(col[ptr[r]:ptr[r + 1]] - r) for r in range(M)}
     if len(pats) * (int(n.max()) + 1) <= 4096:
         return "narrow"
-    return "wide" if len(pats) < 65536 and sum(len(p) + 2 for p in pats) + 1 <= 18432 else None
+    return "wide" if len(pats) < 65536 and sum(len(p) + 2 for p in pats) + 1 <= 19968 else None
 
 
 def _sellp_eligible(entries, M):
