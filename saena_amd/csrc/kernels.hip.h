@@ -74,7 +74,6 @@ struct SpmvArgs {
     // dst holds the pattern id of every row
     const int            *ptab;
     int                   pt_w, pt_n;
-    int                   gpw;       // k_sellp<WIDE> / k_sellp2<WIDE>: groups of slices per workgroup
     int                   ncols;     // k_sellp2: columns of x (its 16-byte loads stay inside the vector)
     int                   nt;        // non-temporal stream loads (k_csr_stream / cc16 / cm / wave / xlds): see ld_stream_*
     int                   nt_from;   // k_sell: first slice read with non-temporal loads (the slices before it stay in the Infinity Cache)
@@ -681,32 +680,32 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
 // the stores of y) are non-temporal, x is not.  Measured on Poisson 256^3 (1.2 GB stored, profiles/r03_sellp_nt.log):
 // 257 -> 220 us back to back; on the cache-resident 128^3 operator it loses (22.5 -> 30 us), so the launch picks by size.
 // Two slices per wave (twice the loads in flight per lane) changed nothing, four were slower (profiles/r03_sellp_ns.log).
-// WIDE: the table of an operator whose rows follow a few HUNDRED patterns of several dozen entries -- the first smoothed-
-// aggregation level of a structured grid: Poisson 128^3 / 256^3 level 1 has 321 patterns, 14 469 offsets in all, whatever the
-// size (two of them cover 85 % of the rows).  The table is stored compactly (a.ptab: pt_n start offsets, then per pattern its
-// length and that many offsets; a.pt_w ints in all, <= SPW_MAX_TABLE = 78 KiB), a workgroup of 1024 threads shares one copy
-// (two workgroups per CU: full occupancy at <= 64 VGPRs) and works through a.gpw groups of 16 slices with it.
-constexpr int SPW_MAX_TABLE = 19968;      // 78 KiB: two workgroups per CU (the local part of a rank between two neighbours follows ~420 patterns)
+// WIDE: an operator whose rows follow a few HUNDRED patterns of several dozen entries -- the first smoothed-aggregation level of
+// a structured grid: Poisson 128^3 / 256^3 level 1 has 321 patterns, 14 469 offsets in all, whatever the size (two of them cover
+// 85 % of the rows); the local part of a rank of the row-partitioned level has a hundred more (rows next to a neighbour lose their
+// remote entries).  A workgroup of 1024 threads = 1024 consecutive rows meets a few dozen of them, so the host stores, PER
+// WORKGROUP, just those (a.ptab + a.segptr[b]: n start offsets, then per pattern its length and that many offsets; at most
+// SPW_MAX_TABLE ints, typically 2 K = 8 KiB next to 557 KiB of values) and a.dst numbers the rows' patterns within them -- no limit on
+// the number of patterns of the operator.  (First form: one compact table of all patterns in 72-78 KiB of LDS per workgroup; the
+// local parts of a 4-rank run already exceeded it.)
+constexpr int SPW_MAX_TABLE = 8192;
 constexpr int SPW_BLOCK     = 1024;
 template <int EPI, bool HALO, bool PAIR, bool NT, bool WIDE = false>
 __global__ __launch_bounds__(WIDE ? SPW_BLOCK : BLOCK) void k_sellp(const SpmvArgs a, int nrows) {
     constexpr int BS = WIDE ? SPW_BLOCK : BLOCK;
-    extern __shared__ int ptab_dyn[];
-    int *ptab_lds;
-    if constexpr (WIDE) { __shared__ int ptab_wide[SPW_MAX_TABLE]; ptab_lds = ptab_wide; } else ptab_lds = ptab_dyn;
+    extern __shared__ int ptab_lds[];
     if constexpr (HALO) fork_signal(a);
-    {
-        const int tn = WIDE ? a.pt_w : a.pt_n * (a.pt_w + 1);
-        for (int i = threadIdx.x; i < tn; i += BS) ptab_lds[i] = a.ptab[i];
-    }
-    __syncthreads();
     constexpr int SPB = BS / 64;
     const int lane = threadIdx.x & 63;
     const int ngrp = (a.nblk + SPB - 1) / SPB;
-    const int gpw = WIDE ? a.gpw : 1;
-    const int b0 = xcd_remap(blockIdx.x, (ngrp + gpw - 1) / gpw) * gpw;
-    for (int g = 0; g < gpw; ++g) {
-    const int s = __builtin_amdgcn_readfirstlane((b0 + g) * SPB + ((int)threadIdx.x >> 6));
+    const int b0 = xcd_remap(blockIdx.x, ngrp);
+    {
+        const int t0 = WIDE ? a.segptr[b0] : 0, tn = WIDE ? a.segptr[b0 + 1] - t0 : a.pt_n * (a.pt_w + 1);
+        for (int i = threadIdx.x; i < tn; i += BS) ptab_lds[i] = a.ptab[t0 + i];
+    }
+    __syncthreads();
+    {
+    const int s = __builtin_amdgcn_readfirstlane(b0 * SPB + ((int)threadIdx.x >> 6));
     if (s >= a.nblk) return;
     const int r = s * 64 + lane;
     const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 6;
@@ -892,23 +891,20 @@ constexpr int SPW2_BLOCK = 512;
 template <int EPI, bool HALO, bool NT, bool WIDE = false>
 __global__ __launch_bounds__(WIDE ? SPW2_BLOCK : BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
     constexpr int BS = WIDE ? SPW2_BLOCK : BLOCK;
-    extern __shared__ int ptab_dyn[];
-    int *ptab_lds;
-    if constexpr (WIDE) { __shared__ int ptab_wide[SPW_MAX_TABLE]; ptab_lds = ptab_wide; } else ptab_lds = ptab_dyn;
+    extern __shared__ int ptab_lds[];
     if constexpr (HALO) fork_signal(a);
-    {
-        const int tn = WIDE ? a.pt_w : a.pt_n * (a.pt_w + 1);
-        for (int i = threadIdx.x; i < tn; i += BS) ptab_lds[i] = a.ptab[i];
-    }
-    __syncthreads();
     constexpr int SPB = BS / 64;
     const int lane = threadIdx.x & 63;
     const int ngrp = (a.nblk + SPB - 1) / SPB;
-    const int gpw = WIDE ? a.gpw : 1;
-    const int b0 = xcd_remap(blockIdx.x, (ngrp + gpw - 1) / gpw) * gpw;
+    const int b0 = xcd_remap(blockIdx.x, ngrp);
+    {                                                              // (WIDE: the workgroup's own table -- its 8 slices of 128 rows are k_sellp<WIDE>'s 16 of 64)
+        const int t0 = WIDE ? a.segptr[b0] : 0, tn = WIDE ? a.segptr[b0 + 1] - t0 : a.pt_n * (a.pt_w + 1);
+        for (int i = threadIdx.x; i < tn; i += BS) ptab_lds[i] = a.ptab[t0 + i];
+    }
+    __syncthreads();
     const int xlast = a.ncols - 1;
-    for (int g = 0; g < gpw; ++g) {
-    const int s = __builtin_amdgcn_readfirstlane((b0 + g) * SPB + ((int)threadIdx.x >> 6));
+    {
+    const int s = __builtin_amdgcn_readfirstlane(b0 * SPB + ((int)threadIdx.x >> 6));
     if (s >= a.nblk) return;
     const int rA = s * 128 + 2 * lane, rB = rA + 1;
     const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 7;
@@ -972,7 +968,7 @@ __global__ __launch_bounds__(WIDE ? SPW2_BLOCK : BLOCK) void k_sellp2(const Spmv
         bool both = true;
         if constexpr (HALO)                                        // ... unless one of them is a boundary row (written by the halo stream's kernel)
             if (a.skip) both = ((a.skip[rA >> 5] >> (rA & 31)) & 3u) == 0u;      // rA is even: both bits sit in one word
-        if (both) { epilogue2<EPI, NT>(a, rA, sumA, sumB); continue; }
+        if (both) { epilogue2<EPI, NT>(a, rA, sumA, sumB); return; }
     }
     if (rA < nrows) epilogue<EPI, HALO, NT>(a, rA, sumA);
     if (rB < nrows) epilogue<EPI, HALO, NT>(a, rB, sumB);

@@ -162,11 +162,12 @@ struct CsrPart {
     // patterns (sp_n rows of sp_w + 1 ints: length, then the columns relative to the row); shares sl_val / sl_ptr
     unsigned short *sp_pat = nullptr;
     int            *sp_tab = nullptr;
-    int             sp_w = 0, sp_n = 0, sp_gpw = 1;
+    int             sp_w = 0, sp_n = 0;
+    int            *sp_wgptr = nullptr;   // sp_wide: table of row group g = sp_tab[sp_wgptr[g] .. sp_wgptr[g + 1])
     int64_t         sp_bytes = 0;      // values + pattern ids + x + y as this form stores them
-    bool            sp_ok = false, sp_wide = false;   // sp_wide: the compact table of k_sellp<WIDE> (sp_w = its ints)
+    bool            sp_ok = false, sp_wide = false;   // sp_wide: a table per group of 1024 rows (k_sellp<WIDE>; sp_w = the largest, in ints)
     char            sp_tried = 0;
-    void free_sellp() { hipFree(sp_pat); hipFree(sp_tab); sp_pat = nullptr; sp_tab = nullptr; sp_ok = false; sp_wide = false; sp_tried = 0; }      // (and k_sellpx with it: free_sell)
+    void free_sellp() { hipFree(sp_pat); hipFree(sp_tab); hipFree(sp_wgptr); sp_pat = nullptr; sp_tab = nullptr; sp_wgptr = nullptr; sp_ok = false; sp_wide = false; sp_tried = 0; }      // (and k_sellpx with it: free_sell)
     // the column codes of k_sell alone (k_sellp keeps the values and the slice pointers)
     void free_sell_columns() {
         hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr);
@@ -618,13 +619,14 @@ int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
 }
 
 // Row patterns of the local part (k_sellp) on top of build_sell's values: every row is (length, columns relative to the
-// row index); the operator qualifies when its rows follow at most 65 535 distinct patterns whose table fits LDS:
-//   * 4096 ints at a fixed width of (longest row + 1) -- stencils on structured grids (the boundary-stripped 7-point Laplacian:
-//     27 patterns), band matrices: the table of k_sellp / k_sellp2 with 256 threads per workgroup;
-//   * else 19 968 ints stored compactly (start offsets, then length + offsets per pattern) -- the first smoothed-aggregation
-//     level of a structured grid (Poisson level 1: 321 patterns, 14 469 offsets at every size): k_sellp<WIDE>, 1024 threads
-//     around one table (sp_wide).
-// Ids are dealt in order of first appearance, so the table does not depend on threads or hashing.
+// row index); the operator qualifies when its rows follow at most 65 535 distinct patterns and
+//   * they fit 4096 ints at a fixed width of (longest row + 1) -- stencils on structured grids (the boundary-stripped 7-point
+//     Laplacian: 27 patterns), band matrices: ONE table for k_sellp / k_sellp2 with 256 threads per workgroup; or
+//   * the patterns that 1024 consecutive rows follow fit SPW_MAX_TABLE ints, group of rows by group (sp_wide) -- the first
+//     smoothed-aggregation level of a structured grid (Poisson level 1: 321 patterns at every size, ~400 in the local part of a
+//     rank with two neighbours; a group meets a few dozen): every workgroup of k_sellp<WIDE> gets its own table (start offsets,
+//     then length + offsets per pattern) and the rows' ids count within it.
+// Ids are dealt in order of first appearance, so the tables do not depend on threads or hashing.
 constexpr int SP_MAX_TABLE = 4096;
 int build_sellp(CsrPart &P) {
     if (P.sp_ok || P.sp_tried || !P.sl_ok || P.h_rp.empty()) return SGPU_OK;
@@ -633,6 +635,7 @@ int build_sellp(CsrPart &P) {
     int W = 1;
     for (int r = 0; r < M; ++r) W = std::max(W, P.h_rp[r + 1] - P.h_rp[r]);
     if (W + 3 > sk::SPW_MAX_TABLE) return SGPU_OK;
+    const size_t max_ints = (size_t)P.nnz / 8 + 65536;          // an operator whose patterns hold an eighth of its entries is not this kind of operator
     std::vector<int> ctab, cstart;                             // patterns back to back: length, then that many offsets
     std::vector<unsigned short> pat(((size_t)M + 127) / 128 * 128, 0);
     std::unordered_map<std::string, int> ids;
@@ -650,7 +653,7 @@ int build_sellp(CsrPart &P) {
         for (int j = 0; j < n; ++j) { const int o = P.h_col[(size_t)p0 + j] - r; key.append(reinterpret_cast<const char *>(&o), sizeof o); }
         auto it = ids.find(key);
         if (it == ids.end()) {
-            if (npat == 65535 || (size_t)npat + 1 + ctab.size() + (size_t)n + 1 + 1 > (size_t)sk::SPW_MAX_TABLE) return SGPU_OK;   // not this kind of operator
+            if (npat == 65535 || ctab.size() + (size_t)n + 1 > max_ints) return SGPU_OK;
             it = ids.emplace(key, npat++).first;
             cstart.push_back((int)ctab.size());
             ctab.push_back(n);
@@ -660,32 +663,55 @@ int build_sellp(CsrPart &P) {
         pat[(size_t)r] = (unsigned short)prev;
     }
     if (npat == 0) return SGPU_OK;
-    std::vector<int> tab;
+    std::vector<int> tab, wgptr;
+    std::vector<unsigned short> lpat;                          // wide: the rows' ids within their group's table
     const bool wide = (size_t)npat * (W + 1) > (size_t)SP_MAX_TABLE;
+    size_t max_group = 0;
     if (!wide) {                                               // fixed width: W + 1 ints per pattern
         tab.assign((size_t)npat * (W + 1), 0);
         for (int i = 0; i < npat; ++i) {
             const int *c = &ctab[(size_t)cstart[(size_t)i]];
             for (int j = 0; j <= c[0]; ++j) tab[(size_t)i * (W + 1) + j] = c[j];
         }
-    } else {                                                   // compact: [start of pattern i in this array] [patterns] [one spare int]
-        tab.reserve((size_t)npat + ctab.size() + 1);
-        for (int i = 0; i < npat; ++i) tab.push_back(npat + cstart[(size_t)i]);
-        tab.insert(tab.end(), ctab.begin(), ctab.end());
-        tab.push_back(0);
+    } else {                                                   // per group of SPW_BLOCK rows: [start of its k-th pattern in the group's table] [patterns] [one spare int]
+        const int G = sk::SPW_BLOCK, ngrp = (M + G - 1) / G;
+        wgptr.assign((size_t)ngrp + 1, 0);
+        lpat.assign(pat.size(), 0);
+        std::vector<int> local((size_t)npat, -1), used;
+        for (int g = 0; g < ngrp; ++g) {
+            used.clear();
+            for (int r = g * G; r < std::min(M, (g + 1) * G); ++r) {
+                const int id = pat[(size_t)r];
+                if (local[(size_t)id] < 0) { local[(size_t)id] = (int)used.size(); used.push_back(id); }
+                lpat[(size_t)r] = (unsigned short)local[(size_t)id];
+            }
+            size_t ints = used.size() + 1;
+            for (int id : used) ints += 1 + (size_t)ctab[(size_t)cstart[(size_t)id]];
+            if (ints > (size_t)sk::SPW_MAX_TABLE || tab.size() + ints > (size_t)INT32_MAX - 8) return SGPU_OK;
+            max_group = std::max(max_group, ints);
+            const size_t t0 = tab.size();
+            tab.resize(t0 + ints, 0);
+            size_t at = t0 + used.size();
+            for (size_t k = 0; k < used.size(); ++k) {
+                const int *c = &ctab[(size_t)cstart[(size_t)used[k]]];
+                tab[t0 + k] = (int)(at - t0);
+                for (int j = 0; j <= c[0]; ++j) tab[at++] = c[j];
+                local[(size_t)used[k]] = -1;
+            }
+            wgptr[(size_t)g + 1] = (int)tab.size();
+        }
     }
-    if (std::getenv("SAENA_SETUP_TIMING"))
-        fprintf(stderr, "[sgpu] row patterns: %d rows follow %d patterns of <= %d entries (%zu ints, %s table)\n", M, npat, W, tab.size(), wide ? "compact" : "fixed-width");
-    CHK(dev_upload(&P.sp_pat, pat.data(), pat.size()));
+    if (std::getenv("SAENA_SETUP_TIMING")) {
+        if (wide) fprintf(stderr, "[sgpu] row patterns: %d rows follow %d patterns of <= %d entries (%zu offsets in all); a table per %d rows, at most %zu ints, %.1f MB in all\n", M, npat, W,
+                          ctab.size() - (size_t)npat, sk::SPW_BLOCK, max_group, (double)tab.size() * 4e-6);
+        else fprintf(stderr, "[sgpu] row patterns: %d rows follow %d patterns of <= %d entries (%zu ints, fixed-width table)\n", M, npat, W, tab.size());
+    }
+    CHK(dev_upload(&P.sp_pat, wide ? lpat.data() : pat.data(), pat.size()));
     CHK(dev_upload(&P.sp_tab, tab.data(), tab.size()));
-    P.sp_w = wide ? (int)tab.size() : W; P.sp_n = npat; P.sp_wide = wide;
+    if (wide) CHK(dev_upload(&P.sp_wgptr, wgptr.data(), wgptr.size()));
+    P.sp_w = wide ? (int)max_group : W; P.sp_n = npat; P.sp_wide = wide;
     P.h_pstart = std::move(cstart); P.h_ptab = std::move(ctab); P.h_pat = std::move(pat);      // (for build_sellpx; dropped when the plan settles)
-    {                                                          // groups of 16 slices per workgroup of the wide form: the table load is paid once per workgroup
-        const int ngrp = (P.nslices + 15) / 16, env = std::getenv("SAENA_SELLPW_GROUPS") ? std::atoi(std::getenv("SAENA_SELLPW_GROUPS")) : 0;
-        (void)ngrp;                                            // measured on Poisson level 1: 1 group 123 / 960 us (128^3 / 256^3), 2 groups 128 / 962, 4 groups - / 995
-        P.sp_gpw = env > 0 ? std::min(env, 64) : 1;
-    }
-    P.sp_bytes = 8 * (int64_t)P.h_rp.back() + 2 * (int64_t)M + 8 * (int64_t)P.ncols + 8 * (int64_t)M;
+    P.sp_bytes = 8 * (int64_t)P.h_rp.back() + 2 * (int64_t)M + 8 * (int64_t)P.ncols + 8 * (int64_t)M + (wide ? 4 * (int64_t)tab.size() : 0);
     P.sp_ok = true;
     return SGPU_OK;
 }
@@ -1238,7 +1264,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d; a.y2 = e.y2;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12; a.dst = nullptr; a.cmptr = nullptr;
-    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0; a.gpw = 1; a.ncols = P.ncols; a.nt_from = 0;
+    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0; a.ncols = P.ncols; a.nt_from = 0;
     static const int nt_rt = std::getenv("SAENA_STREAM_NT") ? std::atoi(std::getenv("SAENA_STREAM_NT")) : 0;
     a.nt = nt_rt == 1 || (nt_rt == 2 && 12 * P.nnz > (int64_t)256 * 1024 * 1024) ? 1 : 0;
     const bool halo = skip != nullptr || seq != 0;
@@ -1268,10 +1294,9 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         const bool nt = nt_env2 >= 0 ? nt_env2 != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
         a.nt_from = nt ? resident_slices(P.sp2_nslices, 8.0 * (double)P.nnz / (double)std::max(1, P.sp2_nslices)) : 0;
         a.ncols = P.ncols;
-        if (P.sp_wide) {                                          // compact table shared by 512 threads, gpw groups of 8 slices per workgroup
-            const int ngrp = (P.sp2_nslices + 7) / 8;
-            a.gpw = P.sp_gpw;
-            SGPU_LAUNCH(pick_sellp2<true>(epi, halo, nt), dim3((ngrp + a.gpw - 1) / a.gpw), dim3(sk::SPW2_BLOCK), 0, g.cs, a, P.nrows);
+        if (P.sp_wide) {                                          // a table per workgroup: 512 threads, 8 slices of 128 rows
+            a.segptr = P.sp_wgptr;
+            SGPU_LAUNCH(pick_sellp2<true>(epi, halo, nt), dim3((P.sp2_nslices + 7) / 8), dim3(sk::SPW2_BLOCK), (size_t)P.sp_w * sizeof(int), g.cs, a, P.nrows);
         } else
         SGPU_LAUNCH(pick_sellp2<false>(epi, halo, nt), dim3((P.sp2_nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
     } else if (P.variant == 13) {                                 // row templates: a thread per row, no operator stream at all
@@ -1303,10 +1328,9 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         static const int nt_env = std::getenv("SAENA_SELLP_NT") ? std::atoi(std::getenv("SAENA_SELLP_NT")) : -1;
         const bool nt = nt_env >= 0 ? nt_env != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
         a.nt_from = nt ? resident_slices(P.nslices, 8.0 * (double)P.nnz / (double)std::max(1, P.nslices)) : 0;
-        if (P.sp_wide) {                                          // compact table shared by 1024 threads, gpw groups of 16 slices per workgroup
-            const int ngrp = (P.nslices + 15) / 16;
-            a.gpw = P.sp_gpw;
-            SGPU_LAUNCH(pick_sellp(epi, halo, P.sl_pair, nt, true), dim3((ngrp + a.gpw - 1) / a.gpw), dim3(sk::SPW_BLOCK), 0, g.cs, a, P.nrows);
+        if (P.sp_wide) {                                          // a table per workgroup: 1024 threads, 16 slices of 64 rows
+            a.segptr = P.sp_wgptr;
+            SGPU_LAUNCH(pick_sellp(epi, halo, P.sl_pair, nt, true), dim3((P.nslices + 15) / 16), dim3(sk::SPW_BLOCK), (size_t)P.sp_w * sizeof(int), g.cs, a, P.nrows);
         } else
         SGPU_LAUNCH(pick_sellp(epi, halo, P.sl_pair, nt, false), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
     } else if (P.variant == 9) {                                  // sliced ELLPACK, a lane per row
@@ -2146,7 +2170,7 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
         CHK(build_sellp(op->loc));
         if (!op->loc.sp_ok)
             return fail(SGPU_ERR_ARG, "the row-pattern form needs what the sliced-ELLPACK form needs and rows that follow at most %d-int's worth of "
-                                      "(length, relative columns) patterns", sk::SPW_MAX_TABLE);
+                                      "(length, relative columns) patterns per group of %d rows", sk::SPW_MAX_TABLE, sk::SPW_BLOCK);
     }
     if (variant == 10) {
         CHK(build_xlds(op->loc));
@@ -2333,8 +2357,10 @@ int sgpu_op_autotune(sgpu_op *op) {
             if (!std::getenv("SAENA_NO_SELLP")) {                                                    // rows that repeat a few patterns: no column stream
                 CHK(build_sellp(op->loc));
                 if (op->loc.sp_ok) variants.push_back(11);
-                if (op->loc.sp_ok && !op->loc.sp_wide && !std::getenv("SAENA_NO_SELLP2")) {               // ... and a lane per two rows: half the gathers (with the
-                                                                                                         // wide table it ties with k_sellp: 957 / 962 us on 256^3 level 1, 124 / 123 on 128^3)
+                // ... and a lane per two rows: half the gathers.  With a table per workgroup (sp_wide: the 68-entry level) it wins on the
+                // operator of 128^3 (110 against 116 us, k_sellpx 114) and ties on that of 256^3 (940 / 945, k_sellpx 890), whose row-paired
+                // copy is 4.5 GB to build: tried up to 1 GB (profiles/r03_sellp_pergroup_tables.log)
+                if (op->loc.sp_ok && (!op->loc.sp_wide || op->loc.sp_bytes <= ((int64_t)1 << 30)) && !std::getenv("SAENA_NO_SELLP2")) {
                     CHK(build_sellp2(op->loc, op->h_val_all));
                     if (op->loc.sp2_ok) variants.push_back(14);
                 }
