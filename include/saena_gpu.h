@@ -128,8 +128,8 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
  * piece, sgpu_op_set_lanes_per_row); 11 k_sellp: k_sell's values without a column stream -- a 16-bit id per row into a
  * table of (length, columns relative to the row) patterns held in LDS, 8 B per entry + 2 B per row (operators that
  * qualify for 9 and whose rows follow few enough patterns for a table of 4096 ints: stencils on structured grids, band
- * matrices; or for a compact table of 19 968 ints around 1024 threads, "k_sellp<wide>": the first smoothed-aggregation
- * level of a structured grid; the local loop of src/saena_matrix_matvec.cpp:68-80 with the same sequential row sum); 12 k_sellx: sliced
+ * matrices; or, "k_sellp<wide>", where the patterns that every group of 1024 consecutive rows follows fit 8192 ints -- a
+ * table per workgroup: the first smoothed-aggregation level of a structured grid; the local loop of src/saena_matrix_matvec.cpp:68-80 with the same sequential row sum); 12 k_sellx: sliced
  * ELLPACK inside the (row chunk, column window) blocks of the x-in-LDS plan, a lane per row piece (rows of a few hundred
  * entries; at most 25 % padding); 13 k_rowt: row templates -- rows that repeat (length, relative columns, values) served
  * from a table in LDS, a 16-bit template id per row and nothing else of the operator (constant-coefficient stencils; never

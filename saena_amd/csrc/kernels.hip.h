@@ -880,13 +880,12 @@ __global__ __launch_bounds__(SPX_BLOCK) void k_sellpx(const SpmvArgs a, int nrow
 // a.val: the row-paired values, a.cmptr: slice starts (multiples of 128), a.dst: pattern ids, a.ptab / pt_w / pt_n: the table,
 // a.nblk: slices of 128 rows.
 // Lanes whose two rows differ in pattern (1 % of them on the 7-point level) take two 8-byte gathers.
-// WIDE: the compact table of k_sellp<WIDE> (a few hundred patterns of several dozen entries: level 1 of a structured grid),
-// 512 threads around one copy -- two workgroups per CU at <= 128 VGPRs -- each serving a.gpw groups of 8 slices.  There a lane
-// whose two rows differ in pattern still takes the 16-byte load for its first row and ONE 8-byte gather for the second: a wave
-// with such lanes issues two gather instructions per position instead of three (on level 1 of the Poisson cube the pattern
-// changes at the end of every grid line -- 63 rows at 128^3 -- so nearly every slice of 128 rows holds such a lane).  Measured
-// on that level it ties with k_sellp<WIDE> (957 / 962 us at 256^3, 124 / 123 us at 128^3: neither bytes nor gather instructions
-// bound it there), so the autotune does not build it; sgpu_op_set_variant does.
+// WIDE: the tables of k_sellp<WIDE> (a few hundred patterns of several dozen entries: level 1 of a structured grid; one table per
+// 1024 rows), 512 threads = the same 1024 rows per workgroup.  There a lane whose two rows differ in pattern still takes the 16-byte
+// load for its first row and ONE 8-byte gather for the second: a wave with such lanes issues two gather instructions per position
+// instead of three (on level 1 of the Poisson cube the pattern changes at the end of every grid line -- 63 rows at 128^3 -- so nearly
+// every slice of 128 rows holds such a lane).  Measured on that level: the fastest form on the 128^3 operator (110 against
+// k_sellp<WIDE>'s 116 and k_sellpx's 114 us), a tie on the 256^3 one (940 / 945 us; k_sellpx 890).
 constexpr int SPW2_BLOCK = 512;
 template <int EPI, bool HALO, bool NT, bool WIDE = false>
 __global__ __launch_bounds__(WIDE ? SPW2_BLOCK : BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
