@@ -859,12 +859,11 @@ def test_row_patterns_wide_table(capi, variant, monkeypatch):
     du = capi.DeviceVector(M, rhs)
     G.prolong_correct(dx, du)
     np.testing.assert_array_equal(du.download(), rhs - A.matvec(x))
-    if variant != 15 or True:
-        many = _patterned_operator(30000, 600, 40, 50, 12)    # every group of 1024 rows meets all 600 patterns x 41 ints: beyond a workgroup's table
-        assert _sellp_table(many, 30000) is None
-        G2 = util.gpu_operator(orc.OracleOp(many, 30000, 30000, orc.split_even(30000, 1)))
-        with pytest.raises(capi.SgpuError, match="row-pattern"):
-            G2.set_variant(variant)
+    many = _patterned_operator(30000, 600, 40, 50, 12)    # every group of 1024 rows meets all 600 patterns x 41 ints: beyond a workgroup's table
+    assert _sellp_table(many, 30000) is None
+    G2 = util.gpu_operator(orc.OracleOp(many, 30000, 30000, orc.split_even(30000, 1)))
+    with pytest.raises(capi.SgpuError, match="row-pattern"):
+        G2.set_variant(variant)
 
 
 def test_row_patterns_with_x_in_lds_windows(capi, monkeypatch):
