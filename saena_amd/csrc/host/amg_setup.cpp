@@ -8,6 +8,7 @@
 #include <cfloat>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <fstream>
 #include <cstdlib>
 #include <mutex>
@@ -202,8 +203,7 @@ Csr spgemm(const CsrRef &A, const Csr &B, index_t row_offset = 0) {
         std::vector<size_t> slots;
         auto &oc = tcol[t];
         auto &ov = tval[t];
-        oc.reserve((size_t)((work[hi] - work[lo]) / 4 + 16));
-        ov.reserve(oc.capacity());
+        { LazyBigalloc lazy; oc.reserve((size_t)((work[hi] - work[lo]) / 4 + 16)); ov.reserve(oc.capacity()); }     // an estimate: not touched
         for (index_t i = lo; i < hi; ++i) {
             const nnz_t products = work[i + 1] - work[i] - 1;
             nnz_t cnt = 0;
@@ -779,20 +779,27 @@ int amg_hierarchy::next_stride(long nnzC, index_t rowsC, int np, int stride_prev
     index_t rows_rule = shrink_rows;
     if (const char *e = std::getenv("SAENA_SHRINK_CHAIN_US")) chain = std::atof(e);
     if (const char *e = std::getenv("SAENA_SHRINK_ROWS")) rows_rule = (index_t)std::atol(e);
-    if (np == 1) return 1;
-    if (stride_prev >= np) return np;
-    if (rowsC <= rows_rule) return np;
-    if (chain <= 0) return stride_prev;
     const double T1 = 12.0 * (double)nnzC / shrink_bw * 1e6 + shrink_launch_us;     // us per apply on one GPU
-    if (T1 <= chain) return np;                                                      // decide_shrinking_c: one rank
-    const int active = (np + stride_prev - 1) / stride_prev;
+    const int active = (np + std::max(1, stride_prev) - 1) / std::max(1, stride_prev);
     const double compute = T1 / active;
-    if (active > 1 && chain > 2.0 * compute) {                                       // decide_shrinking: comm > 2 x compute
+    int stride = stride_prev;
+    const char *rule = "stays";
+    if (np == 1) { stride = 1; rule = "one rank"; }
+    else if (stride_prev >= np) { stride = np; rule = "already on one rank"; }
+    else if (rowsC <= rows_rule) { stride = np; rule = "row rule: one rank"; }
+    else if (chain <= 0) rule = "no chain: stays";
+    else if (T1 <= chain) { stride = np; rule = "T1 <= chain: one rank"; }           // decide_shrinking_c: one rank
+    else if (active > 1 && chain > 2.0 * compute) {                                  // decide_shrinking: comm > 2 x compute
         int f = (int)std::floor(chain / compute / 5.0);
         f = std::max(2, std::min(4, f));
-        return std::min(np, stride_prev * f);
+        stride = std::min(np, stride_prev * f);
+        rule = "chain > 2 x compute: groups merge";
     }
-    return stride_prev;
+    // every decision with the chain it was taken with (the measured one is a run-time number: round-3 advisor finding)
+    if (np > 1 && std::getenv("SAENA_SETUP_TIMING"))
+        fprintf(stderr, "[saena] agglomeration: level of %ld rows / %ld entries, %d active ranks: T1 %.1f us, chain %.1f us (%s) -> stride %d (%s)\n", (long)rowsC, nnzC,
+                active, T1, chain, std::getenv("SAENA_SHRINK_CHAIN_US") ? "SAENA_SHRINK_CHAIN_US" : g_measured_chain_us > 0.0 ? "measured at init, quantised" : "constant", stride, rule);
+    return stride;
 }
 
 // shrink_set_params (src/saena_matrix_shrink.cpp:120-129): ranks that are not a multiple of `stride` hand their block
@@ -1319,6 +1326,7 @@ int amg_hierarchy::setup_rows_distributed(saena_matrix *Ad, const amg_options &o
                 for (index_t i = r0; i < r1; ++i) {
                     if (i == probe && A.ptr[i] > A.ptr[r0]) {
                         const size_t est = (size_t)(1.1 * (double)oc.size() / (double)(A.ptr[i] - A.ptr[r0]) * (double)(A.ptr[r1] - A.ptr[r0])) + 4096;
+                        LazyBigalloc lazy;                                         // an estimate: advised, not touched
                         oc.reserve(est); ov.reserve(est);
                     }
                     row.clear();

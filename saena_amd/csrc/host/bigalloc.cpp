@@ -19,6 +19,14 @@
 #include <dlfcn.h>
 #include <sys/mman.h>
 
+#include "par.h"
+
+// Reservations (vector::reserve of an over-estimate: the products' 1.15 x estimate of up to 3e9 entries, a thread's piece of the
+// smoothed P) only get the huge-page advice inside a LazyBigalloc scope: touching them would turn capacity that may never be
+// filled into resident memory (round-3 advisor finding: with several ranks per node that is what reaches the OOM killer first).
+// Whoever fills the block later faults it in 2 MiB at a time.
+int &saena_host::bigalloc_lazy_depth() { static thread_local int depth = 0; return depth; }
+
 namespace {
 
 constexpr size_t BIG = (size_t)8 << 20;          // from here on: huge pages + parallel first touch
@@ -40,6 +48,7 @@ void make_resident(void *p, size_t n) {
     // a block this large is a mapping of its own (glibc: mmap beyond the threshold): advise its 2 MiB-aligned interior
     const uintptr_t lo = ((uintptr_t)b + HUGE - 1) & ~(uintptr_t)(HUGE - 1), hi = ((uintptr_t)b + n) & ~(uintptr_t)(HUGE - 1);
     if (hi > lo) madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    if (saena_host::bigalloc_lazy_depth() > 0) return;          // a reservation: advice only
     const int T = touch_threads();
     auto touch = [b, n](size_t a, size_t e) { for (size_t i = a; i < e && i < n; i += 4096) static_cast<volatile char *>(b)[i] = 0; };
     if (T == 1 || n < 4 * BIG) { touch(0, n); return; }

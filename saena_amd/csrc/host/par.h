@@ -14,6 +14,15 @@
 
 namespace saena_host {
 
+// bigalloc.cpp: allocations made by this thread inside a LazyBigalloc scope are advised to use huge pages but not touched
+int &bigalloc_lazy_depth();
+struct LazyBigalloc {
+    LazyBigalloc() { ++bigalloc_lazy_depth(); }
+    ~LazyBigalloc() { --bigalloc_lazy_depth(); }
+    LazyBigalloc(const LazyBigalloc &) = delete;
+    LazyBigalloc &operator=(const LazyBigalloc &) = delete;
+};
+
 inline int setup_threads() {
     static const int n = [] {
         if (const char *e = std::getenv("SAENA_SETUP_THREADS")) return std::max(1, std::atoi(e));

@@ -2,6 +2,7 @@
 #include "shm_comm.h"
 
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
@@ -28,6 +29,7 @@ struct PerRank {
 };
 struct Ctl {
     std::atomic<uint32_t> magic, bar_count, bar_gen, failed;
+    std::atomic<uint32_t> attached, go;                // attach handshake: ranks != 0 count in, rank 0 opens the gate
     uint32_t nranks;
     PerRank r[MAXR];
 };
@@ -40,6 +42,7 @@ struct ShmComm : Comm {
     int    fd[MAXR];
     char  *seg[MAXR];
     size_t mapped[MAXR];
+    size_t committed = 0;                              // bytes of the own segment whose pages tmpfs has reserved
     double timeout = 900.0;
 
     ShmComm() { for (int i = 0; i < MAXR; ++i) { fd[i] = -1; seg[i] = nullptr; mapped[i] = 0; } }
@@ -77,18 +80,33 @@ struct ShmComm : Comm {
             wait_until([&] { return ctl->bar_gen.load(std::memory_order_acquire) != gen; }, "the other ranks at a barrier");
         }
     }
-    // own segment: at least `bytes`
+    // own segment: at least `bytes`, WITH their pages.  ftruncate alone only moves the end of the file -- tmpfs hands out pages
+    // at the first touch, and a /dev/shm smaller than an exchange (a container's default is 64 MB) would then end the process
+    // with SIGBUS inside a copy.  posix_fallocate reserves the pages now and reports ENOSPC as an error the caller can act on
+    // (bench.py falls back to the gloo transport).
+    void commit(size_t bytes) {
+        if (bytes <= committed) return;
+        const size_t upto = std::min(mapped[rank], (bytes + GRAIN - 1) / GRAIN * GRAIN);
+        int rc;
+        do rc = posix_fallocate(fd[rank], (off_t)committed, (off_t)(upto - committed)); while (rc == EINTR);
+        if (rc != 0)
+            die("no room for " + std::to_string(upto) + " bytes in /dev/shm (" + std::strerror(rc) + "): the exchanges of a " + std::to_string(nranks) +
+                "-rank setup need that much shared memory per rank -- enlarge /dev/shm or use another setup transport");
+        committed = upto;
+    }
     void reserve(size_t bytes) {
-        if (bytes <= mapped[rank]) return;
-        size_t cap = std::max(bytes, 2 * mapped[rank]);
-        cap = (cap + GRAIN - 1) / GRAIN * GRAIN;
-        if (ftruncate(fd[rank], (off_t)cap) != 0) die("ftruncate of the data segment to " + std::to_string(cap) + " bytes failed (is /dev/shm full?)");
-        if (seg[rank]) munmap(seg[rank], mapped[rank]);
-        void *m = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd[rank], 0);
-        if (m == MAP_FAILED) { seg[rank] = nullptr; mapped[rank] = 0; die("mmap of the data segment failed"); }
-        seg[rank] = static_cast<char *>(m);
-        mapped[rank] = cap;
-        ctl->r[rank].seg_size.store(cap, std::memory_order_release);
+        if (bytes > mapped[rank]) {
+            size_t cap = std::max(bytes, 2 * mapped[rank]);
+            cap = (cap + GRAIN - 1) / GRAIN * GRAIN;
+            if (ftruncate(fd[rank], (off_t)cap) != 0) die("ftruncate of the data segment to " + std::to_string(cap) + " bytes failed: " + std::strerror(errno));
+            if (seg[rank]) munmap(seg[rank], mapped[rank]);
+            void *m = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd[rank], 0);
+            if (m == MAP_FAILED) { seg[rank] = nullptr; mapped[rank] = 0; die("mmap of the data segment failed"); }
+            seg[rank] = static_cast<char *>(m);
+            mapped[rank] = cap;
+            ctl->r[rank].seg_size.store(cap, std::memory_order_release);
+        }
+        commit(bytes);
     }
     // a peer's segment, mapped at its current size
     const char *peer(int p) {
@@ -102,9 +120,9 @@ struct ShmComm : Comm {
         }
         return seg[p];
     }
-    // give the pages of a large exchange back (tmpfs pages are memory)
+    // give the pages of a large exchange back (tmpfs pages are memory); the next exchange reserves its own again
     void release(size_t used) {
-        if (used > ((size_t)64 << 20)) madvise(seg[rank], mapped[rank], MADV_REMOVE);
+        if (used > ((size_t)64 << 20) && madvise(seg[rank], mapped[rank], MADV_REMOVE) == 0) committed = 0;
     }
 
     void alltoallv(const void *send, const size_t *sc, const size_t *sd, void *recv, const size_t *rc, const size_t *rd) override {
@@ -138,6 +156,7 @@ struct ShmComm : Comm {
         char *r = static_cast<char *>(recv);
         for (int p = 0; p < nranks; ++p) std::memcpy(r + (size_t)p * bytes, p == rank ? static_cast<const char *>(send) : peer(p), bytes);
         barrier();
+        release(bytes);
     }
     template <class T>
     void allreduce(T *v, int n) {
@@ -166,38 +185,68 @@ std::unique_ptr<Comm> make_shm_comm(const std::string &name, int rank, int nrank
     if (const char *t = std::getenv("SAENA_SHM_TIMEOUT")) c->timeout = std::max(1.0, atof(t));
     try {
         // ---- control block: rank 0 creates and initialises it, the others wait for it ----
-        int cfd = -1;
+        // A name can outlive a job that died before its ranks had all attached.  Rank 0 marks such a leftover FAILED before it
+        // replaces it, and a rank that has mapped a block only trusts it once rank 0 has opened the gate (`go`) after counting
+        // every rank in -- so a rank that opened the leftover a moment before rank 0 replaced it sees `failed`, lets go of it and
+        // opens the name again, instead of sitting in a dead block's barrier until the timeout.
+        auto map_ctl = [&](int cfd) -> Ctl * {
+            void *m = mmap(nullptr, sizeof(Ctl), PROT_READ | PROT_WRITE, MAP_SHARED, cfd, 0);
+            close(cfd);
+            return m == MAP_FAILED ? nullptr : static_cast<Ctl *>(m);
+        };
+        const double t_attach = now_s();
         if (rank == 0) {
-            shm_unlink(c->base.c_str());                 // a leftover of a job that died before its ranks had all attached
-            cfd = shm_open(c->base.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-            if (cfd < 0) return fail("shm_open(" + c->base + ") failed: " + std::strerror(errno));
-            if (ftruncate(cfd, (off_t)sizeof(Ctl)) != 0) { close(cfd); shm_unlink(c->base.c_str()); return fail("ftruncate of the control block failed"); }
-        } else {
-            const double t0 = now_s();
-            while (true) {
-                cfd = shm_open(c->base.c_str(), O_RDWR, 0600);
-                if (cfd >= 0) {
-                    struct stat st;
-                    if (fstat(cfd, &st) == 0 && (size_t)st.st_size >= sizeof(Ctl)) break;
-                    close(cfd); cfd = -1;
-                }
-                if (now_s() - t0 > c->timeout) return fail("timed out waiting for rank 0 to create " + c->base);
-                timespec ts{0, 2000000};
-                nanosleep(&ts, nullptr);
+            int old = shm_open(c->base.c_str(), O_RDWR, 0600);
+            if (old >= 0) {
+                struct stat st;
+                if (fstat(old, &st) == 0 && (size_t)st.st_size >= sizeof(Ctl)) {
+                    if (Ctl *dead = map_ctl(old)) { dead->failed.store(1, std::memory_order_release); munmap(dead, sizeof(Ctl)); }
+                } else close(old);
+                shm_unlink(c->base.c_str());
             }
-        }
-        void *m = mmap(nullptr, sizeof(Ctl), PROT_READ | PROT_WRITE, MAP_SHARED, cfd, 0);
-        close(cfd);
-        if (m == MAP_FAILED) return fail("mmap of the control block failed");
-        c->ctl = static_cast<Ctl *>(m);
-        if (rank == 0) {
+            int cfd = shm_open(c->base.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (cfd < 0) return fail("shm_open(" + c->base + ") failed: " + std::strerror(errno));
+            int rc = ftruncate(cfd, (off_t)sizeof(Ctl)) != 0 ? errno : 0;
+            if (rc == 0) do rc = posix_fallocate(cfd, 0, (off_t)sizeof(Ctl)); while (rc == EINTR);
+            if (rc != 0) { close(cfd); shm_unlink(c->base.c_str()); return fail(std::string("no room for the control block in /dev/shm: ") + std::strerror(rc)); }
+            c->ctl = map_ctl(cfd);
+            if (!c->ctl) { shm_unlink(c->base.c_str()); return fail("mmap of the control block failed"); }
             c->ctl->bar_count.store(0); c->ctl->bar_gen.store(0); c->ctl->failed.store(0);
+            c->ctl->attached.store(0); c->ctl->go.store(0);
             c->ctl->nranks = (uint32_t)nranks;
             for (int p = 0; p < MAXR; ++p) c->ctl->r[p].seg_size.store(0);
             c->ctl->magic.store(MAGIC, std::memory_order_release);
+            c->wait_until([&] { return c->ctl->attached.load(std::memory_order_acquire) == (uint32_t)(nranks - 1); }, "the other ranks to attach");
+            c->ctl->go.store(1, std::memory_order_release);
         } else {
-            c->wait_until([&] { return c->ctl->magic.load(std::memory_order_acquire) == MAGIC; }, "rank 0 to initialise the control block");
-            if (c->ctl->nranks != (uint32_t)nranks) c->die("the ranks disagree about the size of the job");
+            while (true) {
+                if (now_s() - t_attach > c->timeout) return fail("timed out waiting for rank 0 to create " + c->base);
+                timespec ts{0, 2000000};
+                int cfd = shm_open(c->base.c_str(), O_RDWR, 0600);
+                struct stat st;
+                if (cfd < 0 || fstat(cfd, &st) != 0 || (size_t)st.st_size < sizeof(Ctl)) {
+                    if (cfd >= 0) close(cfd);
+                    nanosleep(&ts, nullptr);
+                    continue;
+                }
+                Ctl *m = map_ctl(cfd);
+                if (!m) return fail("mmap of the control block failed");
+                // this block's rank 0 either opens the gate or (a leftover) some rank 0 marks it failed
+                bool counted = false, stale = false;
+                while (true) {
+                    if (m->failed.load(std::memory_order_acquire)) { stale = true; break; }
+                    if (m->magic.load(std::memory_order_acquire) == MAGIC) {
+                        if (m->nranks != (uint32_t)nranks) { munmap(m, sizeof(Ctl)); return fail("shared-memory communicator: the ranks disagree about the size of the job"); }
+                        if (!counted) { m->attached.fetch_add(1, std::memory_order_acq_rel); counted = true; }
+                        if (m->go.load(std::memory_order_acquire)) break;
+                    }
+                    if (now_s() - t_attach > c->timeout) { munmap(m, sizeof(Ctl)); return fail("timed out waiting for rank 0 to initialise " + c->base); }
+                    nanosleep(&ts, nullptr);
+                }
+                if (!stale) { c->ctl = m; break; }
+                munmap(m, sizeof(Ctl));                  // a leftover of an earlier job: open the name again
+                nanosleep(&ts, nullptr);
+            }
         }
         // ---- data segments: everyone creates its own, then opens the others' ----
         const std::string mine = c->base + "." + std::to_string(rank);

@@ -1781,9 +1781,16 @@ static int calibrate_chain() {
     NCCLCHK(ncclAllReduce(g.dscalar, g.dscalar, 1, ncclDouble, ncclMax, g.comm, g.cs));
     HIPCHK(hipMemcpyAsync(&us, g.dscalar, sizeof(double), hipMemcpyDeviceToHost, g.cs));
     HIPCHK(hipStreamSynchronize(g.cs));
+    // The agglomeration rules compare this number with thresholds (T1 <= chain, chain > 2 T1 / active): a 20-rep event timing
+    // moves by a microsecond or two from run to run, and near a threshold that would move a coarse level between ranks -- and with
+    // it the order of its reductions (round-3 advisor finding).  The model therefore sees the measurement on a coarse grid, steps
+    // of sqrt(2) around the 23 us constant (16.3, 23, 32.5, 46, ...): a run-to-run wobble stays inside a step except at its edges,
+    // and SAENA_SHRINK_CHAIN_US pins it for tests and benches that depend on where a level lives.
+    const double raw = us;
+    us = 23.0 * std::exp2(std::round(2.0 * std::log2(std::max(us, 1.0) / 23.0)) / 2.0);
     g.chain_us = us;
     saena_host::g_measured_chain_us = us;
-    if (std::getenv("SAENA_SETUP_TIMING") && g.rank == 0) fprintf(stderr, "[sgpu] exchange chain on this communicator: %.1f us (pack -> send/recv of %d doubles with rank %d -> rows, + 9 us of fork / join)\n", us, n, peer);
+    if (std::getenv("SAENA_SETUP_TIMING") && g.rank == 0) fprintf(stderr, "[sgpu] exchange chain on this communicator: %.1f us measured (pack -> send/recv of %d doubles with rank %d -> rows, + 9 us of fork / join), %.1f us in the agglomeration model\n", raw, n, peer, us);
     return SGPU_OK;
 }
 
@@ -1842,7 +1849,7 @@ int sgpu_init(int device_id, int rank, int nranks, const void *uid) {
     sgpu_install_spgemm_hook(1);         // the AMG setup's Galerkin products run on this device from now on (sgpu_spgemm.hip)
     if (g.comm && !std::getenv("SAENA_NO_CHAIN_CALIBRATION")) {
         const int s = calibrate_chain();
-        if (s != SGPU_OK) { g.live = false; return s; }
+        if (s != SGPU_OK) { sgpu_finalize(); return s; }      // streams, buffers and the communicator go with the failed context (the error text stays)
     }
     return SGPU_OK;
 }
@@ -2115,9 +2122,12 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
     return SGPU_OK;
 }
 
+// the kernel forms, by number: ONE table, whose length is what set_variant, the plan cache's lookup and its store accept
+static const char *const VARIANT_NAMES[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx", "k_rowt", "k_sellp2", "k_sellpx"};   // (3, 4, 7, 8 are named with their slot/offset split below)
+static constexpr int MAX_VARIANT = (int)(sizeof VARIANT_NAMES / sizeof VARIANT_NAMES[0]) - 1;
+
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    static const char *names[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx", "k_rowt", "k_sellp2", "k_sellpx"};   // (3, 4, 7, 8 are named with their slot/offset split below)
     if (variant) *variant = op->loc.variant;
     if (kernel_name) {
         const int v = op->loc.variant;
@@ -2128,7 +2138,7 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
             const_cast<sgpu_op *>(op)->vname = buf;
             *kernel_name = op->vname.c_str();
         } else {
-            *kernel_name = (v == 11 && op->loc.sp_wide) ? "k_sellp<wide>" : (v == 14 && op->loc.sp_wide) ? "k_sellp2<wide>" : names[v];      // the compact table around 1024 threads
+            *kernel_name = (v == 11 && op->loc.sp_wide) ? "k_sellp<wide>" : (v == 14 && op->loc.sp_wide) ? "k_sellp2<wide>" : VARIANT_NAMES[v];      // the compact table around 1024 threads
         }
     }
     return SGPU_OK;
@@ -2136,7 +2146,7 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
 
 int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
-    if (variant < 0 || variant > 15) return fail(SGPU_ERR_ARG, "variant must be 0..15");
+    if (variant < 0 || variant > MAX_VARIANT) return fail(SGPU_ERR_ARG, "variant must be 0..%d", MAX_VARIANT);
     if (variant == 15) {
         CHK(build_sell(op->loc, op->h_val_all));
         CHK(build_sellp(op->loc));
@@ -2257,7 +2267,7 @@ bool plan_cache_lookup(uint64_t key, int *v, int *lanes) {
     bool hit = false;
     while (fgets(line, sizeof line, f)) {               // the last line of a key wins
         unsigned long long k; int vv, ll;
-        if (sscanf(line, "%llx %d %d", &k, &vv, &ll) == 3 && k == key && vv >= 0 && vv <= 14 && ll >= 1 && ll <= 64) { *v = vv; *lanes = ll; hit = true; }
+        if (sscanf(line, "%llx %d %d", &k, &vv, &ll) == 3 && k == key && vv >= 0 && vv <= MAX_VARIANT && ll >= 1 && ll <= 64) { *v = vv; *lanes = ll; hit = true; }
     }
     fclose(f);
     return hit;

@@ -493,7 +493,7 @@ int gpu_spgemm(int a_rows, int b_rows, int b_cols, const long *a_ptr, const int 
             for (int i = r0; i < r1; ++i) p0 += prod[(size_t)i];
             if (p0 > 0) {
                 const double est = 1.15 * (double)out_n / (double)p0 * (double)products_total;
-                if (est < 3.0e9) { c_col.reserve((size_t)est); c_val.reserve((size_t)est); }
+                if (est < 3.0e9) { saena_host::LazyBigalloc lazy; c_col.reserve((size_t)est); c_val.reserve((size_t)est); }   // an estimate: advised, not touched
             }
         }
         c_col.resize(base + (size_t)out_n);

@@ -78,7 +78,8 @@ def test_config1_poisson128_pcg_reproduces_the_reference_line(capi):
     A = host.Matrix(host.Comm("gpu", "rccl")).laplacian3D(128).assemble()
     S = host.AmgSolver(A, host.options(L, **host.OPTIONS001)).to_device()
     rows = [S.level_info(l)["rows"] for l in range(S.num_levels)]
-    assert rows == [2000376, 1000188, 92501, 13633, 2569, 715, 228, 48]
+    pin = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hierarchy_integers.json")))["poisson128"]      # the reference's printed integers
+    assert rows == pin["rows"] and [S.level_info(l)["nnzA"] for l in range(S.num_levels)] == pin["nnz"]
     u, it, hist, ok = S.solve_pCG(A.laplacian3D_rhs())
     assert ok and it == 9
     assert f"{hist[0]:.6e}" == "5.992963e+04" and f"{hist[-1]:.6e}" == "5.355578e-05"
@@ -92,6 +93,8 @@ def test_config2_poisson256_full_vcycle_pipeline(capi):
     assert M == 254 ** 3 and A.nnz == 7 * 254 ** 3 - 6 * 254 ** 2
     S = host.AmgSolver(A, host.options(L, **host.OPTIONS001)).to_device()
     assert S.num_levels == 10 and S.level_info(1)["rows"] == 8193532
+    pin = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hierarchy_integers.json")))["poisson256"]      # every level, rows and entries
+    assert [S.level_info(l)["rows"] for l in range(10)] == pin["rows"] and [S.level_info(l)["nnzA"] for l in range(10)] == pin["nnz"]
     rhs = A.laplacian3D_rhs()
     u, it, hist, ok = S.solve_pCG(rhs)
     assert ok and it == 9

@@ -941,6 +941,37 @@ def test_plan_cache_makes_a_second_operator_take_the_first_one_s_plan(capi, tmp_
     np.testing.assert_array_equal(y1.download(), A.matvec(x))
 
 
+def test_plan_cache_honours_every_variant_the_autotune_can_store(capi, tmp_path, monkeypatch):
+    """Round-3 advisor finding: the lookup accepted variants 0..14 while the autotune can pick and store 15 (k_sellpx), so a cached
+    k_sellpx line was never honoured and every process tuned again and appended another line.  Lookup, store and set_variant
+    now share one bound (MAX_VARIANT): a cached line naming the highest variant is taken without a sweep and without a new line."""
+    cache = tmp_path / "plans.tsv"
+    monkeypatch.setenv("SAENA_PLAN_CACHE", str(cache))
+    M = 16384
+    entries = orc.band_matrix(M, 63)                        # ~1 M entries, 63 per row: the row-pattern forms apply, k_sellpx included
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    G1 = util.gpu_operator(A)
+    G1.autotune()
+    lines = cache.read_text().strip().splitlines()
+    assert len(lines) == 1
+    f = lines[0].split("\t")
+    f[1] = "15"                                              # what an autotune that picked k_sellpx writes
+    cache.write_text("\t".join(f) + "\n")
+    G2 = util.gpu_operator(A)
+    G2.autotune()
+    assert G2.variant() == (15, "k_sellpx"), G2.variant()
+    assert len(cache.read_text().strip().splitlines()) == 1, "a cached k_sellpx plan must be taken, not tuned again"
+    x = inputs.v2(M)
+    dx, dy = capi.DeviceVector(M, x), capi.DeviceVector(M)
+    G2.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), A.matvec(x))         # sequential row sum: the oracle's bit for bit
+    f[1] = "16"                                              # beyond the table: ignored (tuned afresh, one more line)
+    cache.write_text("\t".join(f) + "\n")
+    G3 = util.gpu_operator(A)
+    G3.autotune()
+    assert G3.variant()[0] <= 15 and len(cache.read_text().strip().splitlines()) == 2
+
+
 def test_wave_streamed_kernel_keeps_a_nan_in_the_rows_that_own_it(capi):
     """k_csr_wave reads whole 16-byte quads, so the first and last quad of a row carry entries of its neighbours: those
     are dropped with BOTH factors zeroed -- a NaN in x at a column only the neighbouring row owns must not reach this row."""

@@ -125,7 +125,10 @@ def test_bench_two_ranks_at_the_full_per_rank_size_of_configs3():
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-3000:]
     o = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][-1])["vcycle"]
     assert o["rows"] == w["rows"] and o["nnz"] == w["nnz"], "the row-distributed hierarchy must be the one-rank hierarchy"
+    pin = json.load(open(os.path.join(ROOT, "tests", "golden", "hierarchy_integers.json")))["poisson323"]
+    assert w["rows"] == pin["rows"] and w["nnz"] == pin["nnz"], "the 323^3 hierarchy moved: rows / entries per level differ from the committed integers"
     h1, h2 = o["residual_history"], w["residual_history"]
     assert len(h1) == len(h2) == 10
     for a, b in zip(h1, h2):
         assert abs(a - b) <= 1e-10 * h1[0], (h1, h2)
+        assert abs(a - b) <= 1e-6 * a, (h1, h2)          # and relative to each entry itself: the tail of the history is pinned too
