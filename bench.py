@@ -54,6 +54,8 @@ def parse():
                     "--gpus 1 (BASELINE configs[1]) and 512 at --gpus N>1 (configs[3] at N=8; at N=2/4 the cube with the same rows per GPU)")
     ap.add_argument("--hbm-m", "--m-hbm", dest="m_hbm", type=int, default=256, help="grid of the secondary HBM-resident SpMV figure at --gpus 1 (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--irregular-blocks", type=int, default=200, help="--gpus 1: diagonal blocks of the configs[4] operator (SiH4 replicated with per-block "
+                    "permutations, coupling and hub rows: tests/irregular.py; 200 -> 1 008 200 rows, 34.7 M entries; 0 = skip)")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
     ap.add_argument("--vcycle-timeout", type=float, default=480.0, help="watchdog of the multi-rank V-cycle legs, seconds")
     ap.add_argument("--config4-vcycle", action="store_true", help="(the default since round 3; kept for old command lines)")
@@ -63,6 +65,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the cpu_baseline sample")
     ap.add_argument("--spmv-timeout", type=float, default=300.0, help="N>1: watchdog of the SpMV measurement itself, seconds")
     ap.add_argument("--assemble-timeout", type=float, default=300.0, help="N>1: watchdog of the rendezvous + assemble phase before it, seconds")
+    ap.add_argument("--no-balanced", action="store_true",
+                    help="N>1: skip the second SpMV measurement (and the second 128^3 leg) under the opt-in finer row partition (`value_balanced`)")
+    ap.add_argument("--balanced-buckets", type=int, default=4096, help="N>1: row buckets of the opt-in finer partition (the reference uses nparts^2)")
     return ap.parse_args()
 
 
@@ -160,6 +165,8 @@ def vcycle_leg(capi, host, A, m, dist=None, check_residual=False):
     t_v = (time.perf_counter() - t0) / n
     levels = [S.level_info(l) for l in range(S.num_levels)]
     crit = {}
+    if dist is not None:      # where the levels live: ranks that own rows of each level (all of them -> every k-th -> rank 0: the agglomeration)
+        crit["ranks_per_level"] = [int(np.count_nonzero(np.diff(S.level_split(l)) > 0)) for l in range(S.num_levels)]
     if check_residual:
         # the criterion that needs no CPU reference at this size: ||A u - rhs|| of the returned iterate, formed ON THE HOST
         # from this rank's layout arrays (halo values of u fetched from their owners over the rendezvous group), against
@@ -177,7 +184,8 @@ def vcycle_leg(capi, host, A, m, dist=None, check_residual=False):
             "vcycles_per_s": round(1.0 / t_v, 2), "vcycle_ms": round(t_v * 1e3, 4),
             "initial_residual": float(hh[0]), "final_residual": float(hh[-1]), "relative_residual": float(hh[-1] / hh[0]),
             "residual_history": [float(x) for x in hh],
-            "options": "data/options001.xml values: jacobi 3+3, tol 1e-8, conn_str 0.2", "host_setup_s": round(t_setup, 2)}
+            "options": "data/options001.xml values: jacobi 3+3, tol 1e-8, conn_str 0.2", "host_setup_s": round(t_setup, 2),
+            "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 2 ** 20, 2)}
 
 
 def host_residual_sq(np, host, A, u, rhs, dist):
@@ -235,18 +243,31 @@ def verify_spmv(np, host, A, op, x, y, g0):
     return err, int(M)
 
 
+# committed rocprofv3 --pmc passes of this command, by operator size and kernel FAMILY (most specific first): a kernel the passes did
+# not profile falls back to its family's file and the line says which kernel the counters belong to (round-3 review: a third pick of
+# the autotune must not drop `traffic` silently)
+PMC_FILES = {
+    128: [("k_sellp2", "r03_pmc_spmv_128_sellp2.json"), ("k_sellp", "r03_pmc_spmv_128_sellp.json"), ("k_sell", "r02_pmc_spmv_128_sell.json"),
+          ("k_csr_cc16", "r02_pmc_spmv_128_cc16.json"), ("k_csr_stream", "r01_pmc_spmv_128.json")],
+    256: [("k_sellp2", "r03_pmc_spmv_256_sellp2.json"), ("k_sellp", "r03_pmc_spmv_256_sellp.json"), ("k_csr_cc16", "r02_pmc_spmv_256_cc16.json")],
+}
+
+
 def pmc_traffic(m, world, kernel_name):
     """Memory-side bytes per launch from the COMMITTED rocprofv3 PMC passes of this same command (PMC counters cannot
     be read from inside the process, so this is never a measurement of the present run: the line says so with
-    `traffic_measured_in_run: false`).  Only for the kernel those passes profiled; None for anything else."""
-    table = {"k_sellp": "r03_pmc_spmv_128_sellp.json", "k_sellp2": "r03_pmc_spmv_128_sellp2.json", "k_sell": "r02_pmc_spmv_128_sell.json", "k_csr_cc16<16KiB,4+12>": "r02_pmc_spmv_128_cc16.json",
-             "k_csr_stream<16KiB>": "r01_pmc_spmv_128.json"}
-    name = table.get(kernel_name)
-    path = os.path.join(ROOT, "profiles", name) if name else None
-    if m == 128 and world == 1 and path and os.path.exists(path):
-        with open(path) as f:
-            return json.load(f)["traffic_bytes_per_launch"], "profiles/" + name
-    return None, None
+    `traffic_measured_in_run: false`).  -> (bytes, file, kernel the passes profiled) or (None, None, None)."""
+    if world != 1:
+        return None, None, None
+    fams = PMC_FILES.get(m, [])
+    # the kernel's own family first, then (same stored bytes) its nearest relative: k_sellp2 <-> k_sellp
+    order = [f for f in fams if kernel_name.startswith(f[0])] + [f for f in fams if kernel_name.startswith("k_sellp") and f[0].startswith("k_sellp")]
+    for fam, name in order:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f)["traffic_bytes_per_launch"], "profiles/" + name, fam
+    return None, None, None
 
 
 import contextlib
@@ -306,16 +327,126 @@ def measure_spmv(capi, host, np, A, rank, steps, warmup, sync_all):
 def stored_bytes(info, kernel_name):
     """bytes the SpMV's operands occupy in HBM: values, column ids as the chosen kernel stores them, row pointers, x, y"""
     nnz = info["nnz_local"] + info["nnz_remote"]
-    if kernel_name in ("k_sellp", "k_sellp2"):           # no column stream: a 16-bit pattern id per row (+ a table of a few hundred ints)
-        return 8 * nnz + 2 * info["M"] + 8 * info["N_local"] + 8 * info["M"]
-    if kernel_name == "k_sell":                          # 16-bit column codes, a 16-bit row length instead of the row pointer (padding < 1 % here)
-        return 10 * nnz + 2 * info["M"] + 8 * info["N_local"] + 8 * info["M"]
+    vec = 8 * info["N_local"] + 8 * info["M"]
+    if kernel_name == "k_rowt":                          # (opt-in) a 16-bit template id per row, nothing per entry
+        return 2 * info["M"] + vec
+    if kernel_name.startswith("k_sellp"):                # k_sellp, k_sellp2, their <wide> forms, k_sellpx: no column stream, a 16-bit pattern id per row
+        return 8 * nnz + 2 * info["M"] + vec             # (+ a table of a few hundred ints / a few KiB per workgroup)
+    if kernel_name in ("k_sell", "k_sellx", "k_csr_xlds"):   # 16-bit column codes; k_sell: a 16-bit row length instead of the row pointer (padding < 1 % here)
+        return 10 * nnz + (2 if kernel_name == "k_sell" else 4) * info["M"] + vec
+    if kernel_name == "k_dense_rows":
+        return 8 * info["M"] * info["N_local"] + vec
     col_bytes = 2 if ("cc16" in kernel_name or "k_csr_cm" in kernel_name) else 4
     extra = 2 if "k_csr_cm" in kernel_name else 0       # k_csr_cm: + a 16-bit tile slot per entry
-    return (8 + col_bytes + extra) * nnz + 4 * (info["M"] + 1) + 8 * info["N_local"] + 8 * info["M"]
+    return (8 + col_bytes + extra) * nnz + 4 * (info["M"] + 1) + vec
 
 
 INFINITY_CACHE_BYTES = 256 * 2 ** 20                    # MI355X: 256 MiB memory-side cache (MI355X_MICROARCH.md)
+
+
+def irregular_leg(capi, host, np, comm, nblocks, sync_all):
+    """BASELINE.json configs[4] ("SuiteSparse/Florida matrix ... irregular nnz/row, stresses load-balance of wavefront CSR") at a size
+    where it is bound by the memory system: the reference's SiH4 (data/FloridaCollection, 5 041 rows -- 4 us of launch floor on this
+    chip) replicated to >= 1 M rows with per-block permutations, coupling between blocks and hub rows (tests/irregular.py).  SpMV and
+    Jacobi sweep through the same entry points, kernel from the plan-time autotune, one more SpMV checked against the host product."""
+    from tests import irregular
+    t0 = time.perf_counter()
+    r, c, v, M = irregular.sih4_replicated(nblocks)
+    lens = irregular.row_length_stats(r, M)
+    Ai = host.Matrix(comm)
+    Ai.set_remove_boundary(False)
+    Ai.set_many(r, c, v)
+    del r, c, v
+    Ai.assemble()
+    t_build = time.perf_counter() - t0
+    op = host.device_operator(Ai)
+    plan = op.block_plan(0)                              # before the autotune frees the host copies it does not need
+    if os.environ.get("SAENA_BENCH_VARIANT_IRREGULAR"):
+        op.set_variant(int(os.environ["SAENA_BENCH_VARIANT_IRREGULAR"]))
+    else:
+        op.autotune()
+    info = op.info()
+    _, kname = op.variant()
+    x = capi.DeviceVector(M, np.sin(0.001 * np.arange(M)))
+    y, rhs = capi.DeviceVector(M), capi.DeviceVector(M, np.ones(M))
+    for _ in range(5):
+        op.spmv(x, y)
+    sync_all()
+    ms = op.time_kernel(0, x, None, y, 50)
+    ms_j = op.time_kernel(1, x, rhs, y, 50)
+    # check: one more SpMV against the host-formed product from the layout arrays
+    op.spmv(x, y)
+    got = y.download()
+    d = host.desc_arrays(Ai.desc())
+    rows = np.repeat(np.arange(M), d["nnzPerRow_local"])
+    t = d["val_local"] * np.sin(0.001 * d["col_local"].astype(np.float64))
+    want = np.bincount(rows, weights=t, minlength=M)
+    bound = float(np.bincount(rows, weights=np.abs(t), minlength=M).max())
+    err = float(np.max(np.abs(got - want)) / bound)
+    nnz = info["nnz_local"]
+    B, Bj = op.algorithmic_bytes(0), op.algorithmic_bytes(1)
+    ws = stored_bytes(info, kname)
+    rf = roofline_object(capi, info, kname, ms, B, B / (ms * 1e-3) / 1e9, ws, None, None, 20)
+    out = {"workload": f"SiH4 (reference data/FloridaCollection) x {nblocks} permuted diagonal blocks + coupling + hub rows: {M} rows x {nnz} nnz; BASELINE configs[4] scaled to an HBM-bound size",
+           "rows": M, "nnz": nnz, "row_lengths": lens,
+           "row_block_plan": {**plan, "mean_nnz_per_block": round(plan["nnz"] / max(1, plan["blocks"]), 1),
+                              "max_over_mean": round(plan["max_nnz_per_block"] * plan["blocks"] / max(1, plan["nnz"]), 3),
+                              "what": "the tile kernels' row blocks (<= 2048 products and <= 256 rows each; a longer row gets a block of its own): the "
+                                      "spread of work a workgroup gets -- blocks are dealt to the CUs dynamically, so the spread costs a tail, not a stall"},
+           **rf, "stored_bytes_per_nnz": round((ws - 16 * M) / nnz, 3),
+           "jacobi": {"us_per_sweep": round(ms_j * 1e3, 3), "achieved": round(Bj / (ms_j * 1e-3) / 1e9, 2), "frac": round(Bj / (ms_j * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unit": "GB/s"},
+           "check_max_rel_err": err, "check_ok": bool(err <= 1e-13), "build_s": round(t_build, 2)}
+    op.destroy()
+    for vec in (x, y, rhs):
+        vec.free()
+    Ai.free()
+    return out
+
+
+def roofline_object(capi, info, kernel_name, ms_kernel, B_alg, achieved, ws, traffic, traffic_src, reps, traffic_kernel=None):
+    """The contract's roofline object.  `achieved` = algorithmic bytes / kernel time.  What it is divided by depends on where the
+    working set lives (round-3 review: the spec-peak fraction of a cache-resident operator was 1.10 -- not an HBM fraction):
+      * beyond the 256 MiB Infinity Cache: bound "hbm", `peak` = the 8 TB/s spec peak, `frac` = achieved / peak (algorithmic bytes:
+        a form that stores 8 B per entry where the contract counts 12 can pass 1; `stored_frac` = the bytes actually stored / peak
+        cannot), plus `peak_measured` / `frac_of_measured` against the in-run streaming ceiling;
+      * inside it: bound "infinity_cache", `peak` = `peak_measured` (the in-run streaming ceiling of this byte mix, which the cache
+        serves as well), `frac` = `frac_of_measured` <= 1; the spec-peak ratio is kept as `frac_of_hbm_spec_peak` with a note."""
+    cache = bool(ws <= INFINITY_CACHE_BYTES)
+    lanes = 1 if kernel_name in ("k_sell", "k_sellp", "k_sellp<wide>", "k_sellpx") else 0.5 if kernel_name.startswith("k_sellp2") else info["lanes_per_row"]
+    mc = measured_ceiling(capi, info, kernel_name, ms_kernel, B_alg, reps)
+    o = {"bound": "infinity_cache" if cache else "hbm", "kernel": f"{kernel_name}, {lanes} lane(s)/row", "achieved": round(achieved, 2), "unit": "GB/s"}
+    if cache:
+        o.update(peak=mc["peak_measured"], frac=mc["frac_of_measured"], peak_hbm_spec=HBM_PEAK_GBS, frac_of_hbm_spec_peak=round(achieved / HBM_PEAK_GBS, 4),
+                 note="the operator and vectors fit the 256 MiB Infinity Cache: repeated launches are served by it, so the rate is not an HBM rate and "
+                      "`frac_of_hbm_spec_peak` may pass 1; `peak` is the streaming ceiling of the same stored bytes measured in this run (in the "
+                      "contract's algorithmic bytes), `frac` = time(ceiling) / time(kernel); see spmv_hbm_resident for the HBM-bound figure")
+    else:
+        o.update(peak=HBM_PEAK_GBS, frac=round(achieved / HBM_PEAK_GBS, 4), stored_frac=round(ws / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 note="working set beyond the 256 MiB Infinity Cache: HBM-bound; `frac` is in the contract's algorithmic bytes (12 B per entry: a form that "
+                      "stores fewer can pass 1), `stored_frac` in the bytes the chosen form stores, `frac_of_measured` against the in-run streaming ceiling")
+    o.update(mc)
+    o.update(us_per_launch=round(ms_kernel * 1e3, 3), algorithmic_bytes=B_alg, working_set_bytes=ws,
+             stored_bytes_rate_gbs=round(ws / (ms_kernel * 1e-3) / 1e9, 2), cache_resident=cache,
+             traffic=traffic, traffic_source=traffic_src, traffic_measured_in_run=False if traffic is not None else None)
+    if traffic is not None:
+        o["traffic_kernel"] = traffic_kernel             # the kernel the committed counter passes profiled (its family's, if not this one)
+    return o
+
+
+def measured_ceiling(capi, info, kernel_name, ms_kernel, B_alg, reps):
+    """What THIS device gives a kernel that moves the bytes the chosen form stores (values, its column / pattern ids, x once,
+    y once) with coalesced 16-byte loads and does nothing else -- sgpu_debug_stream_ceiling, timed in this process right after
+    the operator's own launches, the fastest of plain / non-temporal loads and stores.  `peak_measured` is that rate in the
+    contract's ALGORITHMIC bytes (so that achieved / peak_measured = time(ceiling) / time(kernel)), `frac_of_measured` <= 1 by
+    construction: the operator's kernel moves the same bytes and gathers on top."""
+    ws = stored_bytes(info, kernel_name)
+    wr = 8 * info["M"]
+    us, mode, moved = capi.stream_ceiling(ws - wr, wr, reps)
+    us_scaled = us * ws / moved                          # (the ceiling's read stream is rounded to whole 16-byte loads per row)
+    return {"peak_measured": round(B_alg / (us_scaled * 1e-6) / 1e9, 2), "frac_of_measured": round(us_scaled / (ms_kernel * 1e3), 4),
+            "ceiling": {"us_per_launch": round(us_scaled, 3), "form": mode, "bytes_moved": int(moved), "stored_bytes": int(ws),
+                        "stored_bytes_rate_gbs": round(ws / (us_scaled * 1e-6) / 1e9, 2),
+                        "what": "pure streaming kernel over the operator's stored byte mix (no gathers, no LDS), same process, back-to-back launches"}}
 
 
 def main():
@@ -374,23 +505,68 @@ def main():
     # (N > 1: a stall in the rendezvous or in the assemble's collectives must not look like a long run either)
     asm_dog = watchdog(args.assemble_timeout, "the rendezvous + assemble phase", 5) if world > 1 else None
     setup_comm = os.environ.get("SAENA_BENCH_SETUP_COMM", "shm")
+    comm_state = {"kind": setup_comm if world > 1 else "rccl", "note": None}
     if world > 1 and setup_comm == "shm":
-        # the job's ranks sit on one node (the launch contract): the setup's collectives are memory copies through the native
-        # shared-memory communicator (saena_amd/csrc/host/shm_comm.cpp); the name is fresh for every job
-        box = [f"{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}_{int(time.time() * 1e3) % 10 ** 9}" if rank == 0 else None]
+        # the shared-memory segments live in /dev/shm: a container's default is 64 MB while the exchanges of the configs[3] setup
+        # move gigabytes per rank (round-3 advisor finding) -- not enough room there means the gloo transport from the start
+        try:
+            st = os.statvfs("/dev/shm")
+            free = st.f_bavail * st.f_frsize
+        except OSError:
+            free = 0
+        need = world * (4 << 30)
+        box = [free if rank == 0 else None]                # one decision for the job: rank 0's view
         dist.broadcast_object_list(box, src=0)
-        comm = host.Comm("gpu", "shm", (box[0], rank, world))
-    elif world > 1 and setup_comm == "gloo":
-        comm = host.Comm("gpu", "dist", dist)
-    else:
-        comm = host.Comm("gpu", "rccl")
-    A = host.Matrix(comm)
+        if box[0] < need:
+            comm_state.update(kind="gloo", note=f"/dev/shm has {box[0] / 2 ** 30:.1f} GiB free, below the {need / 2 ** 30:.0f} GiB kept for {world} ranks: setup collectives over gloo")
+
+    def make_comm(kind):
+        if kind == "shm":
+            # the job's ranks sit on one node (the launch contract): the setup's collectives are memory copies through the native
+            # shared-memory communicator (saena_amd/csrc/host/shm_comm.cpp); the name is fresh for every job and every communicator
+            box = [f"{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}_{time.time_ns() % 10 ** 12}" if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            return host.Comm("gpu", "shm", (box[0], rank, world))
+        if kind == "gloo":
+            return host.Comm("gpu", "dist", dist)
+        return host.Comm("gpu", "rccl")
+
+    def with_shm_fallback(fn):
+        """fn(comm) -> result, collective.  A failure of the shared-memory communicator (no room in /dev/shm: reported by every
+        rank, the others through the failed flag) is not the end of the run: the ranks agree over the rendezvous group, switch
+        the setup's collectives to gloo and run fn again."""
+        err, res = None, None
+        try:
+            res = fn(comm_state["comm"])
+        except Exception as e:                              # noqa: BLE001
+            if comm_state["kind"] != "shm" or "shared-memory communicator" not in str(e):
+                raise
+            err = e
+        if world > 1 and comm_state["kind"] == "shm":
+            import torch
+            t = torch.tensor([1.0 if err is not None else 0.0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if float(t[0]) > 0:
+                comm_state.update(kind="gloo", note=f"shared-memory communicator failed ({err or 'on another rank'}): setup collectives over gloo")
+                print(f"bench.py rank {rank}: {comm_state['note']}", file=sys.stderr, flush=True)
+                comm_state["comm"] = make_comm("gloo")
+                res = fn(comm_state["comm"])
+        return res
+
+    comm_state["comm"] = make_comm(comm_state["kind"])
     if world == 1 or world == 8:
         mg = m
     else:                                                # the cube that gives every GPU the rows it holds at N = 8: (N/8)^(1/3) (m - 2) interior points per side
         mg = int(round((world / 8.0) ** (1.0 / 3.0) * (m - 2))) + 2
     grid = (mg, mg, mg)
-    A.laplacian3D(*grid).assemble()                      # reference partitioner: nnz-balanced contiguous row blocks
+
+    def build_fine(c, buckets=0):
+        Ax = host.Matrix(c)
+        if buckets:
+            Ax.set_partition_buckets(buckets)            # opt-in: NOT the reference's partition
+        return Ax.laplacian3D(*grid).assemble()
+    A = with_shm_fallback(build_fine)                    # reference partitioner: nnz-balanced contiguous row blocks
+    comm = comm_state["comm"]
     if asm_dog is not None:
         asm_dog.cancel()
     grid_s = f"{mg}^3"
@@ -420,29 +596,58 @@ def main():
     op, info, kernel_name, ms_kernel, wall, B_local = R["op"], R["info"], R["kernel_name"], R["ms_kernel"], R["wall"], R["B_local"]
 
     err, _ = verify_spmv(np, host, A, op, R["x"], R["y"], R["g0"])        # outside the timed region
-    B_total = B_local
-    rows_all, halo_all = [info["M"]], [info["nnz_remote"]]
-    if dist is not None:
+
+    def reduce_measurement(Rx, errx):
+        """-> (max error, max wall, total algorithmic bytes, rows per rank, remote nnz per rank, nnz per rank)"""
+        ix = Rx["info"]
+        nz = ix["nnz_local"] + ix["nnz_remote"]
+        if dist is None:
+            return errx, Rx["wall"], Rx["B_local"], [ix["M"]], [ix["nnz_remote"]], [nz]
         import torch
-        e = torch.tensor([err], dtype=torch.float64)
-        dist.all_reduce(e, op=dist.ReduceOp.MAX)
-        err = float(e[0])
-        t = torch.tensor([wall], dtype=torch.float64)
+        t = torch.tensor([errx, Rx["wall"]], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t[0])
-        b = torch.tensor([float(B_local)], dtype=torch.float64)
+        b = torch.tensor([float(Rx["B_local"])], dtype=torch.float64)
         dist.all_reduce(b)
-        B_total = float(b[0])
-        g = [None] * world
-        dist.all_gather_object(g, (info["M"], info["nnz_remote"]))
-        rows_all, halo_all = [x[0] for x in g], [x[1] for x in g]
+        gg = [None] * world
+        dist.all_gather_object(gg, (ix["M"], ix["nnz_remote"], nz))
+        return float(t[0]), float(t[1]), float(b[0]), [x[0] for x in gg], [x[1] for x in gg], [x[2] for x in gg]
+
+    def imbalance(rows, nnzs):
+        """what the slowest rank carries against the mean: `value` divides all ranks' bytes by the slowest rank's wall time, so a
+        weak-scaling efficiency cannot exceed mean / max before any exchange cost"""
+        mr, mn = sum(rows) / len(rows), sum(nnzs) / len(nnzs)
+        return {"rows_max_over_mean": round(max(rows) / mr, 4), "nnz_max_over_mean": round(max(nnzs) / mn, 4),
+                "efficiency_cap": round(mn / max(nnzs), 4)}
+    err, wall, B_total, rows_all, halo_all, nnz_all = reduce_measurement(R, err)
+
+    balanced = None
+    if world > 1 and not args.no_balanced:
+        # The reference's partitioner works on nparts^2 row buckets (src/saena_matrix_repart.cpp:43-170): a rank gets 7-9 of 64
+        # buckets at N = 8, 3-5 of 16 at N = 4.  The same SpMV measurement under the OPT-IN finer histogram
+        # (saena_matrix_set_partition_buckets): reported next to `value`, never instead of it.
+        bal_dog = watchdog(args.assemble_timeout + args.spmv_timeout, "the SpMV measurement under the finer partition", 4)
+        Ab = with_shm_fallback(lambda c: build_fine(c, args.balanced_buckets))
+        Rb = measure_spmv(capi, host, np, Ab, rank, args.steps, args.warmup, sync_all)
+        eb, _ = verify_spmv(np, host, Ab, Rb["op"], Rb["x"], Rb["y"], Rb["g0"])
+        eb, wb, Bb, rows_b, halo_b, nnz_b = reduce_measurement(Rb, eb)
+        bal_dog.cancel()
+        balanced = {"what": f"the same measurement with at least {args.balanced_buckets} row buckets in the nnz-balanced partitioner instead of the "
+                            f"reference's nparts^2 = {world * world} (opt-in: saena_matrix_set_partition_buckets / SAENA_FINE_PARTITION_BUCKETS)",
+                    "value": round(Bb / (wb / args.steps) / 1e9, 2), "unit": "GB/s", "ms_per_step": round(wb / args.steps * 1e3, 6),
+                    "kernel": Rb["kernel_name"], "us_per_launch_rank0": round(Rb["ms_kernel"] * 1e3, 3), "rows_per_gpu": rows_b,
+                    "partition_imbalance": imbalance(rows_b, nnz_b), "check_max_rel_err": eb, "check_ok": bool(eb <= 1e-13)}
+        Rb["op"].destroy()
+        for k in ("x", "y"):
+            Rb[k].free()
+        Ab.free()
+        del Rb, Ab
 
     out = None
     if rank == 0:
         sec_per_step = wall / args.steps
         achieved = B_local / (ms_kernel * 1e-3) / 1e9
         ws = stored_bytes(info, kernel_name)
-        traffic, traffic_src = pmc_traffic(m, world, kernel_name)
+        traffic, traffic_src, traffic_kernel = pmc_traffic(m, world, kernel_name)
         out = {
             "metric": f"fine-level SpMV effective GB/s (3D 7-pt Poisson {grid_s}, fp64)",
             "value": round(B_total / sec_per_step / 1e9, 2),
@@ -465,6 +670,11 @@ def main():
                                 f" weak-scaled to {world} GPUs: the cube with the same {(m - 2) ** 3 // 8} rows per GPU")
                                 if world > 1 else "")),
                 "rows_per_gpu": rows_all, "nnz_per_gpu": info["nnz_local"] + info["nnz_remote"],
+                **({"partition_imbalance": {**imbalance(rows_all, nnz_all),
+                                            "note": f"the reference's partitioner splits at multiples of 1/{world * world} of the rows (nparts^2 buckets); "
+                                                    "`value` = all ranks' bytes / the slowest rank's time, so this caps the weak-scaling efficiency; "
+                                                    "`value_balanced` is the same measurement under the opt-in finer histogram"},
+                    "setup_comm": comm_state["kind"] + (f" ({comm_state['note']})" if comm_state["note"] else "")} if world > 1 else {}),
                 "partition": "1 rank" if world == 1 else
                              f"{world} nnz-balanced contiguous row blocks (reference partitioner), RCCL halo of ~{grid[0] - 2}^2 doubles per side "
                              f"(remote nnz per rank {halo_all})",
@@ -474,20 +684,11 @@ def main():
                                               "Infinity-Cache-resident configs[1] operator (8.1 TB/s) and not the denominator of a weak-scaling ratio"}
                    if world > 1 else {}),
             },
+            **({"value_balanced": balanced["value"], "balanced_partition": balanced} if balanced else {}),
             "check": {"what": "y = A x of one more SpMV against the host-formed product from the layout arrays, halo values included; "
                               "max over all ranks of max_i |y_gpu - y_host| / max_i sum_j |a_ij x_j|",
                       "max_rel_err": err, "ok": bool(err <= 1e-13)},
-            "roofline": {
-                "bound": "hbm", "kernel": f"{kernel_name}, {1 if kernel_name in ('k_sell', 'k_sellp') else 0.5 if kernel_name == 'k_sellp2' else info['lanes_per_row']} lane(s)/row",
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "us_per_launch": round(ms_kernel * 1e3, 3), "algorithmic_bytes": B_local,
-                "working_set_bytes": ws, "stored_bytes_rate_gbs": round(ws / (ms_kernel * 1e-3) / 1e9, 2), "cache_resident": bool(ws <= INFINITY_CACHE_BYTES),
-                "note": ("the operator and vectors fit the 256 MiB Infinity Cache: repeated launches are served by it, so `achieved` "
-                         "can exceed what HBM alone sustains (~6.1 TB/s reads); see spmv_hbm_resident for the HBM-bound figure"
-                         if ws <= INFINITY_CACHE_BYTES else "working set beyond the 256 MiB Infinity Cache: HBM-bound"),
-                "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False if traffic is not None else None,
-            },
+            "roofline": roofline_object(capi, info, kernel_name, ms_kernel, B_local, achieved, ws, traffic, traffic_src, max(20, args.steps // 4), traffic_kernel),
         }
     # free the big operator's vectors before the legs allocate theirs
     if world == 1 and not multi and args.m_hbm and args.m_hbm != m:
@@ -500,26 +701,21 @@ def main():
         e3, _ = verify_spmv(np, host, A3, R3["op"], R3["x"], R3["y"], 0)
         a3 = R3["B_local"] / (R3["ms_kernel"] * 1e-3) / 1e9
         ws3 = stored_bytes(R3["info"], R3["kernel_name"])
-        out["spmv_hbm_resident"] = {
-            "workload": f"Poisson {args.m_hbm}^3: {R3['info']['M']} rows x {R3['info']['nnz_local']} nnz, same kernel path",
-            "kernel": f"{R3['kernel_name']}, {1 if R3['kernel_name'] in ('k_sell', 'k_sellp') else 0.5 if R3['kernel_name'] == 'k_sellp2' else R3['info']['lanes_per_row']} lane(s)/row", "steps": steps3, "warmup": warm3,
-            "us_per_launch": round(R3["ms_kernel"] * 1e3, 3), "algorithmic_bytes": R3["B_local"], "working_set_bytes": ws3,
-            "stored_bytes_rate_gbs": round(ws3 / (R3["ms_kernel"] * 1e-3) / 1e9, 2),
-            "cache_resident": bool(ws3 <= INFINITY_CACHE_BYTES), "achieved": round(a3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(a3 / HBM_PEAK_GBS, 4), "check_max_rel_err": e3,
-        }
-        # bytes leaving the L2 per launch from the COMMITTED PMC passes of this leg (tools/pmc_spmv_hbm.sh), same kernel only
-        pmc_name = {"k_sellp": "r03_pmc_spmv_256_sellp.json", "k_sellp2": "r03_pmc_spmv_256_sellp2.json"}.get(R3["kernel_name"], "r02_pmc_spmv_256_cc16.json" if "k_csr_cc16" in R3["kernel_name"] else None)
-        pmc3 = os.path.join(ROOT, "profiles", pmc_name) if pmc_name else None
-        if args.m_hbm == 256 and pmc3 and os.path.exists(pmc3):
-            with open(pmc3) as f:
-                out["spmv_hbm_resident"].update(traffic=json.load(f)["traffic_bytes_per_launch"], traffic_source="profiles/" + pmc_name,
-                                                traffic_measured_in_run=False)
+        rf3 = roofline_object(capi, R3["info"], R3["kernel_name"], R3["ms_kernel"], R3["B_local"], a3, ws3, None, None, 20)
+        out["spmv_hbm_resident"] = {"workload": f"Poisson {args.m_hbm}^3: {R3['info']['M']} rows x {R3['info']['nnz_local']} nnz, same kernel path",
+                                    "steps": steps3, "warmup": warm3, **rf3, "check_max_rel_err": e3}
+        # bytes leaving the L2 per launch from the COMMITTED PMC passes of this leg (tools/pmc_spmv_hbm.sh), by kernel family
+        t3, src3, k3 = pmc_traffic(args.m_hbm, world, R3["kernel_name"])
+        if t3 is not None:
+            out["spmv_hbm_resident"].update(traffic=t3, traffic_source=src3, traffic_measured_in_run=False, traffic_kernel=k3)
         R3["op"].destroy()
         for k in ("x", "y"):
             R3[k].free()
         A3.free()
         del R3, A3
+
+    if world == 1 and not multi and args.irregular_blocks:
+        out["spmv_irregular"] = irregular_leg(capi, host, np, comm, args.irregular_blocks, sync_all)
 
     if rank == 0:
         if world == 1 and not multi and not args.no_vcycle:
@@ -559,25 +755,55 @@ def main():
         try:
             # (1) parity: the SAME global Poisson 128^3 problem as at N=1 (strong scaling), row blocks from the reference's
             #     nnz-balanced partitioner -- the residuals are comparable with the reference's printed digits
-            A2 = host.Matrix(comm)
-            A2.laplacian3D(128 if m >= 128 else m).assemble()
-            leg = vcycle_leg(capi, host, A2, m, dist)
-            leg["scaling"] = "strong"
-            leg["partition"] = f"{world} nnz-balanced row blocks of the global Poisson {128 if m >= 128 else m}^3 operator"
+            m128 = 128 if m >= 128 else m
+
+            def leg128(c, buckets=0):
+                A2 = host.Matrix(c)
+                if buckets:
+                    A2.set_partition_buckets(buckets)
+                A2.laplacian3D(m128).assemble()
+                lg = vcycle_leg(capi, host, A2, m, dist)
+                lg["scaling"] = "strong"
+                lg["rows_per_gpu"] = [int(x) for x in np.diff(A2.split)]
+                A2.free()
+                return lg
+            leg = with_shm_fallback(leg128)
+            leg["partition"] = f"{world} nnz-balanced row blocks of the global Poisson {m128}^3 operator (reference partitioner)"
             legs["vcycle"] = leg
-            A2.free()
+            if not args.no_balanced:
+                # the same solve under the opt-in finer partition: the residual history does not depend on the partition
+                # (every ||r_k|| within 1e-10 ||r_0|| of the reference-partition run, checked here and in tests/test_gpu_rccl.py)
+                capi.check(fatal(line("the 128^3 multi-rank V-cycle leg under the finer partition ended with a fatal signal").encode()))
+                lb = with_shm_fallback(lambda c: leg128(c, args.balanced_buckets))
+                lb["partition"] = f"{world} row blocks of the same operator from at least {args.balanced_buckets} buckets (opt-in)"
+                h1, h2 = leg["residual_history"], lb["residual_history"]
+                same = len(h1) == len(h2) and all(abs(a - b) <= 1e-10 * h1[0] for a, b in zip(h1, h2))
+                lb["history_matches_reference_partition"] = {"criterion": "same iteration count, every ||r_k|| within 1e-10 ||r_0||",
+                                                             "max_abs_diff_over_r0": (max(abs(a - b) for a, b in zip(h1, h2)) / h1[0]) if len(h1) == len(h2) else None,
+                                                             "ok": bool(same)}
+                legs["vcycle_balanced_partition"] = lb
+                if not same:
+                    raise RuntimeError("the 128^3 residual history under the finer partition differs from the reference-partition history")
             if args.no_config4_vcycle:
                 legs["vcycle_config4"] = {"skipped": "--no-config4-vcycle"}
             else:
                 capi.check(fatal(line("the configs[3] V-cycle leg ended with a fatal signal").encode()))
                 # (2) configs[3]: the operator of the SpMV measurement above (16.6 M rows per GPU at m = 512); every
                 #     rank builds only its rows of the hierarchy (row-distributed setup)
-                leg = vcycle_leg(capi, host, A, m, dist, check_residual=True)
+                fine = {"A": A, "comm": comm_state["comm"]}
+
+                def leg4(c):
+                    if fine["comm"] is not c:              # the setup's transport changed under us: the operator is tied to the old one
+                        fine.update(A=build_fine(c), comm=c)
+                    return vcycle_leg(capi, host, fine["A"], m, dist, check_residual=True)
+                leg = with_shm_fallback(leg4)
                 leg["scaling"] = "weak"
-                leg["partition"] = f"{world} nnz-balanced row blocks of Poisson {grid_s}"
+                leg["partition"] = f"{world} nnz-balanced row blocks of Poisson {grid_s} (reference partitioner)"
                 legs["vcycle_config4"] = leg
                 if not leg["residual_check"]["ok"]:
                     raise RuntimeError(f"configs[3] V-cycle leg: host-recomputed relative residual {leg['residual_check']['host_relative_residual']:.3e} > 2e-8")
+            if comm_state["note"] and rank == 0:
+                out["config"]["setup_comm"] = comm_state["kind"] + f" ({comm_state['note']})"
         except Exception as e:                              # noqa: BLE001 -- reported with the SpMV line, then a failing status
             dog.cancel()
             msg = f"{type(e).__name__}: {e}"

@@ -63,6 +63,8 @@ public:
     void set_eig(const std::string &opts_fname);   // reads the optional eig="..." attribute of the options XML
     void set_eig(double eig);
     void set_remove_boundary(bool remove_bound);
+    // NOT in the reference: resolution of assemble()'s nnz-balanced row partition (0 = the reference's nparts^2 buckets)
+    void set_partition_buckets(int n_buckets);
     bool add_dup = true;                           // if false replace the duplicate, otherwise add the values together
     int  add_duplicates(bool add);
 

@@ -56,6 +56,10 @@ int   saena_matrix_read_file(saena_matrix_h *A, const char *name, const char *in
 int   saena_matrix_write_bin(saena_matrix_h *A, const char *name);
 int   saena_matrix_write_mtx(saena_matrix_h *A, const char *name);   /* saena.hpp:53 writeMatrixToFile: "<name>-r<rank>.mtx" */
 int   saena_matrix_set_remove_boundary(saena_matrix_h *A, int remove_bound);                        /* :44 */
+/* resolution of the nnz-balanced row partition of assemble(): 0 = the reference's nparts^2 row buckets
+   (src/saena_matrix_repart.cpp:43-170; max / mean rows 1.25 at 4 ranks, 1.125 at 8 on a uniform operator), n > 0 = at least n
+   buckets -- opt-in, NOT the reference's partition (also: SAENA_FINE_PARTITION_BUCKETS) */
+int   saena_matrix_set_partition_buckets(saena_matrix_h *A, int n_buckets);
 int   saena_matrix_add_duplicates(saena_matrix_h *A, int add);                                      /* :47 */
 int   saena_matrix_set_eig(saena_matrix_h *A, double eig);                                          /* :38 (value form) */
 int   saena_matrix_assemble(saena_matrix_h *A);                                                     /* :49 */

@@ -10,6 +10,7 @@
 #define SAENA_GPU_DEBUG_H
 
 #include "saena_gpu.h"
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -27,6 +28,19 @@ int sgpu_debug_allow_local_only(sgpu_op *op, int allow);
 /* diagnostic: time of the x[col] gather alone over the local part, mode 0 = production lane mapping (4 consecutive
  * nnz per lane), 1 = 64 consecutive nnz per gather instruction */
 int sgpu_debug_gather_probe(sgpu_op *op, int mode, const value_t *x, int reps, float *ms);
+
+/* bench.py (configs[4], "stresses load-balance of wavefront CSR"): the spread of work over the row blocks of the tile kernels' plan
+ * (big = 0: 16 KiB tiles of <= 2048 products / 256 rows, 1: 32 KiB tiles).  out[0..7] = blocks, fewest / most entries in a block,
+ * entries in all, fewest / most rows in a block, rows longer than the tile (a block of their own: the long-row path), longest row. */
+int sgpu_debug_block_plan(const sgpu_op *op, int big, long *out);
+
+/* bench.py: the streaming ceiling of a byte mix on this device -- a kernel that reads `read_bytes` with wave-coalesced 16-byte
+ * loads and writes `write_bytes` with 8-byte stores and does nothing else (no gathers, no LDS), `reps` launches back to back after
+ * 3 warm-up launches, plain and non-temporal loads / stores: *us = the fastest of the four forms, *mode = which (bit 0: non-temporal
+ * loads, bit 1: non-temporal stores), *bytes_moved = the bytes one launch actually moves (the read stream is rounded to whole
+ * 16-byte loads per written double).  A sweep over an operator that stores those bytes cannot be faster: time(ceiling) /
+ * time(kernel) is `roofline.frac_of_measured`, <= 1 whether the working set is cache- or HBM-resident. */
+int sgpu_debug_stream_ceiling(size_t read_bytes, size_t write_bytes, int reps, float *us, int *mode, size_t *bytes_moved);
 
 /* Host-routed transport (validation without one GPU per rank): the context of rank `rank` of `nranks` is created
  * WITHOUT an RCCL communicator; every halo exchange is staged through host memory and handed to `exchange`, every

@@ -76,6 +76,8 @@ SYMBOLS = {
     "sgpu_prolong_correct": (C.c_int, [_VP, _VP, _VP]),
     "sgpu_debug_pack": (C.c_int, [_VP, _VP, _PD]),
     "sgpu_debug_gather_probe": (C.c_int, [_VP, C.c_int, _VP, C.c_int, C.POINTER(C.c_float)]),
+    "sgpu_debug_block_plan": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_long)]),
+    "sgpu_debug_stream_ceiling": (C.c_int, [C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "sgpu_debug_inject_halo": (C.c_int, [_VP, _PD]),
     "sgpu_spmv_host": (C.c_int, [_VP, _PD, _PD]),
     "sgpu_jacobi_host": (C.c_int, [_VP, C.c_int, C.c_double, _PD, _PD]),
@@ -308,6 +310,13 @@ class Operator:
     def set_lanes_per_row(self, lanes):
         check(lib().sgpu_op_set_lanes_per_row(self.h, int(lanes)))
 
+    def block_plan(self, big=0):
+        """spread of work over the row blocks of the tile kernels' plan (sgpu_debug_block_plan)"""
+        o = (C.c_long * 8)()
+        check(lib().sgpu_debug_block_plan(self.h, int(big), o))
+        k = ("blocks", "min_nnz_per_block", "max_nnz_per_block", "nnz", "min_rows_per_block", "max_rows_per_block", "long_rows", "longest_row")
+        return dict(zip(k, (int(x) for x in o)))
+
     def variant(self):
         v, name = C.c_int(), C.c_char_p()
         check(lib().sgpu_op_get_variant(self.h, C.byref(v), C.byref(name)))
@@ -450,6 +459,13 @@ class Amg:
                 self.destroy()
         except Exception:
             pass
+
+
+def stream_ceiling(read_bytes, write_bytes, reps=20):
+    """-> (microseconds, mode name, bytes moved) of the fastest pure streaming kernel over this byte mix (sgpu_debug_stream_ceiling)"""
+    us, mode, moved = C.c_float(), C.c_int(), C.c_size_t()
+    check(lib().sgpu_debug_stream_ceiling(int(read_bytes), int(write_bytes), int(reps), C.byref(us), C.byref(mode), C.byref(moved)))
+    return us.value, ("plain loads and stores", "non-temporal loads", "non-temporal stores", "non-temporal loads and stores")[mode.value], moved.value
 
 
 def device_info():

@@ -82,6 +82,7 @@ void matrix::set_eig(const std::string &fname) {          // saena.cpp:124-135: 
     if (e != 0.0) m_pImpl->set_eig(e);
 }
 void matrix::set_remove_boundary(bool b) { m_pImpl->remove_boundary = b; }
+void matrix::set_partition_buckets(int n) { m_pImpl->partition_buckets = n < 0 ? 0 : n; }
 int matrix::add_duplicates(bool add) { add_dup = add; m_pImpl->add_duplicates = add; return 0; }
 int matrix::assemble(bool scale, bool use_dense) {
     if (scale || use_dense) throw std::runtime_error("saena::matrix::assemble: scale/use_dense are not on the GPU path (defaults are false in the reference's drivers)");

@@ -109,6 +109,7 @@ int saena_matrix_read_file(saena_matrix_h *A, const char *name, const char *type
 int saena_matrix_write_bin(saena_matrix_h *A, const char *name) { return guard([&] { A->A.write_bin(name); }); }
 int saena_matrix_write_mtx(saena_matrix_h *A, const char *name) { return guard([&] { A->A.writeMatrixToFile(name); }); }
 int saena_matrix_set_remove_boundary(saena_matrix_h *A, int b) { A->A.remove_boundary = b != 0; return 0; }
+int saena_matrix_set_partition_buckets(saena_matrix_h *A, int n) { if (!A || n < 0) return -1; A->A.partition_buckets = n; return 0; }
 int saena_matrix_add_duplicates(saena_matrix_h *A, int add) { A->A.add_duplicates = add != 0; return 0; }
 int saena_matrix_set_eig(saena_matrix_h *A, double e) { A->A.set_eig(e); return 0; }
 int saena_matrix_assemble(saena_matrix_h *A) { return guard([&] { A->A.assemble(); }); }

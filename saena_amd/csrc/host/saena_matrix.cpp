@@ -348,13 +348,18 @@ std::vector<index_t> nnz_balanced_split(Comm &c, index_t Mbig, nnz_t nnz_g, int 
     return split;
 }
 
+int saena_matrix::default_partition_buckets() {
+    const char *e = std::getenv("SAENA_FINE_PARTITION_BUCKETS");
+    return e ? std::max(0, std::atoi(e)) : 0;
+}
+
 void saena_matrix::repartition_nnz_initial() {
     Comm &c = *comm;
     const int nprocs = c.nranks;
     split = nnz_balanced_split(c, Mbig, nnz_g, nprocs, [this](const std::vector<index_t> &firstSplit, std::vector<long> &H) {
         const int n_buckets = (int)H.size();
         for (const auto &e : entry) H[lower_bound2(firstSplit.data(), firstSplit.data() + n_buckets, e.row)]++;
-    });
+    }, partition_buckets);
     // move the entries to their owners (saena_matrix_repart.cpp:293 MPI_Alltoallv) and sort column-major
     entry = route(c, std::move(entry), split, [](const cooEntry &e) { return e.row; });
     sort_col_major(entry);

@@ -86,6 +86,13 @@ public:
     bool   add_duplicates = true;        // saena.hpp:47
     bool   remove_boundary = true;       // saena_matrix.h:101
     bool   assembled = false;
+    // Resolution of the nnz-balanced row partition (repartition_nnz_initial).  0 = the reference's nparts^2 row buckets
+    // (saena_matrix_repart.cpp:43-170: a part boundary can only sit at a multiple of Mbig / nparts^2 -- 7 to 9 of 64 buckets per
+    // rank at 8 ranks, 3 to 5 of 16 at 4: max / mean rows 1.125 and 1.25 on a uniform operator); n > 0 = at least n buckets
+    // (OPT-IN, not the reference's partition: SAENA_FINE_PARTITION_BUCKETS or saena_matrix_set_partition_buckets; the coarse
+    // operators have used 4096 since round 3, host/amg_setup.cpp).  Same algorithm, finer histogram.
+    int    partition_buckets = default_partition_buckets();
+    static int default_partition_buckets();
     // boundary bookkeeping (remove_boundary_nodes, saena_matrix_setup.cpp:281-365)
     std::vector<index_t> bound_row_global;   // ALL removed rows (global, sorted), same on every rank
     index_t Mbig_with_bound = 0;

@@ -1620,4 +1620,42 @@ __global__ __launch_bounds__(CG_BLOCK) void k_dense_solve(const double *__restri
     }
 }
 
+
+// ---- the streaming ceiling of a byte mix (bench.py's `roofline.peak_measured`) ----
+// What the memory system of THIS device gives a kernel that moves the same bytes as an operator's sweep and does nothing else:
+// per written double a wave-coalesced run of `q` 16-byte loads per lane (the value stream: 1 KiB per wave instruction) and one
+// 8-byte store.  No gathers, no index arithmetic, no LDS: a real SpMV cannot be faster than this on the same bytes, so
+// time(ceiling) / time(kernel) is a roofline fraction that is <= 1 by construction whether the working set sits in the
+// 256 MiB Infinity Cache or in HBM (the spec-peak fraction of a cache-resident operator is not: 1.10 in round 3).
+// MODE bit 0: non-temporal loads, bit 1: non-temporal stores -- the host keeps the fastest of the four.
+typedef double ceil_d2 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_stream_ceiling(const ceil_d2 *__restrict__ rd, double *__restrict__ wr, size_t n_w, int q) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_w) return;
+    const size_t wave = t >> 6;
+    const int lane = threadIdx.x & 63;
+    const ceil_d2 *p = rd + wave * 64 * (size_t)q + lane;
+    ceil_d2 a0 = {0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
+    int i = 0;
+    for (; i + 4 <= q; i += 4) {                         // four loads in flight per lane and trip, like the kernels' unrolled position loops
+        ceil_d2 v0, v1, v2, v3;
+        if constexpr (MODE & 1) {
+            v0 = __builtin_nontemporal_load(p + (size_t)i * 64); v1 = __builtin_nontemporal_load(p + (size_t)(i + 1) * 64);
+            v2 = __builtin_nontemporal_load(p + (size_t)(i + 2) * 64); v3 = __builtin_nontemporal_load(p + (size_t)(i + 3) * 64);
+        } else {
+            v0 = p[(size_t)i * 64]; v1 = p[(size_t)(i + 1) * 64]; v2 = p[(size_t)(i + 2) * 64]; v3 = p[(size_t)(i + 3) * 64];
+        }
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; i < q; ++i) {
+        if constexpr (MODE & 1) a0 += __builtin_nontemporal_load(p + (size_t)i * 64);
+        else a0 += p[(size_t)i * 64];
+    }
+    const ceil_d2 a = (a0 + a1) + (a2 + a3);
+    const double s = a.x + a.y;
+    if constexpr (MODE & 2) __builtin_nontemporal_store(s, wr + t);
+    else wr[t] = s;
+}
+
 } // namespace sk

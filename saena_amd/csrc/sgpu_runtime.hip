@@ -13,6 +13,7 @@
 #include "host/amg_setup.h"
 
 #include <hip/hip_runtime.h>
+#include <climits>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -2568,6 +2569,65 @@ int sgpu_debug_gather_probe(sgpu_op *op, int mode, const value_t *x, int reps, f
     HIPCHK(hipEventElapsedTime(ms, e0, e1));
     *ms /= reps;
     hipEventDestroy(e0); hipEventDestroy(e1);
+    return SGPU_OK;
+}
+
+int sgpu_debug_block_plan(const sgpu_op *op, int big, long *out) {
+    if (!op || !out) return fail(SGPU_ERR_ARG, "null argument");
+    const CsrPart &P = op->loc;
+    const std::vector<int> &blk = big ? P.h_blk_big : P.h_blk;
+    if (blk.size() < 2 || P.h_rp.empty()) return fail(SGPU_ERR_STATE, "the operator keeps no host copy of its row-block plan");
+    const int nb = (int)blk.size() - 1, cap = big ? sk::CAP_BIG : sk::CAP;
+    long mn = LONG_MAX, mx = 0, rmn = LONG_MAX, rmx = 0, longrows = 0, rowmax = 0;
+    for (int b = 0; b < nb; ++b) {
+        const long e = (long)P.h_rp[(size_t)blk[(size_t)b + 1]] - P.h_rp[(size_t)blk[(size_t)b]], r = blk[(size_t)b + 1] - blk[(size_t)b];
+        mn = std::min(mn, e); mx = std::max(mx, e); rmn = std::min(rmn, r); rmx = std::max(rmx, r);
+        if (r == 1 && e > cap) ++longrows;
+    }
+    for (int r = 0; r < P.nrows; ++r) rowmax = std::max(rowmax, (long)(P.h_rp[(size_t)r + 1] - P.h_rp[(size_t)r]));
+    out[0] = nb; out[1] = mn; out[2] = mx; out[3] = P.nnz; out[4] = rmn; out[5] = rmx; out[6] = longrows; out[7] = rowmax;
+    return SGPU_OK;
+}
+
+int sgpu_debug_stream_ceiling(size_t read_bytes, size_t write_bytes, int reps, float *us, int *mode, size_t *bytes_moved) {
+    CHK(need_ctx());
+    if (!us || reps < 1 || write_bytes < 8 * 64 || read_bytes < 16) return fail(SGPU_ERR_ARG, "bad argument");
+    const size_t n_w = write_bytes / 8;
+    const int q = (int)std::max<size_t>(1, (read_bytes + 8 * n_w) / (16 * n_w));       // 16-byte loads per written double, rounded
+    const size_t waves = (n_w + 63) / 64, n_r = waves * 64 * (size_t)q;                // (whole waves: every lane of the last wave has its run)
+    void *rd = nullptr; double *wr = nullptr;
+    HIPCHK(hipMalloc(&rd, n_r * 16));
+    if (hipMalloc(reinterpret_cast<void **>(&wr), n_w * 8) != hipSuccess) { hipFree(rd); return fail(SGPU_ERR_HIP, "hipMalloc of the ceiling's output failed"); }
+    struct Free { void *a, *b; hipEvent_t e0 = nullptr, e1 = nullptr; ~Free() { hipFree(a); hipFree(b); if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); } } fr{rd, wr};
+    HIPCHK(hipMemsetAsync(rd, 0, n_r * 16, g.cs));
+    HIPCHK(hipEventCreate(&fr.e0)); HIPCHK(hipEventCreate(&fr.e1));
+    const dim3 grid((unsigned)((n_w + sk::BLOCK - 1) / sk::BLOCK)), block(sk::BLOCK);
+    auto launch = [&](int m) {
+        const sk::ceil_d2 *r = static_cast<const sk::ceil_d2 *>(rd);
+        switch (m) {
+        case 0: SGPU_LAUNCH(sk::k_stream_ceiling<0>, grid, block, 0, g.cs, r, wr, n_w, q); break;
+        case 1: SGPU_LAUNCH(sk::k_stream_ceiling<1>, grid, block, 0, g.cs, r, wr, n_w, q); break;
+        case 2: SGPU_LAUNCH(sk::k_stream_ceiling<2>, grid, block, 0, g.cs, r, wr, n_w, q); break;
+        default: SGPU_LAUNCH(sk::k_stream_ceiling<3>, grid, block, 0, g.cs, r, wr, n_w, q); break;
+        }
+    };
+    float best = 1e30f; int bm = 0;
+    for (int round = 0; round < 2; ++round)              // twice round the four forms: the first ones of a process run at ramping clocks
+        for (int m = 0; m < 4; ++m) {
+            for (int i = 0; i < 3; ++i) launch(m);
+            HIPCHK(hipEventRecord(fr.e0, g.cs));
+            for (int i = 0; i < reps; ++i) launch(m);
+            HIPCHK(hipEventRecord(fr.e1, g.cs));
+            HIPCHK(hipEventSynchronize(fr.e1));
+            HIPCHK(hipGetLastError());
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, fr.e0, fr.e1));
+            ms /= reps;
+            if (ms < best) { best = ms; bm = m; }
+        }
+    *us = best * 1e3f;
+    if (mode) *mode = bm;
+    if (bytes_moved) *bytes_moved = n_r * 16 + n_w * 8;
     return SGPU_OK;
 }
 

@@ -41,6 +41,7 @@ HOST_SYMBOLS = {
     "saena_matrix_write_bin": (C.c_int, [_VP, C.c_char_p]),
     "saena_matrix_write_mtx": (C.c_int, [_VP, C.c_char_p]),
     "saena_matrix_set_remove_boundary": (C.c_int, [_VP, C.c_int]),
+    "saena_matrix_set_partition_buckets": (C.c_int, [_VP, C.c_int]),
     "saena_matrix_add_duplicates": (C.c_int, [_VP, C.c_int]),
     "saena_matrix_set_eig": (C.c_int, [_VP, C.c_double]),
     "saena_matrix_assemble": (C.c_int, [_VP]),
@@ -256,6 +257,11 @@ class Matrix:
 
     def set_remove_boundary(self, flag):
         self.L.saena_matrix_set_remove_boundary(self.h, 1 if flag else 0)
+
+    def set_partition_buckets(self, n):
+        """opt-in: at least n row buckets in the nnz-balanced partition of assemble() instead of the reference's nparts^2"""
+        _check(self.L, self.L.saena_matrix_set_partition_buckets(self.h, int(n)))
+        return self
 
     def laplacian3D(self, mx, my=None, mz=None):
         my = mx if my is None else my

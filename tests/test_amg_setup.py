@@ -101,7 +101,7 @@ POLICIES = {
 }
 
 
-def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, policy="rows4096", comm_kind="dist"):
+def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, policy="rows4096", comm_kind="dist", buckets=0):
     import os
     import sys
     import torch.distributed as dist
@@ -122,8 +122,13 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, polic
             A.assemble(np.array([r * n2 * nz for r in range(world + 1)], np.int32))
             A1 = host.Matrix(host.Comm("host", "self")).laplacian3D(m, m, nz * world + 2).assemble()
         else:
-            A = host.Matrix(comm).laplacian3D(m).assemble()
+            A = host.Matrix(comm).set_partition_buckets(buckets).laplacian3D(m).assemble()
             A1 = host.Matrix(host.Comm("host", "self")).laplacian3D(m).assemble()
+            rows = np.diff(A.split).astype(np.float64)
+            if buckets:      # the opt-in finer fine-level partition: a rank's rows within 5 % of the mean (the reference's nparts^2
+                assert rows.max() <= 1.05 * rows.mean(), A.split      # buckets: 1.25 at 4 ranks, 1.125 at 8 on this operator)
+            elif world in (4, 8):
+                assert rows.max() >= 1.1 * rows.mean(), A.split
         S = host.AmgSolver(A, host.options(L, **kw))
         S1 = host.AmgSolver(A1, host.options(L, **kw))     # the same hierarchy at one rank, in this process
         assert S.num_levels == S1.num_levels
@@ -141,7 +146,10 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, polic
         elif policy == "model":
             assert all(o == [0] for o in owners[1:]), owners
         else:
-            assert any(o == list(range(0, world, 2)) for o in owners[1:]), owners       # groups of 2 merged onto ranks 0, 2
+            strided = [o for o in owners[1:] if 1 < len(o) < world]
+            assert strided and all(o == list(range(0, world, world // len(o)))[:len(o)] or o == list(range(0, world, -(-world // len(o)))) for o in strided), owners      # groups of k merged onto ranks 0, k, 2k ...
+            if world == 4:
+                assert any(o == [0, 2] for o in owners[1:]), owners
             assert all(set(owners[l + 1]) <= set(owners[l]) for l in range(len(owners) - 1)), owners   # agglomeration is monotone
         # the coarse operators are re-partitioned by nnz over the ranks that still own rows (the reference's Ac->repart()):
         # every owner of a distributed coarse level holds about its share of the level's entries
@@ -229,7 +237,11 @@ def _dist_worker(rank, world, port, m, ret, smoother="jacobi", slab=False, polic
     ("rows", "jacobi", 4, True, "rows4096", "dist"), ("gathered", "jacobi", 2, False, "rows4096", "dist"),
     ("rows", "jacobi", 4, False, "model", "dist"), ("rows", "chebyshev", 4, False, "stride", "dist"),
     ("gathered", "jacobi", 4, False, "stride", "dist"),
-    ("rows", "chebyshev", 3, False, "rows4096", "shm"), ("rows", "jacobi", 4, True, "stride", "shm")])
+    ("rows", "chebyshev", 3, False, "rows4096", "shm"), ("rows", "jacobi", 4, True, "stride", "shm"),
+    # round 4: the opt-in finer fine-level partition (the hierarchy is still the one-rank hierarchy bit for bit), and EIGHT ranks
+    # over the shared-memory communicator with the k-rank agglomeration firing (configs[3]'s rank count)
+    ("rows", "jacobi", 4, False, "rows4096", "shm+balanced"), ("rows", "jacobi", 8, False, "stride", "shm"),
+    ("rows", "chebyshev", 8, False, "rows4096", "shm+balanced")])
 def test_distributed_hierarchy_gloo(mode, smoother, world, slab, policy, comm_kind, monkeypatch):
     """The hierarchy built over several ranks -- every rank building only its rows of every level (the default), or the
     older gather-then-slice form -- is the one-rank hierarchy bit for bit: every level's A, P and R layout equals the
@@ -238,12 +250,14 @@ def test_distributed_hierarchy_gloo(mode, smoother, world, slab, policy, comm_ki
     import torch.multiprocessing as mp
     from tests.test_host_layout import _free_port
     monkeypatch.setenv("SAENA_SETUP", mode)
-    monkeypatch.setenv("SAENA_SETUP_THREADS", "2")
+    monkeypatch.setenv("SAENA_SETUP_THREADS", "2" if world < 8 else "1")
+    buckets = 4096 if comm_kind.endswith("+balanced") else 0
+    comm_kind = comm_kind.split("+")[0]
     port = _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 30 if slab else 24, ret, smoother, slab, policy, comm_kind)) for r in range(world)]
+        procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 30 if slab else 24, ret, smoother, slab, policy, comm_kind, buckets)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:

@@ -941,6 +941,33 @@ def test_plan_cache_makes_a_second_operator_take_the_first_one_s_plan(capi, tmp_
     np.testing.assert_array_equal(y1.download(), A.matvec(x))
 
 
+def test_config5_irregular_operator_against_the_oracle(capi):
+    """BASELINE configs[4] as bench.py measures it (`spmv_irregular`: SiH4 replicated with per-block permutations, coupling entries
+    and hub rows, tests/irregular.py), at 3 blocks -- a size the oracle runs in a second: rows of 13 to 3 000 entries, a hub row
+    longer than the 16 KiB tile (the long-row path).  One lane per row: the reference's sequential sum, bit for bit; the autotuned
+    kernel and its Jacobi sweeps within the stated tolerances."""
+    from tests import irregular
+    r, c, v, M = irregular.sih4_replicated(3)
+    A = orc.OracleOp(orc.coo_from_arrays(r, c, v), M, M, orc.split_even(M, 1))
+    G = util.gpu_operator(A)
+    plan = G.block_plan(0)
+    assert plan["nnz"] == len(r) and plan["long_rows"] >= 1 and plan["longest_row"] >= 2900, plan
+    G.set_lanes_per_row(1)
+    x, rhs = inputs.v2(M), inputs.rhs2(M)
+    dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
+    G.spmv(dx, dy)
+    want = A.matvec(x)
+    np.testing.assert_array_equal(dy.download(), want)
+    G.autotune()                                             # 518 K entries: above the autotune's floor
+    G.spmv(dx, dy)
+    rows = np.asarray(r)
+    bound = np.bincount(rows, weights=np.abs(v * x[c]), minlength=M)
+    assert np.all(np.abs(dy.download() - want) <= 1e-13 * bound)
+    G.jacobi(3, dx, dr)
+    wj = A.jacobi(3, x, rhs)
+    assert rel(dx.download(), wj) <= 1e-12
+
+
 def test_plan_cache_honours_every_variant_the_autotune_can_store(capi, tmp_path, monkeypatch):
     """Round-3 advisor finding: the lookup accepted variants 0..14 while the autotune can pick and store 15 (k_sellpx), so a cached
     k_sellpx line was never honoured and every process tuned again and appended another line.  Lookup, store and set_variant

@@ -83,6 +83,28 @@ def test_read_file_mtx_and_bin(name, tmp_path):
     assert_layout_equal(B.layout(), want, name + ".bin")
 
 
+def test_config5_irregular_generator():
+    """tests/irregular.py (bench.py's `spmv_irregular`, BASELINE configs[4] scaled up): deterministic, symmetric, no duplicate
+    entries, a diagonal in every row, rows from 13 entries to a hub of ~3 000; assembled by the product's host library it is the
+    oracle's layout bit for bit"""
+    from tests import irregular
+    r, c, v, M = irregular.sih4_replicated(3)
+    r2, c2, v2, _ = irregular.sih4_replicated(3)
+    assert np.array_equal(r, r2) and np.array_equal(c, c2) and np.array_equal(v, v2)
+    key = r.astype(np.int64) * M + c
+    assert len(np.unique(key)) == len(key)
+    assert set(key.tolist()) == set((c.astype(np.int64) * M + r).tolist()), "pattern must be symmetric"
+    assert np.count_nonzero(r == c) == M
+    st = irregular.row_length_stats(r, M)
+    assert st["min"] >= 1 and st["max"] >= 2900 and st["coefficient_of_variation"] > 0.8, st
+    A = host.Matrix(host.Comm("host", "self"))
+    A.set_remove_boundary(False)
+    A.set_many(r, c, v)
+    A.assemble()
+    O = orc.OracleOp(orc.coo_from_arrays(r, c, v), M, M, orc.split_even(M, 1))
+    assert_layout_equal(A.layout(), oracle_layout(O, 0), "sih4 x 3")
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
