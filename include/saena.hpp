@@ -4,7 +4,8 @@
 // saena::options, saena::amg and the generator functions of include/aux_functions2.h:12-43) with
 // the same method names, argument meaning and defaults, and the index_t / nnz_t / value_t typedefs
 // of include/data_struct.h:36-38, so that a driver such as experiments/Poisson.cpp ports by
-// replacing `MPI_Comm` with `saena::comm`.  Only the members on (or feeding) the V-cycle hot path
+// replacing `MPI_Comm` with `saena::comm` -- or, unchanged, by including include/saena_mpi.hpp instead
+// (MPI_Comm overloads; tests/test_cpp_surface.py compiles the reference's flow against it).  Only the members on (or feeding) the V-cycle hot path
 // are provided; GMRES, lazy updates, matmat, PETSc bridges etc. are out of scope.
 //
 // Differences from the reference, all at the boundary:
@@ -36,6 +37,14 @@ void finalize();
 class comm {
 public:
     comm();                       // the world communicator of saena::init()
+#ifdef SAENA_MPI_HPP
+    // include/saena_mpi.hpp (source compatibility with drivers of the reference, which pass MPI_Comm): brings the GPU runtime up over
+    // the MPI job the first time it is used -- rank / size from the communicator, device = rank within the node, the RCCL unique id
+    // broadcast with MPI_Bcast -- and stands for the world communicator afterwards.  Member FUNCTIONS only: the layout is the library's.
+    comm(MPI_Comm c);
+    operator MPI_Comm() const;
+#define SAENA_HPP_HAS_MPI 1
+#endif
     int rank() const;
     int size() const;
     saena_host::Comm *impl() const { return c_; }
@@ -50,8 +59,8 @@ public:
     matrix();
     explicit matrix(comm c);
     ~matrix();
-    matrix(const matrix &) = delete;
-    matrix &operator=(const matrix &) = delete;
+    matrix(const matrix &B);              // copy constructor: the host-side matrix is copied, the device operator is created again on first use
+    matrix &operator=(const matrix &B);
 
     int read_file(const char *name);
     int read_file(const char *name, const std::string &input_type);
@@ -59,6 +68,7 @@ public:
     int set(index_t i, index_t j, value_t val);                                  // set individual value
     int set(index_t *row, index_t *col, value_t *val, nnz_t nnz_local);          // set multiple values
     int set(index_t i, index_t j, unsigned int size_x, unsigned int size_y, value_t *val);   // set contiguous block
+    int set(index_t i, index_t j, unsigned int *di, unsigned int *dj, value_t *val, nnz_t nnz_local);   // set generic block
 
     void set_eig(const std::string &opts_fname);   // reads the optional eig="..." attribute of the options XML
     void set_eig(double eig);
@@ -70,6 +80,7 @@ public:
 
     int assemble(bool scale = false, bool use_dense = false);
     int assemble_band_matrix(bool use_dense = false);
+    int assemble_writeToFile(const char *folder_name = "");      // assemble(), then writeMatrixToFile(folder_name)
     int writeMatrixToFile(const std::string &name = "") const;   // "<name>-r<rank>.mtx", MatrixMarket coordinate real general
     // Knobs of the reference's CPU implementation that have no counterpart on this path; accepted so that drivers
     // written against the reference compile and run unchanged (reference saena.cpp:115-140,205-214):
@@ -209,6 +220,9 @@ public:
     // C = A B (host SpGEMM, one rank in this round); C is erased first and assembled unless assemble == false
     void matmat(saena::matrix *A, saena::matrix *B, saena::matrix *C, bool assemble = true, bool print_timing = false);
     void profile_matvecs();                                   // average matvec time of every level's A
+    int solve_pCG_profile(value_t *&u, saena::options *opts);  // solve_pCG with its timing printed (the reference prints a per-phase profile)
+    int solve_petsc(value_t *&u, saena::options *opts);        // PETSc bridge: out of scope -- prints why and returns 1 (kept so that drivers compile)
+    comm get_orig_comm();
 
     int  switch_to_dense(bool val);                 // dense row-major storage for the coarse levels past the density threshold
     int  set_dense_threshold(float thre);

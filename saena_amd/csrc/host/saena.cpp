@@ -58,6 +58,17 @@ int comm::size() const { return c_->nranks; }
 matrix::matrix() : c_(), m_pImpl(new saena_host::saena_matrix(c_.impl())) {}
 matrix::matrix(comm c) : c_(c), m_pImpl(new saena_host::saena_matrix(c.impl())) {}
 matrix::~matrix() { destroy(); }
+// copies (reference saena.cpp:14-31): the host-side matrix is copied whole; the copy builds its own device operator on first use
+matrix::matrix(const matrix &B) : add_dup(B.add_dup), c_(B.c_), m_pImpl(B.m_pImpl ? new saena_host::saena_matrix(*B.m_pImpl) : nullptr) {}
+matrix &matrix::operator=(const matrix &B) {
+    if (this != &B) {
+        destroy();
+        c_ = B.c_;
+        m_pImpl = B.m_pImpl ? new saena_host::saena_matrix(*B.m_pImpl) : nullptr;
+        add_dup = B.add_dup;
+    }
+    return *this;
+}
 int matrix::read_file(const char *name) { return m_pImpl->read_file(name, ""); }
 int matrix::read_file(const char *name, const std::string &t) { return m_pImpl->read_file(name, t); }
 void matrix::set_comm(comm c) { c_ = c; m_pImpl->comm = c.impl(); }
@@ -67,6 +78,12 @@ int matrix::set(index_t i, index_t j, unsigned int size_x, unsigned int size_y, 
     // contiguous block, row-major values (saena_matrix.cpp set(i,j,size_x,size_y,val))
     for (unsigned int a = 0; a < size_x; ++a)
         for (unsigned int b = 0; b < size_y; ++b) m_pImpl->set(i + (index_t)a, j + (index_t)b, val[a * size_y + b]);
+    return 0;
+}
+int matrix::set(index_t i, index_t j, unsigned int *di, unsigned int *dj, value_t *val, nnz_t n) {
+    // generic block (reference saena.cpp:100-112): entry k at (i + di[k], j + dj[k]); exact zeros are skipped
+    for (nnz_t k = 0; k < n; ++k)
+        if (val[k] != 0) m_pImpl->set(i + (index_t)di[k], j + (index_t)dj[k], val[k]);
     return 0;
 }
 void matrix::set_eig(double e) { m_pImpl->set_eig(e); }
@@ -95,6 +112,10 @@ int matrix::print(int ran, std::string name) {          // saena_matrix::print_e
     printf("\nmatrix %s on rank %d: %ld entries\n", name.c_str(), c_.rank(), (long)m_pImpl->entry.size());
     for (const auto &e : m_pImpl->entry) printf("%d\t%d\t%.12g\n", e.row, e.col, e.val);
     return 0;
+}
+int matrix::assemble_writeToFile(const char *folder_name) {   // reference saena.cpp:157-172
+    if (!m_pImpl->assembled) assemble();
+    return writeMatrixToFile(folder_name ? folder_name : "");
 }
 int matrix::writeMatrixToFile(const std::string &name) const { return m_pImpl->writeMatrixToFile(name.empty() ? "mat" : name); }
 saena_host::saena_matrix *matrix::get_internal_matrix() { return m_pImpl; }
@@ -354,6 +375,23 @@ void amg::profile_matvecs() {
     if (A_->get_comm().rank() == 0)
         for (size_t l = 0; l < us.size(); ++l) printf("matvec level %zu: %e s\n", l, us[l] * 1e-6);
 }
+
+// solve_pCG_profile (saena_object_solve.cpp: the reference prints the time of every phase of its CPU loop): here the solve runs
+// as device graphs, so what there is to print is the solve itself -- iterations, time, time per iteration
+int amg::solve_pCG_profile(value_t *&u, saena::options *opts) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int st = run(u, opts, 1, false);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (A_ && A_->get_comm().rank() == 0)
+        printf("solve_pCG profile: %d iterations in %e s (%e s per iteration: one V-cycle, one fine matvec, the dots), incl. upload / download of u\n",
+               iters_, dt, iters_ ? dt / iters_ : 0.0);
+    return st;
+}
+int amg::solve_petsc(value_t *&, saena::options *) {
+    fprintf(stderr, "saena::amg::solve_petsc: the PETSc bridge is not part of the MI355X path (SURVEY.md 2: out of scope)\n");
+    return 1;
+}
+comm amg::get_orig_comm() { return A_ ? A_->get_comm() : comm(); }
 
 void free_vector(value_t *u) { std::free(u); }
 
