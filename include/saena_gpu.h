@@ -138,7 +138,9 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
  * and whose row pairs share a length; what the autotune keeps on fine levels larger than the Infinity Cache).
  * 15 k_sellpx: k_sellp with the windows of x that a workgroup of 512 rows reaches staged in LDS and a 16-bit table per
  * workgroup (operators that qualify for 11 and whose pattern offsets fall into at most 16 clusters that fit 80 KiB of LDS
- * together with the table).
+ * together with the table); 16 k_csr_xldsr: k_csr_xlds with FOUR consecutive rows per group step (4 / 8 / 16 lanes per
+ * group) -- irregular operators of a few dozen entries per row, where one row per step leaves the kernel waiting on the
+ * latency of a row (BASELINE configs[4] scaled to 1 M rows).
  * 7, 8, 9 and 11 to 15 are
  * built from a host copy of the values that the library keeps only until the plan-time autotune (SGPU_ERR_ARG
  * afterwards, and where the form does not apply) */

@@ -1128,7 +1128,15 @@ struct XldsArgs {
     double     *acc;       // [M] partial row sums between windows (nullptr when every workgroup has one window)
     int         ncols;
 };
-template <int EPI, int G, bool HALO>
+// RP > 1 (k_csr_xldsr, round 4): SHORT rows -- an irregular operator of a few dozen entries per row (BASELINE configs[4] scaled to
+// 1 M rows: 13-205 entries, hubs of 3 000).  With one row per group step the kernel is bound by the LATENCY of a row, not by bytes:
+// fetch the row's entry range -> its value / column quads -> the LDS gathers -> the shuffle sum -> the epilogue -> the counter, one
+// after the other, ~2.5 us for a row whose 34 entries give a group of 8 lanes a single trip (111 us against a streaming ceiling of
+// 55 us).  Here a group takes RP consecutive rows per step and streams their quads as ONE sequence (a quad belongs to exactly one of
+// the rows; the lane keeps a sum per row), so four times the loads are in flight per trip and the fixed part of the chain is paid
+// once per RP rows; lanes 0..RP-1 then run the RP epilogues side by side.  Same products; a row's entries are added lane by lane
+// and then across the group like before, with another lane-to-quad mapping: deterministic, parity at the smoothers' tolerance.
+template <int EPI, int G, bool HALO, int RP = 1>
 __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const XldsArgs w) {
     __shared__ __attribute__((aligned(16))) double xs[XL_MAX];
     __shared__ int next_row;
@@ -1153,6 +1161,79 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
         if (tid == 0) next_row = NG;                              // the first NG rows go to the groups in order
         __syncthreads();
         const int *ts = w.tab + inf.z + t * nr, *te = ts + nr;
+        if constexpr (RP > 1) {
+            static_assert(G >= RP, "a lane per epilogue");
+            if (tid == 0) next_row = NG * RP;                     // (rewritten before the barrier above took effect for RP == 1: set again here)
+            __syncthreads();
+            int k = (tid / G) * RP;
+            while (k < nr) {
+                int p0[RP], p1[RP], a0[RP], qe[RP];               // entry range, its quad-aligned start, end of the row's quads in the group's sequence
+                int nq = 0;
+#pragma unroll
+                for (int j = 0; j < RP; ++j) {
+                    const bool have = k + j < nr;
+                    p0[j] = have ? ts[k + j] : 0; p1[j] = have ? te[k + j] : 0;
+                    a0[j] = p0[j] & ~3;
+                    nq += p1[j] > p0[j] ? (p1[j] - a0[j] + 3) >> 2 : 0;
+                    qe[j] = nq;
+                }
+                double sum[RP];
+#pragma unroll
+                for (int j = 0; j < RP; ++j) sum[j] = 0.0;
+                for (int q = l; q < nq; q += 4 * G) {
+                    double2 v01[4], v23[4];
+                    uint2   c[4];
+                    int     i[4], lo[4], hi[4], wj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int qq = q + G * u;
+                        int j = 0;
+#pragma unroll
+                        for (int t2 = 0; t2 < RP - 1; ++t2) j += qq >= qe[t2] ? 1 : 0;
+                        int qb = 0, ab = a0[0]; lo[u] = p0[0]; hi[u] = p1[0];
+#pragma unroll
+                        for (int t2 = 1; t2 < RP; ++t2)
+                            if (j == t2) { qb = qe[t2 - 1]; ab = a0[t2]; lo[u] = p0[t2]; hi[u] = p1[t2]; }
+                        wj[u] = j;
+                        i[u] = ab + 4 * (qq - qb);
+                        v01[u].x = v01[u].y = v23[u].x = v23[u].y = 0.0;
+                        c[u].x = c[u].y = 0u;
+                        if (qq < nq) {
+                            v01[u] = ld_stream_d2(a.val + i[u], a.nt);
+                            v23[u] = ld_stream_d2(a.val + i[u] + 2, a.nt);
+                            c[u]   = ld_stream_u2(a.ccol + i[u], a.nt);
+                        } else wj[u] = -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        double x0 = xs[c[u].x & 0xffffu], x1 = xs[c[u].x >> 16], x2 = xs[c[u].y & 0xffffu], x3 = xs[c[u].y >> 16];
+                        if (wj[u] < 0) x0 = x1 = x2 = x3 = 0.0;
+                        else if (i[u] < lo[u] || i[u] + 4 > hi[u]) {
+                            x0 = stray(i[u], lo[u], hi[u]) ? 0.0 : x0;     x1 = stray(i[u] + 1, lo[u], hi[u]) ? 0.0 : x1;
+                            x2 = stray(i[u] + 2, lo[u], hi[u]) ? 0.0 : x2; x3 = stray(i[u] + 3, lo[u], hi[u]) ? 0.0 : x3;
+                        }
+#pragma unroll
+                        for (int j = 0; j < RP; ++j)
+                            if (wj[u] == j) { sum[j] += v01[u].x * x0; sum[j] += v01[u].y * x1; sum[j] += v23[u].x * x2; sum[j] += v23[u].y * x3; }
+                    }
+                }
+                double mine = 0.0;
+#pragma unroll
+                for (int j = 0; j < RP; ++j) {
+                    const double sj = group_sum<G>(sum[j]);
+                    if (l == j) mine = sj;
+                }
+                if (l < RP && k + l < nr) {                       // lanes 0 .. RP-1: an epilogue each
+                    const int r = r0 + k + l;
+                    if (t > 0) mine = w.acc[r] + mine;
+                    if (t < T - 1) w.acc[r] = mine;
+                    else epilogue<EPI, HALO>(a, r, mine);
+                }
+                int nk = 0;
+                if (l == 0) nk = atomicAdd(&next_row, RP);
+                k = __shfl(nk, lane & ~(G - 1), 64);
+            }
+        } else {
         int k = tid / G;
         while (k < nr) {
             const int p0 = ts[k], p1 = te[k];
@@ -1195,6 +1276,7 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
                 nk = atomicAdd(&next_row, 1);
             }
             k = __shfl(nk, lane & ~(G - 1), 64);
+        }
         }
     }
 }

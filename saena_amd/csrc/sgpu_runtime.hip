@@ -1256,6 +1256,24 @@ SellxKernelFn pick_sellx_h(int epi) {
     }
 }
 XldsKernelFn pick_xlds(int epi, int lanes, bool halo) { return halo ? pick_xlds_h<true>(epi, lanes) : pick_xlds_h<false>(epi, lanes); }
+// k_csr_xldsr: four rows per group step (short rows), 4 / 8 / 16 lanes per group
+template <int EPI, bool HALO>
+XldsKernelFn pick_xldsr_g(int lanes) {
+    return lanes <= 4 ? sk::k_csr_xlds<EPI, 4, HALO, 4> : lanes <= 8 ? sk::k_csr_xlds<EPI, 8, HALO, 4> : sk::k_csr_xlds<EPI, 16, HALO, 4>;
+}
+template <bool HALO>
+XldsKernelFn pick_xldsr_h(int epi, int lanes) {
+    switch (epi) {
+        case sk::EPI_SPMV:     return pick_xldsr_g<sk::EPI_SPMV, HALO>(lanes);
+        case sk::EPI_RESIDUAL: return pick_xldsr_g<sk::EPI_RESIDUAL, HALO>(lanes);
+        case sk::EPI_JACOBI:   return pick_xldsr_g<sk::EPI_JACOBI, HALO>(lanes);
+        case sk::EPI_CHEBY0:   return pick_xldsr_g<sk::EPI_CHEBY0, HALO>(lanes);
+        case sk::EPI_CHEBYK:   return pick_xldsr_g<sk::EPI_CHEBYK, HALO>(lanes);
+        case sk::EPI_RSWEEP:   return pick_xldsr_g<sk::EPI_RSWEEP, HALO>(lanes);
+        default:               return pick_xldsr_g<sk::EPI_SUB, HALO>(lanes);
+    }
+}
+XldsKernelFn pick_xldsr(int epi, int lanes, bool halo) { return halo ? pick_xldsr_h<true>(epi, lanes) : pick_xldsr_h<false>(epi, lanes); }
 
 int launch_part(const CsrPart &P, int epi, const double *x, double *y, const EpiArgs &e, const unsigned *skip = nullptr, uint64_t seq = 0) {
     if (P.nblk == 0) return SGPU_OK;
@@ -1315,12 +1333,12 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         w.info = P.xl_info; w.bptr = P.sx_bptr; w.sptr = P.sx_sptr; w.meta = P.sx_meta; w.val = P.sx_val; w.col = P.sx_col; w.acc = P.xl_acc; w.ncols = P.ncols;
         if (nt_rt == 0 && !std::getenv("SAENA_STREAM_NT")) a.nt = 10 * P.nnz > (int64_t)256 * 1024 * 1024 ? 1 : 0;      // non-temporal streams beyond the Infinity Cache (438 -> 426 us)
         SGPU_LAUNCH(halo ? pick_sellx_h<true>(epi) : pick_sellx_h<false>(epi), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, w);
-    } else if (P.variant == 10) {                                 // x in LDS, a workgroup per CU
+    } else if (P.variant == 10 || P.variant == 16) {              // x in LDS, a workgroup per CU (16: four rows per group step -- short rows)
         if (!P.xl_ok || !P.xl_col) return fail(SGPU_ERR_STATE, "the x-in-LDS form was not built");
         a.blk_row = P.xl_blk; a.nblk = P.xl_nblk; a.ccol = P.xl_col;
         sk::XldsArgs w;
         w.info = P.xl_info; w.tab = P.xl_tab; w.acc = P.xl_acc; w.ncols = P.ncols;
-        SGPU_LAUNCH(pick_xlds(epi, P.lanes, halo), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, w);
+        SGPU_LAUNCH(P.variant == 16 ? pick_xldsr(epi, P.lanes, halo) : pick_xlds(epi, P.lanes, halo), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, w);
     } else if (P.variant == 11) {                                 // sliced ELLPACK values + row patterns, a lane per row
         if (!P.sp_ok || !P.sl_val) return fail(SGPU_ERR_STATE, "the row-pattern form was not built");
         a.blk_row = nullptr; a.nblk = P.nslices;
@@ -2124,7 +2142,7 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes) {
 }
 
 // the kernel forms, by number: ONE table, whose length is what set_variant, the plan cache's lookup and its store accept
-static const char *const VARIANT_NAMES[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx", "k_rowt", "k_sellp2", "k_sellpx"};   // (3, 4, 7, 8 are named with their slot/offset split below)
+static const char *const VARIANT_NAMES[] = {"k_csr_stream<16KiB>", "k_csr_stream<32KiB>", "k_csr_vector", "k_csr_cc16<16KiB>", "k_csr_cc16<32KiB>", "k_dense_rows", "k_csr_wave", "k_csr_cm<16KiB>", "k_csr_cm<32KiB>", "k_sell", "k_csr_xlds", "k_sellp", "k_sellx", "k_rowt", "k_sellp2", "k_sellpx", "k_csr_xldsr"};   // (3, 4, 7, 8 are named with their slot/offset split below)
 static constexpr int MAX_VARIANT = (int)(sizeof VARIANT_NAMES / sizeof VARIANT_NAMES[0]) - 1;
 
 int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_name) {
@@ -2183,7 +2201,7 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
             return fail(SGPU_ERR_ARG, "the row-pattern form needs what the sliced-ELLPACK form needs and rows that follow at most %d-int's worth of "
                                       "(length, relative columns) patterns per group of %d rows", sk::SPW_MAX_TABLE, sk::SPW_BLOCK);
     }
-    if (variant == 10) {
+    if (variant == 10 || variant == 16) {
         CHK(build_xlds(op->loc));
         if (!op->loc.xl_ok)
             return fail(SGPU_ERR_ARG, "the x-in-LDS form needs row chunks (one per CU) that reach over at most %d columns",
@@ -2273,11 +2291,13 @@ bool plan_cache_lookup(uint64_t key, int *v, int *lanes) {
     fclose(f);
     return hit;
 }
-void plan_cache_store(uint64_t key, const sgpu_op *op, int v, int lanes, float ms) {
+void plan_cache_store(uint64_t key, const sgpu_op *op, int v, int lanes, float ms, int rv = -1, int rlanes = 0, float rms = 0) {
     const std::string path = plan_cache_path();
     if (path.empty()) return;
     char line[256];
-    const int n = snprintf(line, sizeof line, "%016llx\t%d\t%d\t%.4f\t# %d rows %lld nnz\n", (unsigned long long)key, v, lanes, ms, op->M, (long long)op->loc.nnz);
+    int n = snprintf(line, sizeof line, "%016llx\t%d\t%d\t%.4f\t# %d rows %lld nnz", (unsigned long long)key, v, lanes, ms, op->M, (long long)op->loc.nnz);
+    if (rv >= 0) n += snprintf(line + n, sizeof line - (size_t)n, "; %s %.4f ms; runner-up %s with %d lanes %.4f ms", VARIANT_NAMES[v], ms, VARIANT_NAMES[rv], rlanes, rms);   // (the lookup reads the first three fields)
+    n += snprintf(line + n, sizeof line - (size_t)n, "\n");
     const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);    // one write() of one short line: appends of concurrent ranks do not interleave
     if (fd < 0) return;
     if (::write(fd, line, (size_t)n) != n) { /* a cache: best effort */ }
@@ -2305,7 +2325,7 @@ void finish_plan(sgpu_op *op, int bv) {
     if (!keep) { std::vector<int>().swap(op->loc.h_pstart); std::vector<int>().swap(op->loc.h_ptab); std::vector<unsigned short>().swap(op->loc.h_pat); }
     if (bv != 13 && !keep) op->loc.free_rowt();
     if (bv != 12 && !keep) op->loc.free_sellx();
-    if (bv != 10 && bv != 12 && !keep) op->loc.free_xlds();
+    if (bv != 10 && bv != 12 && bv != 16 && !keep) op->loc.free_xlds();
     else if (bv == 12 && !keep) { hipFree(op->loc.xl_col); hipFree(op->loc.xl_tab); op->loc.xl_col = nullptr; op->loc.xl_tab = nullptr; }      // k_sellx keeps the chunk plan only
     if (!keep) std::vector<double>().swap(op->h_val_all);       // (a later set_variant(7/8/9/11) on this operator is refused: the values are gone)
     for (int k = 0; k < 2 && !keep; ++k)              // free the compressed arrays of the plans that lost
@@ -2401,9 +2421,14 @@ int sgpu_op_autotune(sgpu_op *op) {
     }
     variants.push_back(2);                                                                           // vector CSR: no build
     if (op->loc.nnz >= 256 * (int64_t)std::max(1, op->loc.nrows)) variants.push_back(6);             // long rows: the wave-streamed kernel
-    if (op->loc.nnz >= 48 * (int64_t)std::max(1, op->loc.nrows) && !std::getenv("SAENA_NO_XLDS") && (!short_rows)) {
-        CHK(build_xlds(op->loc));                                                                    // long rows over few columns: x in LDS
+    // x in LDS: long rows over few columns; and (round 4) IRREGULAR operators of a few dozen entries per row -- no sliced-ELLPACK form
+    // (uneven rows), random columns inside a window: the tile kernels' gathers are what bounds them (configs[4] at 1 M rows: 134 us
+    // against 111 us with x in LDS, 4 rows per group step below that)
+    const bool irregular_short = !sell_like && avg_row >= 12.0;
+    if ((op->loc.nnz >= 48 * (int64_t)std::max(1, op->loc.nrows) || irregular_short) && !std::getenv("SAENA_NO_XLDS") && (!short_rows)) {
+        CHK(build_xlds(op->loc));
         if (op->loc.xl_ok && op->loc.xl_piece >= 24.0) variants.push_back(10);
+        if (op->loc.xl_ok && op->loc.xl_piece >= 8.0 && op->loc.xl_piece < 160.0 && !std::getenv("SAENA_NO_XLDSR")) variants.push_back(16);   // short pieces: four rows per group step
     }
     // (on the transfers it does not pay: P1 of 256^3, 18 entries per row, 504 us against 350; P2 ties; R2 165 against 156 us,
     //  profiles/r03_sellx_steps.log)
@@ -2435,9 +2460,10 @@ int sgpu_op_autotune(sgpu_op *op) {
         const int gx = std::min(64, std::max(4, pow2floor((int)std::max(1.0, op->loc.xl_piece / 64.0))));
         for (int g : {gx / 2, gx, gx * 2}) if (g >= 4 && g <= 64) lanes_x.push_back(g);
     }
+    const std::vector<int> lanes_r = {4, 8, 16};          // k_csr_xldsr: lanes per group of four rows
     std::vector<std::pair<int, int>> cands;
     for (int v : variants)
-        for (int gl : (v == 10 ? lanes_x : lanes)) {
+        for (int gl : (v == 10 ? lanes_x : v == 16 ? lanes_r : lanes)) {
             if ((v == 9 || v == 11 || v == 12 || v == 13 || v == 14 || v == 15) && gl != lanes.front()) continue;      // a lane per row (piece) whatever the setting
             if (v == 5 && gl != lanes.front()) continue;                   // one wave per dense row likewise
             cands.push_back({v, gl});
@@ -2478,28 +2504,51 @@ int sgpu_op_autotune(sgpu_op *op) {
             auto it = seen.find(c);
             if (it == seen.end()) seen[c] = ms; else it->second = std::min(it->second, ms);
         }
+    // The deciding rounds (round 4): the candidates within 8 % of the fastest are timed again in three INTERLEAVED trials of >= 3 ms each,
+    // every one keeping its best time -- two 1 ms samples (six launches of a 0.2 ms kernel) let the fine level of 256^3 come out as
+    // k_sellp on one box and k_sellp2 on the next while their times differ by more than the spread of either (204-222 against 218-239 us).
+    {
+        float lead = 1e30f;
+        for (const auto &kv : seen) lead = std::min(lead, kv.second);
+        std::vector<std::pair<int, int>> close;
+        for (const auto &kv : seen) if (kv.second <= 1.08f * lead) close.push_back(kv.first);
+        if (close.size() > 1)
+            for (int trial = 0; trial < 3; ++trial)
+                for (const auto &c : close) {
+                    const int reps = std::min(64, std::max(8, (int)(3.0f / std::max(seen[c], 1e-3f)) + 1));
+                    float ms = 0;
+                    CHK(sample(c.first, c.second, reps, &ms));
+                    seen[c] = std::min(seen[c], ms);
+                }
+    }
     float best = 1e30f;
     for (const auto &kv : seen) if (kv.first.first != 7 && kv.first.first != 8) best = std::min(best, kv.second);
     float best_cm = 1e30f;
     for (const auto &kv : seen) if (kv.first.first == 7 || kv.first.first == 8) best_cm = std::min(best_cm, kv.second);
     const bool cm_wins = best_cm < 0.95f * best;          // the column-major copy costs 2 B/nnz more: it has to win clearly
     const float bar = 1.03f * (cm_wins ? best_cm : best);
+    // Inside the 3 % band: forms with the reference's sequential row sum first.  They are bit-identical to ONE ANOTHER (k_sell, k_sellp,
+    // k_sellp2, k_sellpx, the tile kernels at one lane per row), so among them the choice cannot move a result and simply goes to the
+    // fastest; between forms whose sums differ it goes by the fixed (variant, lanes) order, so that noise does not move a result.
     int bv = guard.v, bg = guard.l, brank = 1 << 30;
     float bms = 0;
+    int rv = -1, rg = 0; float rms = 0;                   // runner-up (what the cache line records next to the choice)
     for (const auto &kv : seen) {                         // std::map: ascending (variant, lanes)
         const int v = kv.first.first, gl = kv.first.second;
         if ((v == 7 || v == 8) != cm_wins || kv.second > bar) continue;
         const int rank = sequential_sum(v, gl) ? 0 : 1;
-        if (rank < brank) { brank = rank; bv = v; bg = gl; bms = kv.second; }
+        if (rank < brank || (rank == 0 && brank == 0 && kv.second < bms)) { brank = rank; bv = v; bg = gl; bms = kv.second; }
     }
+    for (const auto &kv : seen)
+        if ((kv.first.first != bv || kv.first.second != bg) && (rv < 0 || kv.second < rms)) { rv = kv.first.first; rg = kv.first.second; rms = kv.second; }
     guard.armed = false;
     op->loc.variant = bv; op->loc.lanes = bg;
     finish_plan(op, bv);
-    plan_cache_store(key, op, bv, bg, bms);
+    plan_cache_store(key, op, bv, bg, bms, rv, rg, rms);
     if (verbose)
-        fprintf(stderr, "[sgpu] autotune of %d rows x %lld nnz (%.1f per row): %zu candidates, variant %d with %d lanes at %.1f us (fastest %.1f us); sliced ELLPACK %.2f s, "
+        fprintf(stderr, "[sgpu] autotune of %d rows x %lld nnz (%.1f per row): %zu candidates, variant %d with %d lanes at %.1f us (fastest %.1f us; runner-up variant %d with %d lanes at %.1f us); sliced ELLPACK %.2f s, "
                         "16-bit columns %.2f s, x in LDS %.2f s, column order %.2f s, timing %.2f s\n", op->M, (long long)op->loc.nnz, avg_row, cands.size(), bv, bg, bms * 1e3,
-                (cm_wins ? best_cm : best) * 1e3, t_sell - t_begin, t_cc - t_sell, t_xl - t_cc, t_cm - t_xl, now_s() - t_cm);
+                (cm_wins ? best_cm : best) * 1e3, rv, rg, rms * 1e3, t_sell - t_begin, t_cc - t_sell, t_xl - t_cc, t_cm - t_xl, now_s() - t_cm);
     return SGPU_OK;
 }
 

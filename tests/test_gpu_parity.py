@@ -147,7 +147,7 @@ def _sellp_eligible(entries, M):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 14, 15])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16])
 def test_kernel_variants(capi, name, variant, monkeypatch):
     """32 KiB tiles / vector CSR / 16-bit compressed columns (16 and 32 KiB tiles; long rows included) / wave-streamed
     long rows / compressed columns with the block's entries in column order (16 and 32 KiB tiles) / sliced ELLPACK /
@@ -198,6 +198,8 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         assert G.variant()[1] == "k_sell"
     if variant == 10:
         assert G.variant()[1] == "k_csr_xlds"
+    if variant == 16:
+        assert G.variant()[1] == "k_csr_xldsr"
     if variant == 11:
         assert G.variant()[1] == ("k_sellp" if table == "narrow" else "k_sellp<wide>")
     if variant == 14:
@@ -209,7 +211,7 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         G.set_lanes_per_row(lanes)
         G.spmv(dx, dy)
         got, want = dy.download(), A.matvec(x)
-        if (lanes == 1 or variant in (9, 11, 14, 15)) and variant not in (2, 6, 10, 12) and (name != "band3000_1400" or variant in (1, 4, 8)):
+        if (lanes == 1 or variant in (9, 11, 14, 15)) and variant not in (2, 6, 10, 12, 16) and (name != "band3000_1400" or variant in (1, 4, 8)):
             np.testing.assert_array_equal(got, want)          # stream variants keep the sequential row sum
         else:
             assert np.all(np.abs(got - want) <= TOL_SPMV * bound + 1e-300)
@@ -305,6 +307,18 @@ def test_x_in_lds_column_windows(capi):
         du = capi.DeviceVector(M, x)
         G.jacobi(2, du, dr)
         assert rel(du.download(), A.jacobi(2, x, rhs)) <= TOL_SMOOTH
+    # the same windows with FOUR rows per group step (k_csr_xldsr, round 4: short row pieces -- a group streams the quads of four
+    # consecutive rows as one sequence and runs their four epilogues side by side; partial sums carried between the windows)
+    G.set_variant(16)
+    assert G.variant()[1] == "k_csr_xldsr"
+    for lanes in (4, 8, 16):
+        G.set_lanes_per_row(lanes)
+        G.spmv(dx, dy)
+        assert np.all(np.abs(dy.download() - A.matvec(x)) <= TOL_SPMV * bound + 1e-300)
+        du = capi.DeviceVector(M, x)
+        G.jacobi(3, du, dr)
+        assert rel(du.download(), A.jacobi(3, x, rhs)) <= TOL_SMOOTH
+    G.set_variant(10)
     # the same windows with a LANE per row piece (k_sellx: pieces sorted by length inside every (chunk, window) block, 64 to a
     # slice): every fused epilogue, a few rows emptied so that some pieces are missing and some rows have none at all
     import os
@@ -941,12 +955,13 @@ def test_plan_cache_makes_a_second_operator_take_the_first_one_s_plan(capi, tmp_
     np.testing.assert_array_equal(y1.download(), A.matvec(x))
 
 
-def test_config5_irregular_operator_against_the_oracle(capi):
+def test_config5_irregular_operator_against_the_oracle(capi, monkeypatch):
     """BASELINE configs[4] as bench.py measures it (`spmv_irregular`: SiH4 replicated with per-block permutations, coupling entries
     and hub rows, tests/irregular.py), at 3 blocks -- a size the oracle runs in a second: rows of 13 to 3 000 entries, a hub row
     longer than the 16 KiB tile (the long-row path).  One lane per row: the reference's sequential sum, bit for bit; the autotuned
     kernel and its Jacobi sweeps within the stated tolerances."""
     from tests import irregular
+    monkeypatch.setenv("SAENA_KEEP_HOST_VALUES", "1")       # variants are switched after the autotune below
     r, c, v, M = irregular.sih4_replicated(3)
     A = orc.OracleOp(orc.coo_from_arrays(r, c, v), M, M, orc.split_even(M, 1))
     G = util.gpu_operator(A)
@@ -970,6 +985,14 @@ def test_config5_irregular_operator_against_the_oracle(capi):
     G.jacobi(3, dx, dr)
     wj = A.jacobi(3, x, rhs)
     assert rel(dx.download(), wj) <= 1e-12
+    for v_, lanes in ((10, 8), (16, 4), (16, 8), (16, 16)):  # x in LDS, one / four rows per group step: what the autotune weighs on this operator
+        G.set_variant(v_)
+        G.set_lanes_per_row(lanes)
+        dx.upload(x)
+        G.spmv(dx, dy)
+        assert np.all(np.abs(dy.download() - want) <= 1e-13 * bound), (v_, lanes)
+        G.jacobi(3, dx, dr)
+        assert rel(dx.download(), wj) <= 1e-12, (v_, lanes)
 
 
 def test_plan_cache_honours_every_variant_the_autotune_can_store(capi, tmp_path, monkeypatch):
@@ -996,11 +1019,11 @@ def test_plan_cache_honours_every_variant_the_autotune_can_store(capi, tmp_path,
     dx, dy = capi.DeviceVector(M, x), capi.DeviceVector(M)
     G2.spmv(dx, dy)
     np.testing.assert_array_equal(dy.download(), A.matvec(x))         # sequential row sum: the oracle's bit for bit
-    f[1] = "16"                                              # beyond the table: ignored (tuned afresh, one more line)
+    f[1] = "17"                                              # beyond the table: ignored (tuned afresh, one more line)
     cache.write_text("\t".join(f) + "\n")
     G3 = util.gpu_operator(A)
     G3.autotune()
-    assert G3.variant()[0] <= 15 and len(cache.read_text().strip().splitlines()) == 2
+    assert G3.variant()[0] <= 16 and len(cache.read_text().strip().splitlines()) == 2
 
 
 def test_wave_streamed_kernel_keeps_a_nan_in_the_rows_that_own_it(capi):

@@ -84,22 +84,24 @@ def test_bench_four_ranks_rehearsal_with_vcycle_legs():
     assert max(vb["rows_per_gpu"]) <= 1.05 * sum(vb["rows_per_gpu"]) / 4 < max(v["rows_per_gpu"])
 
 
-def test_bench_six_ranks_rehearsal_of_the_whole_multi_gpu_run():
-    """The largest rank count one card allows (the GPU box admits at most 6 processes on its card; configs[3] has 8, whose
-    row-distributed setup runs at 8 ranks over the shared-memory communicator in tests/test_amg_setup.py without a GPU): the whole
-    `bench.py --gpus 6` run, all ranks on this card through the host transport --
+def test_bench_four_ranks_rehearsal_of_the_whole_multi_gpu_run_at_128():
+    """The largest rank count one card admits for a run launched the driver's way: the GPU box allows 6 processes on its card, and
+    the test runner (which has used the card in the files before this one) and torch.distributed.run's agent are two of them -- a
+    6-rank run was killed by the box's process guard in round 4.  (configs[3] has 8 ranks: its row-distributed setup runs at 8 ranks
+    over the shared-memory communicator in tests/test_amg_setup.py without a GPU, its V-cycle at 8 emulated ranks in
+    tests/test_gpu_vcycle.py.)  The whole `bench.py --gpus 4` run, all ranks on this card through the host transport --
       * exit status 0, one JSON line, SpMV self-check incl. halo values on both partitions;
       * the strong-scaled 128^3 leg prints the reference's line (9 iterations, 5.992963e+04 -> 5.355578e-05) under the reference's
         partition AND under the finer one, history for history within 1e-10 ||r_0||;
-      * its levels go from all six ranks to every second one (the k-rank agglomeration) to rank 0 (the graph tail);
+      * its levels go from all four ranks to every second one (the k-rank agglomeration) to rank 0 (the graph tail);
       * the configs[3] leg (the cube with 1/8 of 130^3's rows per rank) converges and its host-recomputed residual passes."""
     import json
-    out = _bench_rehearsal(6, ["--grid-m", "130", "--vcycle-timeout", "900"], timeout=1150)
+    out = _bench_rehearsal(4, ["--grid-m", "130", "--vcycle-timeout", "900"], timeout=1150)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout[-3000:]
     d = json.loads(lines[0])
-    assert "vcycle_error" not in d and d["n_gpus"] == 6 and d["check"]["ok"] is True and d["balanced_partition"]["check_ok"] is True
+    assert "vcycle_error" not in d and d["n_gpus"] == 4 and d["check"]["ok"] is True and d["balanced_partition"]["check_ok"] is True
     assert d["config"]["setup_comm"].startswith("shm") or "gloo" in d["config"]["setup_comm"]
     assert d["balanced_partition"]["partition_imbalance"]["rows_max_over_mean"] <= 1.05 <= d["config"]["partition_imbalance"]["rows_max_over_mean"]
     for key in ("vcycle", "vcycle_balanced_partition"):
@@ -107,11 +109,11 @@ def test_bench_six_ranks_rehearsal_of_the_whole_multi_gpu_run():
         assert v["pcg_iterations"] == 9, (key, v["pcg_iterations"])
         assert abs(v["initial_residual"] / 5.992963e+04 - 1) < 1e-6 and abs(v["final_residual"] / 5.355578e-05 - 1) < 2e-6, (key, v["residual_history"])
         rp = v["ranks_per_level"]
-        assert rp[0] == 6 and rp[-1] == 1 and all(a >= b for a, b in zip(rp, rp[1:])), rp
-        assert any(1 < x < 6 for x in rp), f"{key}: no level lives on every k-th rank: {rp}"
+        assert rp[0] == 4 and rp[-1] == 1 and all(a >= b for a, b in zip(rp, rp[1:])), rp
+        assert any(1 < x < 4 for x in rp), f"{key}: no level lives on every k-th rank: {rp}"
     assert d["vcycle_balanced_partition"]["history_matches_reference_partition"]["ok"] is True
     w = d["vcycle_config4"]
-    assert w["relative_residual"] <= 1e-8 and w["residual_check"]["ok"] is True and w["ranks_per_level"][0] == 6
+    assert w["relative_residual"] <= 1e-8 and w["residual_check"]["ok"] is True and w["ranks_per_level"][0] == 4
 
 
 def test_bench_failure_in_a_multi_rank_leg_is_a_failing_exit_status():

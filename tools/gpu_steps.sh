@@ -10,7 +10,7 @@ while IFS='|' read -r name tmo cmd; do
     [ -z "$name" ] && continue
     echo "== $name: $cmd" | tee -a "$out/steps.log"
     t0=$(date +%s)
-    timeout -k 10 "$tmo" bash -c "$cmd" > "$out/$name.log" 2> "$out/$name.err"
+    timeout -k 10 "$tmo" bash -c "$cmd" > "$out/$name.log" 2> "$out/$name.err" < /dev/null      # (mpirun and friends read stdin: the step list is ours)
     rc=$?
     echo "== $name: status $rc after $(( $(date +%s) - t0 )) s" | tee -a "$out/steps.log"
     tail -n 3 "$out/$name.log"
