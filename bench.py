@@ -174,11 +174,11 @@ def vcycle_leg(capi, host, A, m, dist=None, check_residual=False):
         capi.check(lib.sgpu_solve_pCG(h, du.ptr, dr.ptr, C.byref(it), hist.ctypes.data_as(PD), 64))
         capi.check(lib.sgpu_device_sync())
         r2, b2 = host_residual_sq(np, host, A, du.download(), dr.download(), dist)
-        crit = {"residual_check": {"what": "||A u - rhs||_2 of the returned iterate recomputed on the host from the layout arrays (halo of u "
+        crit["residual_check"] = {"what": "||A u - rhs||_2 of the returned iterate recomputed on the host from the layout arrays (halo of u "
                                            "exchanged over the rendezvous group), relative to ||rhs||_2; criterion: <= 2 x solver_tol (the stopping "
                                            "test is on the recursively updated residual)",
                                    "host_relative_residual": float(np.sqrt(r2 / b2)), "device_relative_residual": float(hh[-1] / hh[0]),
-                                   "tol": 1e-8, "ok": bool(np.sqrt(r2 / b2) <= 2e-8)}}
+                                   "tol": 1e-8, "ok": bool(np.sqrt(r2 / b2) <= 2e-8)}
     return {**crit, "levels": S.num_levels, "rows": [x["rows"] for x in levels], "nnz": [x["nnzA"] for x in levels],
             "pcg_iterations": it.value, "pcg_iterations_per_s": round(it.value / best, 2), "pcg_solve_ms": round(best * 1e3, 3),
             "vcycles_per_s": round(1.0 / t_v, 2), "vcycle_ms": round(t_v * 1e3, 4),

@@ -1259,7 +1259,9 @@ XldsKernelFn pick_xlds(int epi, int lanes, bool halo) { return halo ? pick_xlds_
 // k_csr_xldsr: four rows per group step (short rows), 4 / 8 / 16 lanes per group
 template <int EPI, bool HALO>
 XldsKernelFn pick_xldsr_g(int lanes) {
-    return lanes <= 4 ? sk::k_csr_xlds<EPI, 4, HALO, 4> : lanes <= 8 ? sk::k_csr_xlds<EPI, 8, HALO, 4> : sk::k_csr_xlds<EPI, 16, HALO, 4>;
+    static const int rp = std::getenv("SAENA_XLDSR_RP") ? std::atoi(std::getenv("SAENA_XLDSR_RP")) : 4;     // (development: rows per group step)
+    if (rp == 8) return lanes <= 8 ? sk::k_csr_xlds<EPI, 8, HALO, 8> : lanes <= 16 ? sk::k_csr_xlds<EPI, 16, HALO, 8> : sk::k_csr_xlds<EPI, 32, HALO, 8>;
+    return lanes <= 4 ? sk::k_csr_xlds<EPI, 4, HALO, 4> : lanes <= 8 ? sk::k_csr_xlds<EPI, 8, HALO, 4> : lanes <= 16 ? sk::k_csr_xlds<EPI, 16, HALO, 4> : sk::k_csr_xlds<EPI, 32, HALO, 4>;
 }
 template <bool HALO>
 XldsKernelFn pick_xldsr_h(int epi, int lanes) {
@@ -2460,7 +2462,7 @@ int sgpu_op_autotune(sgpu_op *op) {
         const int gx = std::min(64, std::max(4, pow2floor((int)std::max(1.0, op->loc.xl_piece / 64.0))));
         for (int g : {gx / 2, gx, gx * 2}) if (g >= 4 && g <= 64) lanes_x.push_back(g);
     }
-    const std::vector<int> lanes_r = {4, 8, 16};          // k_csr_xldsr: lanes per group of four rows
+    const std::vector<int> lanes_r = {8, 16, 32};         // k_csr_xldsr: lanes per group of four rows
     std::vector<std::pair<int, int>> cands;
     for (int v : variants)
         for (int gl : (v == 10 ? lanes_x : v == 16 ? lanes_r : lanes)) {
