@@ -1166,17 +1166,26 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
             if (tid == 0) next_row = NG * RP;                     // (rewritten before the barrier above took effect for RP == 1: set again here)
             __syncthreads();
             int k = (tid / G) * RP;
+            int np0[RP], np1[RP];                                 // the NEXT step's entry ranges, fetched one step ahead
+#pragma unroll
+            for (int j = 0; j < RP; ++j) { const bool have = k + j < nr; np0[j] = have ? ts[k + j] : 0; np1[j] = have ? te[k + j] : 0; }
             while (k < nr) {
                 int p0[RP], p1[RP], a0[RP], qe[RP];               // entry range, its quad-aligned start, end of the row's quads in the group's sequence
                 int nq = 0;
 #pragma unroll
                 for (int j = 0; j < RP; ++j) {
-                    const bool have = k + j < nr;
-                    p0[j] = have ? ts[k + j] : 0; p1[j] = have ? te[k + j] : 0;
+                    p0[j] = np0[j]; p1[j] = np1[j];
                     a0[j] = p0[j] & ~3;
                     nq += p1[j] > p0[j] ? (p1[j] - a0[j] + 3) >> 2 : 0;
                     qe[j] = nq;
                 }
+                // the group's next rows and their ranges NOW, so that the counter's round trip and the range loads run under this
+                // step's stream instead of in front of the next one's (the chain of a step was: counter -> ranges -> quads -> sum -> epilogue)
+                int nk = 0;
+                if (l == 0) nk = atomicAdd(&next_row, RP);
+                const int knext = __shfl(nk, lane & ~(G - 1), 64);
+#pragma unroll
+                for (int j = 0; j < RP; ++j) { const bool have = knext + j < nr; np0[j] = have ? ts[knext + j] : 0; np1[j] = have ? te[knext + j] : 0; }
                 double sum[RP];
 #pragma unroll
                 for (int j = 0; j < RP; ++j) sum[j] = 0.0;
@@ -1229,9 +1238,7 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
                     if (t < T - 1) w.acc[r] = mine;
                     else epilogue<EPI, HALO>(a, r, mine);
                 }
-                int nk = 0;
-                if (l == 0) nk = atomicAdd(&next_row, RP);
-                k = __shfl(nk, lane & ~(G - 1), 64);
+                k = knext;
             }
         } else {
         int k = tid / G;
@@ -1702,6 +1709,34 @@ __global__ __launch_bounds__(CG_BLOCK) void k_dense_solve(const double *__restri
     }
 }
 
+
+// ---- setup: CSR order -> sliced-ELLPACK order, on the device (round 4) ----
+// The plan-time builds of k_sell / k_sellp / k_sellp2 re-ordered the values on the host and uploaded the copy (1.0 s for the
+// 558 M entries of 256^3 level 1, most of a cold "upload").  The CSR values are on the device already: a thread per row copies its
+// entries to their place in the slice layout (reads walk the row, writes of a wave are coalesced).  src is any per-entry array in
+// CSR order (values; 16-bit column codes); dst is zero-filled (padding).  mode 0: slices of 64 rows, position-major; 1: the same
+// in pairs of positions per lane (an odd last position alone); 2: slices of 128 rows, position-major (k_sellp2's row pairs).
+template <class T>
+__global__ __launch_bounds__(BLOCK) void k_sell_scatter(const T *__restrict__ src, const int *__restrict__ row_ptr, const int *__restrict__ sl_ptr,
+                                                       T *__restrict__ dst, int M, int mode) {
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= M) return;
+    const size_t q0 = (size_t)row_ptr[r];
+    const int n = row_ptr[r + 1] - row_ptr[r];
+    if (mode == 2) {
+        const int s = r >> 7, l = r & 127;
+        const size_t p = (size_t)sl_ptr[s];
+        for (int j = 0; j < n; ++j) dst[p + (size_t)j * 128 + l] = src[q0 + j];
+    } else {
+        const int s = r >> 6, l = r & 63;
+        const size_t p = (size_t)sl_ptr[s];
+        const int w = (sl_ptr[s + 1] - sl_ptr[s]) >> 6, PP = w >> 1;
+        for (int j = 0; j < n; ++j) {
+            const size_t o = mode == 0 ? p + (size_t)j * 64 + l : j < 2 * PP ? p + (size_t)(j >> 1) * 128 + (size_t)l * 2 + (j & 1) : p + (size_t)PP * 128 + l;
+            dst[o] = src[q0 + j];
+        }
+    }
+}
 
 // ---- the streaming ceiling of a byte mix (bench.py's `roofline.peak_measured`) ----
 // What the memory system of THIS device gives a kernel that moves the same bytes as an operator's sweep and does nothing else:

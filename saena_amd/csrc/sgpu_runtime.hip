@@ -157,8 +157,9 @@ struct CsrPart {
     int            *sl_base = nullptr, *sl_segptr = nullptr, *sl_ptr = nullptr;   // segment bases of all groups, group g owns [sl_segptr[g], sl_segptr[g+1])
     int             nslices = 0, sl_ob = 12;
     bool            sl_pair = false;       // two positions per lane side by side (rows of >= 16 entries), else one
-    bool            sl_ok = false;
-    char            sl_tried = 0;
+    bool            sl_ok = false;         // values AND column codes: k_sell can run
+    bool            sl_vals = false;       // the values (sl_val, sl_ptr, nslices, sl_pair): what the row-pattern forms need
+    char            sl_tried = 0, sl_vals_tried = 0;
     // row patterns on top of the sliced-ELLPACK values (variant 11, k_sellp): a 16-bit pattern id per row and the table of
     // patterns (sp_n rows of sp_w + 1 ints: length, then the columns relative to the row); shares sl_val / sl_ptr
     unsigned short *sp_pat = nullptr;
@@ -180,7 +181,7 @@ struct CsrPart {
         hipFree(spx_tab); hipFree(spx_pat); hipFree(spx_win); hipFree(spx_wgptr);                                 // (free_sellpx, declared below)
         spx_tab = spx_pat = nullptr; spx_win = spx_wgptr = nullptr; spx_ok = false; spx_tried = 0;
         hipFree(sl_val); hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr); hipFree(sl_ptr);
-        sl_val = nullptr; sl_col = sl_len = nullptr; sl_base = sl_segptr = sl_ptr = nullptr; sl_ok = false; sl_tried = 0;
+        sl_val = nullptr; sl_col = sl_len = nullptr; sl_base = sl_segptr = sl_ptr = nullptr; sl_ok = false; sl_tried = 0; sl_vals = false; sl_vals_tried = 0;
     }
     // x in LDS (variant 10): absolute 16-bit column ids and nnz-balanced row chunks, one per CU
     unsigned short *xl_col = nullptr;
@@ -548,11 +549,14 @@ int build_xlds(CsrPart &P) {
 // Sliced ELLPACK of the local part (k_sell): slices of 64 rows stored position-major in pairs of positions per lane, padded to the slice's longest row;
 // 16-bit column codes against a segment table per group of 4 slices (one workgroup), as in build_cc16.  Built only where
 // it can win: padding <= 12 % of the entries.
-int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
-    if (P.sl_ok || P.sl_tried || P.h_rp.empty()) return SGPU_OK;
-    P.sl_tried = 1;
+// (round 4) The VALUES are re-ordered on the device from the CSR values already there (k_sell_scatter: 1.0 s -> a few ms for the 558 M
+// entries of 256^3 level 1) and are all the row-pattern forms need; the 16-bit column codes -- a host pass over the entries plus
+// 2 B per entry of upload -- are made only when k_sell itself is a candidate (operators whose rows follow no patterns).
+int build_sell_values(CsrPart &P) {
+    if (P.sl_vals || P.sl_vals_tried || P.h_rp.empty() || !P.val || !P.row_ptr) return SGPU_OK;
+    P.sl_vals_tried = 1;
     const int M = P.nrows;
-    if (M == 0 || h_val_all.size() != P.h_col.size()) return SGPU_OK;
+    if (M == 0) return SGPU_OK;
     const int ns = (M + 63) / 64;
     std::vector<int> ptr((size_t)ns + 1, 0);
     int64_t tot = 0;
@@ -566,54 +570,57 @@ int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
     }
     static const double pad_limit = std::getenv("SAENA_SELL_PAD") ? atof(std::getenv("SAENA_SELL_PAD")) : 1.12;
     if ((double)tot > pad_limit * (double)P.nnz) return SGPU_OK;
-    std::vector<int> grp;                                        // row groups of one workgroup: 4 slices
-    for (int r = 0; r < M; r += 256) grp.push_back(r);
-    grp.push_back(M);
-    std::vector<unsigned short> ccol, col((size_t)tot + 64, 0), len((size_t)ns * 64, 0);
-    std::vector<int> segptr, segtab;
-    int ob = 12;
-    if (!encode_cc16(P, grp, ccol, segptr, segtab, ob)) return SGPU_OK;
-    std::vector<double> val((size_t)tot + 64, 0.0);
     // 16-byte value loads pay from a few pairs per row on, and on any operator that streams from HBM (256^3 L0, 7 entries
     // per row: 338 vs 343-350 us); the cache-resident 128^3 fine level is the one case that prefers single positions
     const bool pair = P.nnz >= 16 * (int64_t)M || 10 * P.nnz > (int64_t)256 * 1024 * 1024;
     P.sl_pair = pair;
-    const int nt = std::min(host_threads(), std::max(1, ns / 256));
-    auto work = [&](int t) {
-        const int s0 = (int)((long)ns * t / nt), s1 = (int)((long)ns * (t + 1) / nt);
-        for (int s = s0; s < s1; ++s) {
-            const int p = ptr[(size_t)s];
-            for (int r = s * 64; r < std::min(M, s * 64 + 64); ++r) {
-                const int n = P.h_rp[r + 1] - P.h_rp[r];
-                len[(size_t)r] = (unsigned short)n;
-                const int w = (ptr[(size_t)s + 1] - p) / 64, PP = w >> 1;      // positions in pairs per lane, an odd last one alone
-                for (int j = 0; j < n; ++j) {
-                    const size_t q = (size_t)P.h_rp[r] + j;
-                    const size_t o = !pair ? (size_t)p + (size_t)j * 64 + (r - s * 64)
-                                           : j < 2 * PP ? (size_t)p + (size_t)(j >> 1) * 128 + (size_t)(r - s * 64) * 2 + (j & 1)
-                                                        : (size_t)p + (size_t)PP * 128 + (r - s * 64);
-                    val[o] = h_val_all[q];
-                    col[o] = ccol[q];                             // (padding keeps code 0: slot 0, offset 0 = a valid column of the group)
-                }
-            }
-        }
-    };
-    if (nt == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
-        for (auto &x : th) x.join();
-    }
+    CHK(dev_upload(&P.sl_ptr, ptr.data(), ptr.size()));
+    const size_t nv = (size_t)tot + 64;
+    if (hipMalloc(reinterpret_cast<void **>(&P.sl_val), nv * sizeof(double)) != hipSuccess) { P.sl_val = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of %zu bytes failed", nv * sizeof(double)); }
+    HIPCHK(hipMemsetAsync(P.sl_val, 0, nv * sizeof(double), g.cs));
+    SGPU_LAUNCH(sk::k_sell_scatter<double>, dim3((M + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs, (const double *)P.val, (const int *)P.row_ptr,
+                (const int *)P.sl_ptr, P.sl_val, M, pair ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.cs));
+    P.nslices = ns;
+    P.sl_vals = true;
+    return SGPU_OK;
+}
+
+int build_sell(CsrPart &P, const std::vector<double> &) {
+    if (P.sl_ok || P.sl_tried || P.h_rp.empty()) return SGPU_OK;
+    P.sl_tried = 1;
+    CHK(build_sell_values(P));
+    if (!P.sl_vals) return SGPU_OK;
+    const int M = P.nrows, ns = P.nslices;
+    std::vector<int> grp;                                        // row groups of one workgroup: 4 slices
+    for (int r = 0; r < M; r += 256) grp.push_back(r);
+    grp.push_back(M);
+    std::vector<unsigned short> ccol, len((size_t)ns * 64, 0);
+    std::vector<int> segptr, segtab;
+    int ob = 12;
+    if (!encode_cc16(P, grp, ccol, segptr, segtab, ob)) return SGPU_OK;
+    for (int r = 0; r < M; ++r) len[(size_t)r] = (unsigned short)(P.h_rp[r + 1] - P.h_rp[r]);
+    // the codes in CSR order go up once and take the values' way into the slice layout (padding keeps code 0: slot 0, offset 0 =
+    // a valid column of the group)
+    unsigned short *d_ccol = nullptr;
+    CHK(dev_upload(&d_ccol, ccol.data(), ccol.size()));
+    struct Tmp { unsigned short *p; ~Tmp() { hipFree(p); } } tmp{d_ccol};
+    int tot = 0;
+    HIPCHK(hipMemcpy(&tot, P.sl_ptr + ns, sizeof(int), hipMemcpyDeviceToHost));
+    const size_t nc = (size_t)tot + 64;
+    if (hipMalloc(reinterpret_cast<void **>(&P.sl_col), nc * sizeof(unsigned short)) != hipSuccess) { P.sl_col = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of %zu bytes failed", nc * 2); }
+    HIPCHK(hipMemsetAsync(P.sl_col, 0, nc * sizeof(unsigned short), g.cs));
+    SGPU_LAUNCH(sk::k_sell_scatter<unsigned short>, dim3((M + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs, (const unsigned short *)d_ccol, (const int *)P.row_ptr,
+                (const int *)P.sl_ptr, P.sl_col, M, P.sl_pair ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.cs));
     if (std::getenv("SAENA_SETUP_TIMING"))
         fprintf(stderr, "[sgpu] sliced ELLPACK: %d rows, %lld entries, %.1f %% padding, columns %d+%d bits\n", M, (long long)P.nnz,
                 100.0 * ((double)tot / (double)P.nnz - 1.0), 16 - ob, ob);
-    CHK(dev_upload(&P.sl_val, val.data(), val.size()));
-    CHK(dev_upload(&P.sl_col, col.data(), col.size()));
     CHK(dev_upload(&P.sl_len, len.data(), len.size()));
     CHK(dev_upload(&P.sl_base, segtab.data(), segtab.size(), 1));
     CHK(dev_upload(&P.sl_segptr, segptr.data(), segptr.size()));
-    CHK(dev_upload(&P.sl_ptr, ptr.data(), ptr.size()));
-    P.nslices = ns;
     P.sl_ob = ob;
     P.sl_ok = true;
     return SGPU_OK;
@@ -630,7 +637,7 @@ int build_sell(CsrPart &P, const std::vector<double> &h_val_all) {
 // Ids are dealt in order of first appearance, so the tables do not depend on threads or hashing.
 constexpr int SP_MAX_TABLE = 4096;
 int build_sellp(CsrPart &P) {
-    if (P.sp_ok || P.sp_tried || !P.sl_ok || P.h_rp.empty()) return SGPU_OK;
+    if (P.sp_ok || P.sp_tried || !P.sl_vals || P.h_rp.empty()) return SGPU_OK;
     P.sp_tried = 1;
     const int M = P.nrows;
     int W = 1;
@@ -811,7 +818,7 @@ int build_sellp2(CsrPart &P, const std::vector<double> &h_val_all) {
     if (P.sp2_ok || P.sp2_tried || !P.sp_ok || P.h_rp.empty()) return SGPU_OK;
     P.sp2_tried = 1;
     const int M = P.nrows;
-    if (M < 2 || P.ncols < 2 || h_val_all.size() != P.h_col.size()) return SGPU_OK;      // (the kernel reads x 16 bytes at a time)
+    if (M < 2 || P.ncols < 2 || !P.val || !P.row_ptr) return SGPU_OK;      // (the kernel reads x 16 bytes at a time)
     const int ns = (M + 127) / 128;
     std::vector<int> ptr((size_t)ns + 1, 0);
     int64_t tot = 0;
@@ -823,16 +830,14 @@ int build_sellp2(CsrPart &P, const std::vector<double> &h_val_all) {
         ptr[(size_t)s + 1] = (int)tot;
     }
     if ((double)tot > 1.12 * (double)P.nnz) return SGPU_OK;
-    std::vector<double> val((size_t)tot + 128, 0.0);
-    saena_host::parallel_chunks<int>(ns, 64, [&](int, int s0, int s1) {
-        for (int s = s0; s < s1; ++s)
-            for (int r = s * 128; r < std::min(M, s * 128 + 128); ++r) {
-                const int p0 = P.h_rp[(size_t)r], n = P.h_rp[(size_t)r + 1] - p0, l = r - s * 128;
-                for (int j = 0; j < n; ++j) val[(size_t)ptr[(size_t)s] + (size_t)j * 128 + (size_t)l] = h_val_all[(size_t)p0 + j];
-            }
-    });
-    CHK(dev_upload(&P.sp2_val, val.data(), val.size()));
     CHK(dev_upload(&P.sp2_ptr, ptr.data(), ptr.size()));
+    const size_t nv = (size_t)tot + 128;
+    if (hipMalloc(reinterpret_cast<void **>(&P.sp2_val), nv * sizeof(double)) != hipSuccess) { P.sp2_val = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of %zu bytes failed", nv * sizeof(double)); }
+    HIPCHK(hipMemsetAsync(P.sp2_val, 0, nv * sizeof(double), g.cs));
+    SGPU_LAUNCH(sk::k_sell_scatter<double>, dim3((M + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs, (const double *)P.val, (const int *)P.row_ptr,
+                (const int *)P.sp2_ptr, P.sp2_val, M, 2);            // (round 4: from the CSR values on the device, like build_sell_values)
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.cs));
     P.sp2_nslices = ns;
     P.sp2_ok = true;
     return SGPU_OK;
@@ -2169,7 +2174,7 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
     if (!op) return fail(SGPU_ERR_ARG, "null op");
     if (variant < 0 || variant > MAX_VARIANT) return fail(SGPU_ERR_ARG, "variant must be 0..%d", MAX_VARIANT);
     if (variant == 15) {
-        CHK(build_sell(op->loc, op->h_val_all));
+        CHK(build_sell_values(op->loc));
         CHK(build_sellp(op->loc));
         CHK(build_sellpx(op->loc));
         if (!op->loc.spx_ok)
@@ -2177,7 +2182,7 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
                                       "windows of x which fit %d KiB of LDS together with the table", sk::SPX_MAXWIN, sk::SPX_LDS_BYTES / 1024);
     }
     if (variant == 14) {
-        CHK(build_sell(op->loc, op->h_val_all));
+        CHK(build_sell_values(op->loc));
         CHK(build_sellp(op->loc));
         CHK(build_sellp2(op->loc, op->h_val_all));
         if (!op->loc.sp2_ok)
@@ -2197,7 +2202,7 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
                                       "and the host copy of the values (kept until the plan-time autotune, or with SAENA_KEEP_HOST_VALUES=1)", sk::XL_MAXT);
     }
     if (variant == 11) {
-        CHK(build_sell(op->loc, op->h_val_all));
+        CHK(build_sell_values(op->loc));
         CHK(build_sellp(op->loc));
         if (!op->loc.sp_ok)
             return fail(SGPU_ERR_ARG, "the row-pattern form needs what the sliced-ELLPACK form needs and rows that follow at most %d-int's worth of "
@@ -2382,11 +2387,9 @@ int sgpu_op_autotune(sgpu_op *op) {
     //   more -- x in LDS, the wave-streamed kernel, 16-bit or 32-bit columns on tiles
     std::vector<int> variants;
     bool sell_like = false;
-    if (!op->h_val_all.empty() && !std::getenv("SAENA_NO_SELL") && (all || avg_row <= 160.0)) {    // even rows: a lane per row
-        CHK(build_sell(op->loc, op->h_val_all));
-        if (op->loc.sl_ok) {
-            variants.push_back(9);
-            sell_like = true;
+    if (!std::getenv("SAENA_NO_SELL") && (all || avg_row <= 160.0)) {                                 // even rows: a lane per row
+        CHK(build_sell_values(op->loc));                                                             // (on the device, from the CSR values: round 4)
+        if (op->loc.sl_vals) {
             if (!std::getenv("SAENA_NO_SELLP")) {                                                    // rows that repeat a few patterns: no column stream
                 CHK(build_sellp(op->loc));
                 if (op->loc.sp_ok) variants.push_back(11);
@@ -2401,11 +2404,19 @@ int sgpu_op_autotune(sgpu_op *op) {
                     CHK(build_sellpx(op->loc));
                     if (op->loc.spx_ok) variants.push_back(15);
                 }
-                if (op->loc.sp_ok && std::getenv("SAENA_ROW_TEMPLATES")) {                               // OPT-IN: rows that also repeat their values
+                if (op->loc.sp_ok && std::getenv("SAENA_ROW_TEMPLATES") && !op->h_val_all.empty()) {     // OPT-IN: rows that also repeat their values
                     CHK(build_rowt(op->loc, op->h_val_all));
                     if (op->loc.rt_ok) variants.push_back(13);
                 }
             }
+            // k_sell itself (10 B per entry: the same values + 16-bit column codes, which cost a host pass over the entries and 2 B per
+            // entry of upload) only where the rows follow no patterns -- it never beat k_sellp on an operator that has them (8 B per
+            // entry, the same structure: 128^3 level 1 137.8 against 119.3 us, profiles/r03_sellp_wide_l1_128.log)
+            if (!op->loc.sp_ok || all) {
+                CHK(build_sell(op->loc, op->h_val_all));
+                if (op->loc.sl_ok) variants.push_back(9);
+            }
+            sell_like = op->loc.sp_ok || op->loc.sl_ok;
         }
     }
     const double t_sell = now_s();
@@ -2439,11 +2450,8 @@ int sgpu_op_autotune(sgpu_op *op) {
         if (op->loc.sx_ok) variants.push_back(12);
     }
     const double t_xl = now_s();
-    if (!op->h_val_all.empty() && avg_row >= 96.0 && avg_row <= 768.0 && !std::getenv("SAENA_NO_CM")) {   // rows of a few hundred entries: column order inside the block
-        CHK(build_cm(op->loc, 1, op->h_val_all));
-        if (op->loc.cm_ok[1]) variants.push_back(8);
-    }
-    const double t_cm = now_s();
+    // (k_csr_cm, 12 B per entry, is built further down -- only where the candidates timed so far leave it a chance)
+    const double t_cm = now_s();      // (the builds end here; k_csr_cm's is timed separately below)
     if (!op->has_remote && !op->loc.h_val.empty() && (double)op->loc.nnz >= 0.5 * (double)op->loc.nrows * op->loc.ncols && build_dense(op->loc) == SGPU_OK)
         variants.push_back(5);                         // at least half full: the dense form moves fewer bytes
     // Only the LOCAL part is timed, without the halo exchange: ranks may end up with different candidate
@@ -2497,6 +2505,23 @@ int sgpu_op_autotune(sgpu_op *op) {
     std::map<std::pair<int, int>, float> est, seen;
     float best_est = 1e30f;
     for (const auto &c : cands) { float ms = 0; CHK(sample(c.first, c.second, 3, &ms)); est[c] = ms; best_est = std::min(best_est, ms); }
+    // rows of a few hundred entries: column order inside the block (k_csr_cm) -- a host pass over the entries and a 12 B per entry upload
+    // (0.6-0.9 s on the 150-200 M entry operators of 256^3).  Its best rate anywhere was 5.0 TB/s of stored bytes (256^3 L2), so it is
+    // built only where the forms timed so far are slower than its bytes at 5.2 TB/s (R1 of 256^3: 438 us against a bound of 351 -> built,
+    // wins with 384; L2: k_sellx 440 against 459 -> skipped, it measured 493)
+    const double t_cm0 = now_s();
+    if (!op->h_val_all.empty() && avg_row >= 96.0 && avg_row <= 768.0 && !std::getenv("SAENA_NO_CM") &&
+        (all || (double)best_est > 12.0 * (double)op->loc.nnz / 5.2e9)) {
+        CHK(build_cm(op->loc, 1, op->h_val_all));
+        if (op->loc.cm_ok[1])
+            for (int gl : lanes) {
+                const std::pair<int, int> c{8, gl};
+                float ms = 0;
+                CHK(sample(c.first, c.second, 3, &ms));
+                cands.push_back(c); est[c] = ms; best_est = std::min(best_est, ms);
+            }
+    }
+    const double t_cm1 = now_s();
     for (int round = 1; round < 3; ++round)
         for (const auto &c : cands) {
             if (est[c] > 1.3f * best_est && !all) continue;
@@ -2550,7 +2575,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     if (verbose)
         fprintf(stderr, "[sgpu] autotune of %d rows x %lld nnz (%.1f per row): %zu candidates, variant %d with %d lanes at %.1f us (fastest %.1f us; runner-up variant %d with %d lanes at %.1f us); sliced ELLPACK %.2f s, "
                         "16-bit columns %.2f s, x in LDS %.2f s, column order %.2f s, timing %.2f s\n", op->M, (long long)op->loc.nnz, avg_row, cands.size(), bv, bg, bms * 1e3,
-                (cm_wins ? best_cm : best) * 1e3, rv, rg, rms * 1e3, t_sell - t_begin, t_cc - t_sell, t_xl - t_cc, t_cm - t_xl, now_s() - t_cm);
+                (cm_wins ? best_cm : best) * 1e3, rv, rg, rms * 1e3, t_sell - t_begin, t_cc - t_sell, t_xl - t_cc, t_cm1 - t_cm0, now_s() - t_cm - (t_cm1 - t_cm0));
     return SGPU_OK;
 }
 
