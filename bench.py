@@ -332,7 +332,7 @@ def stored_bytes(info, kernel_name):
         return 2 * info["M"] + vec
     if kernel_name.startswith("k_sellp"):                # k_sellp, k_sellp2, their <wide> forms, k_sellpx: no column stream, a 16-bit pattern id per row
         return 8 * nnz + 2 * info["M"] + vec             # (+ a table of a few hundred ints / a few KiB per workgroup)
-    if kernel_name in ("k_sell", "k_sellx", "k_csr_xlds"):   # 16-bit column codes; k_sell: a 16-bit row length instead of the row pointer (padding < 1 % here)
+    if kernel_name in ("k_sell", "k_sellx", "k_csr_xlds", "k_csr_xldsr"):   # 16-bit column codes; k_sell: a 16-bit row length instead of the row pointer (padding < 1 % here)
         return 10 * nnz + (2 if kernel_name == "k_sell" else 4) * info["M"] + vec
     if kernel_name == "k_dense_rows":
         return 8 * info["M"] * info["N_local"] + vec
@@ -361,8 +361,10 @@ def irregular_leg(capi, host, np, comm, nblocks, sync_all):
     t_build = time.perf_counter() - t0
     op = host.device_operator(Ai)
     plan = op.block_plan(0)                              # before the autotune frees the host copies it does not need
-    if os.environ.get("SAENA_BENCH_VARIANT_IRREGULAR"):
+    if os.environ.get("SAENA_BENCH_VARIANT_IRREGULAR"):      # pinned for the rocprofv3 --pmc passes (tools/pmc_spmv_irregular.sh)
         op.set_variant(int(os.environ["SAENA_BENCH_VARIANT_IRREGULAR"]))
+        if os.environ.get("SAENA_BENCH_LANES_IRREGULAR"):
+            op.set_lanes_per_row(int(os.environ["SAENA_BENCH_LANES_IRREGULAR"]))
     else:
         op.autotune()
     info = op.info()
@@ -386,7 +388,15 @@ def irregular_leg(capi, host, np, comm, nblocks, sync_all):
     nnz = info["nnz_local"]
     B, Bj = op.algorithmic_bytes(0), op.algorithmic_bytes(1)
     ws = stored_bytes(info, kname)
-    rf = roofline_object(capi, info, kname, ms, B, B / (ms * 1e-3) / 1e9, ws, None, None, 20)
+    # bytes leaving the L2 per launch from the committed PMC passes of this leg (same kernel family only)
+    tr, tr_src, tr_k = None, None, None
+    pmc = os.path.join(ROOT, "profiles", "r04_pmc_spmv_irregular.json")
+    if nblocks == 200 and os.path.exists(pmc):
+        with open(pmc) as f:
+            pj = json.load(f)
+        if pj["bench_kernel"].split(",")[0] == kname:
+            tr, tr_src, tr_k = pj["traffic_bytes_per_launch"], "profiles/r04_pmc_spmv_irregular.json", kname
+    rf = roofline_object(capi, info, kname, ms, B, B / (ms * 1e-3) / 1e9, ws, tr, tr_src, 20, tr_k)
     out = {"workload": f"SiH4 (reference data/FloridaCollection) x {nblocks} permuted diagonal blocks + coupling + hub rows: {M} rows x {nnz} nnz; BASELINE configs[4] scaled to an HBM-bound size",
            "rows": M, "nnz": nnz, "row_lengths": lens,
            "row_block_plan": {**plan, "mean_nnz_per_block": round(plan["nnz"] / max(1, plan["blocks"]), 1),

@@ -101,6 +101,8 @@ def load(which="host"):
     """which: 'host' -> libsaena_host.so, 'gpu' -> libsaena_amd.so"""
     if which not in _libs:
         path = os.path.join(_HERE, "libsaena_host.so" if which == "host" else "libsaena_amd.so")
+        if which == "host" and os.environ.get("SAENA_HOST_LIB"):      # tools/sanitize_host.sh: the sanitizer build of the host library
+            path = os.environ["SAENA_HOST_LIB"]
         if not os.path.exists(path):
             raise SgpuError(f"{path} is missing: run __graft_entry__.build()")
         L = C.CDLL(path, mode=C.RTLD_GLOBAL)
