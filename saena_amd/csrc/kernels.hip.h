@@ -1738,6 +1738,74 @@ __global__ __launch_bounds__(BLOCK) void k_sell_scatter(const T *__restrict__ sr
     }
 }
 
+// ---- setup: the 16-bit column codes of k_csr_cc16 / k_sell, on the device (round 4) ----
+// Per row block [blk[b], blk[b + 1]) a table of the distinct column segments (col >> ob) it touches, ascending, and per entry
+// (slot in the table << ob) | (col & (2^ob - 1)).  The host did this with a few threads and uploaded 2 B per entry (1.1 s of the
+// 256^3 hierarchy's cold upload); the 32-bit columns are on the device already.  One workgroup per block: the block's segments as a
+// bitmap in LDS (CC_BM_WORDS x 32 segments cover every operator of up to 16.7 M columns at 8 offset bits), counted (pass 1: the
+// host sums the counts into segptr and sees whether every block fits 2^(16-ob) slots) and then numbered by a prefix sum over the
+// bitmap's words (pass 2: ascending segment order = the host encoder's sorted table, so both encoders produce the same arrays).
+constexpr int CC_BM_WORDS = 2048;
+__global__ __launch_bounds__(BLOCK) void k_cc16_count(const int *__restrict__ col, const int *__restrict__ row_ptr, const int *__restrict__ blk,
+                                                     int ob, int nwords, int maxseg, int *__restrict__ cnt, int *__restrict__ bad) {
+    __shared__ unsigned bm[CC_BM_WORDS];
+    __shared__ int total;
+    const int b = blockIdx.x;
+    const int p0 = row_ptr[blk[b]], p1 = row_ptr[blk[b + 1]];
+    for (int w = threadIdx.x; w < nwords; w += BLOCK) bm[w] = 0u;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    for (int p = p0 + (int)threadIdx.x; p < p1; p += BLOCK) {
+        const int sg = col[p] >> ob;
+        atomicOr(&bm[sg >> 5], 1u << (sg & 31));
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int w = threadIdx.x; w < nwords; w += BLOCK) mine += __popc(bm[w]);
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) { cnt[b] = total; if (total > maxseg) atomicOr(bad, 1); }
+}
+__global__ __launch_bounds__(BLOCK) void k_cc16_encode(const int *__restrict__ col, const int *__restrict__ row_ptr, const int *__restrict__ blk,
+                                                      int ob, int nwords, const int *__restrict__ segptr, int *__restrict__ segtab,
+                                                      unsigned short *__restrict__ ccol) {
+    __shared__ unsigned bm[CC_BM_WORDS];
+    __shared__ int pre[CC_BM_WORDS];                     // set bits in the words before this one
+    __shared__ int part[BLOCK];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int p0 = row_ptr[blk[b]], p1 = row_ptr[blk[b + 1]];
+    for (int w = tid; w < nwords; w += BLOCK) bm[w] = 0u;
+    __syncthreads();
+    for (int p = p0 + tid; p < p1; p += BLOCK) {
+        const int sg = col[p] >> ob;
+        atomicOr(&bm[sg >> 5], 1u << (sg & 31));
+    }
+    __syncthreads();
+    // exclusive prefix of the words' population counts: a thread owns a contiguous run of words
+    const int per = (nwords + BLOCK - 1) / BLOCK, w0 = tid * per, w1 = w0 + per < nwords ? w0 + per : nwords;
+    int run = 0;
+    for (int w = w0; w < w1; ++w) run += __popc(bm[w]);
+    part[tid] = run;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int t = 0; t < BLOCK; ++t) { const int v = part[t]; part[t] = acc; acc += v; } }
+    __syncthreads();
+    run = part[tid];
+    for (int w = w0; w < w1; ++w) { pre[w] = run; run += __popc(bm[w]); }
+    __syncthreads();
+    const int t0 = segptr[b];
+    for (int w = tid; w < nwords; w += BLOCK) {           // the table: segment bases in ascending order
+        unsigned m = bm[w];
+        int k = pre[w];
+        while (m) { const int bit = __ffs(m) - 1; m &= m - 1; segtab[t0 + k++] = ((w << 5) + bit) << ob; }
+    }
+    const int om = (1 << ob) - 1;
+    for (int p = p0 + tid; p < p1; p += BLOCK) {
+        const int c = col[p], sg = c >> ob;
+        const int slot = pre[sg >> 5] + __popc(bm[sg >> 5] & ((1u << (sg & 31)) - 1u));
+        ccol[p] = (unsigned short)((slot << ob) | (c & om));
+    }
+}
+
 // ---- the streaming ceiling of a byte mix (bench.py's `roofline.peak_measured`) ----
 // What the memory system of THIS device gives a kernel that moves the same bytes as an operator's sweep and does nothing else:
 // per written double a wave-coalesced run of `q` 16-byte loads per lane (the value stream: 1 KiB per wave instruction) and one

@@ -395,14 +395,64 @@ bool encode_cc16(const CsrPart &P, const std::vector<int> &blk, std::vector<unsi
     return false;
 }
 
+// The same encoding ON THE DEVICE (round 4), from the 32-bit columns already there: *ok = false when a block touches more than 256
+// segments of 256 columns (the form does not apply) or the operator has more columns than the kernels' bitmap covers (the caller
+// falls back to the host encoder).  d_blk: the row-block boundaries on the device; ccol gets nnz + 8 codes (CSR order).
+int encode_cc16_device(const CsrPart &P, const int *d_blk, int nblk, unsigned short **ccol, int **segptr_d, int **segtab_d, int *ob_out, bool *ok, bool *host_fallback) {
+    *ok = false; *host_fallback = false;
+    *ccol = nullptr; *segptr_d = nullptr; *segtab_d = nullptr;
+    const int ncols = std::max(1, P.ncols);
+    if (!P.col || !P.row_ptr || nblk <= 0) { *host_fallback = true; return SGPU_OK; }
+    if (std::getenv("SAENA_HOST_CC16")) { *host_fallback = true; return SGPU_OK; }
+    int *d_cnt = nullptr, *d_bad = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_cnt), ((size_t)nblk + 1) * sizeof(int)));
+    struct Tmp { int *a, *b; ~Tmp() { hipFree(a); hipFree(b); } } tmp{d_cnt, nullptr};
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_bad), sizeof(int)));
+    tmp.b = d_bad;
+    std::vector<int> cnt((size_t)nblk), segptr((size_t)nblk + 1, 0);
+    for (int ob = 12; ob >= 8; --ob) {
+        const int maxseg = 1 << (16 - ob), nsegs_total = (ncols >> ob) + 1, nwords = (nsegs_total + 31) / 32;
+        if (nwords > sk::CC_BM_WORDS) { if (ob == 8) { *host_fallback = true; return SGPU_OK; } continue; }   // (a finer split needs a larger bitmap still)
+        HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), g.cs));
+        SGPU_LAUNCH(sk::k_cc16_count, dim3(nblk), dim3(sk::BLOCK), 0, g.cs, (const int *)P.col, (const int *)P.row_ptr, d_blk, ob, nwords, maxseg, d_cnt, d_bad);
+        HIPCHK(hipGetLastError());
+        int bad = 0;
+        HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, g.cs));
+        HIPCHK(hipStreamSynchronize(g.cs));
+        if (bad) continue;                                           // too scattered for this split: try more, smaller segments
+        HIPCHK(hipMemcpy(cnt.data(), d_cnt, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost));
+        for (int b = 0; b < nblk; ++b) segptr[(size_t)b + 1] = segptr[(size_t)b] + cnt[(size_t)b];
+        CHK(dev_upload(segptr_d, segptr.data(), segptr.size()));
+        const size_t nt = (size_t)segptr.back() + 1;
+        if (hipMalloc(reinterpret_cast<void **>(segtab_d), nt * sizeof(int)) != hipSuccess) { *segtab_d = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of the segment tables failed"); }
+        HIPCHK(hipMemsetAsync(*segtab_d, 0, nt * sizeof(int), g.cs));
+        const size_t nc = (size_t)P.nnz + 8;
+        if (hipMalloc(reinterpret_cast<void **>(ccol), nc * sizeof(unsigned short)) != hipSuccess) { *ccol = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of the column codes failed"); }
+        HIPCHK(hipMemsetAsync(*ccol, 0, nc * sizeof(unsigned short), g.cs));
+        SGPU_LAUNCH(sk::k_cc16_encode, dim3(nblk), dim3(sk::BLOCK), 0, g.cs, (const int *)P.col, (const int *)P.row_ptr, d_blk, ob, nwords, (const int *)*segptr_d, *segtab_d, *ccol);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g.cs));
+        *ob_out = ob; *ok = true;
+        return SGPU_OK;
+    }
+    return SGPU_OK;
+}
+
 int build_cc16(CsrPart &P, int k) {
     if (P.cc_ok[k] || P.cc_tried[k] || P.h_rp.empty()) return SGPU_OK;
     P.cc_tried[k] = 1;
     const std::vector<int> &blk = k ? P.h_blk_big : P.h_blk;
     if (blk.size() < 2) return SGPU_OK;
+    int ob = 12;
+    {   // on the device, from the 32-bit columns already there (round 4)
+        bool ok = false, fallback = false;
+        unsigned short *d_ccol = nullptr; int *d_segptr = nullptr, *d_segtab = nullptr;
+        CHK(encode_cc16_device(P, k ? P.blk_row_big : P.blk_row, (int)blk.size() - 1, &d_ccol, &d_segptr, &d_segtab, &ob, &ok, &fallback));
+        if (ok) { P.ccol[k] = d_ccol; P.segptr[k] = d_segptr; P.segtab[k] = d_segtab; P.cc_ob[k] = ob; P.cc_ok[k] = true; return SGPU_OK; }
+        if (!fallback) return SGPU_OK;                                    // a block touches more than 256 segments of 256 columns
+    }
     std::vector<unsigned short> ccol;
     std::vector<int> segptr, segtab;
-    int ob = 12;
     if (!encode_cc16(P, blk, ccol, segptr, segtab, ob)) return SGPU_OK;   // a block touches more than 256 segments of 256 columns
     CHK(dev_upload(&P.segtab[k], segtab.data(), segtab.size(), 1));
     CHK(dev_upload(&P.segptr[k], segptr.data(), segptr.size()));
@@ -599,12 +649,25 @@ int build_sell(CsrPart &P, const std::vector<double> &) {
     std::vector<unsigned short> ccol, len((size_t)ns * 64, 0);
     std::vector<int> segptr, segtab;
     int ob = 12;
-    if (!encode_cc16(P, grp, ccol, segptr, segtab, ob)) return SGPU_OK;
     for (int r = 0; r < M; ++r) len[(size_t)r] = (unsigned short)(P.h_rp[r + 1] - P.h_rp[r]);
-    // the codes in CSR order go up once and take the values' way into the slice layout (padding keeps code 0: slot 0, offset 0 =
-    // a valid column of the group)
+    // the codes in CSR order (made on the device where the bitmap covers the operator's columns, else on the host and uploaded)
+    // take the values' way into the slice layout (padding keeps code 0: slot 0, offset 0 = a valid column of the group)
     unsigned short *d_ccol = nullptr;
-    CHK(dev_upload(&d_ccol, ccol.data(), ccol.size()));
+    bool dev_tabs = false;
+    {
+        int *d_grp = nullptr;
+        CHK(dev_upload(&d_grp, grp.data(), grp.size()));
+        struct G { int *p; ~G() { hipFree(p); } } gfree{d_grp};
+        bool ok = false, fallback = false;
+        int *d_segptr = nullptr, *d_segtab = nullptr;
+        CHK(encode_cc16_device(P, d_grp, (int)grp.size() - 1, &d_ccol, &d_segptr, &d_segtab, &ob, &ok, &fallback));
+        if (ok) { P.sl_segptr = d_segptr; P.sl_base = d_segtab; dev_tabs = true; }
+        else if (!fallback) return SGPU_OK;
+    }
+    if (!dev_tabs) {
+        if (!encode_cc16(P, grp, ccol, segptr, segtab, ob)) return SGPU_OK;
+        CHK(dev_upload(&d_ccol, ccol.data(), ccol.size()));
+    }
     struct Tmp { unsigned short *p; ~Tmp() { hipFree(p); } } tmp{d_ccol};
     int tot = 0;
     HIPCHK(hipMemcpy(&tot, P.sl_ptr + ns, sizeof(int), hipMemcpyDeviceToHost));
@@ -619,8 +682,10 @@ int build_sell(CsrPart &P, const std::vector<double> &) {
         fprintf(stderr, "[sgpu] sliced ELLPACK: %d rows, %lld entries, %.1f %% padding, columns %d+%d bits\n", M, (long long)P.nnz,
                 100.0 * ((double)tot / (double)P.nnz - 1.0), 16 - ob, ob);
     CHK(dev_upload(&P.sl_len, len.data(), len.size()));
-    CHK(dev_upload(&P.sl_base, segtab.data(), segtab.size(), 1));
-    CHK(dev_upload(&P.sl_segptr, segptr.data(), segptr.size()));
+    if (!dev_tabs) {
+        CHK(dev_upload(&P.sl_base, segtab.data(), segtab.size(), 1));
+        CHK(dev_upload(&P.sl_segptr, segptr.data(), segptr.size()));
+    }
     P.sl_ob = ob;
     P.sl_ok = true;
     return SGPU_OK;
@@ -2500,8 +2565,9 @@ int sgpu_op_autotune(sgpu_op *op) {
         *ms /= reps;
         return SGPU_OK;
     };
-    // round 0 warms up (clocks, caches, code objects) and estimates; rounds 1 and 2 measure the candidates within 30 % of the
-    // best estimate, each keeping its better time: single 1 ms samples picked losers now and then
+    // round 0 warms up (clocks, caches, code objects) and estimates; round 1 measures the candidates within 30 % of the best
+    // estimate (>= 1 ms each); the deciding rounds then time the ones within 8 % of the fastest three more times, interleaved, >= 3 ms
+    // each, every candidate keeping its best time: single 1 ms samples picked losers now and then
     std::map<std::pair<int, int>, float> est, seen;
     float best_est = 1e30f;
     for (const auto &c : cands) { float ms = 0; CHK(sample(c.first, c.second, 3, &ms)); est[c] = ms; best_est = std::min(best_est, ms); }
@@ -2522,10 +2588,10 @@ int sgpu_op_autotune(sgpu_op *op) {
             }
     }
     const double t_cm1 = now_s();
-    for (int round = 1; round < 3; ++round)
+    for (int round = 1; round < 2; ++round)               // (ONE measuring round since round 4: the deciding rounds below re-time whatever is close)
         for (const auto &c : cands) {
             if (est[c] > 1.3f * best_est && !all) continue;
-            const int reps = std::min(48, std::max(6, (int)(1.0f / std::max(est[c], 1e-3f)) + 1));   // a measuring sample lasts >= 1 ms
+            const int reps = std::min(48, std::max(3, (int)(1.0f / std::max(est[c], 1e-3f)) + 1));   // a measuring sample lasts >= 1 ms
             float ms = 0;
             CHK(sample(c.first, c.second, reps, &ms));
             auto it = seen.find(c);
@@ -2542,7 +2608,7 @@ int sgpu_op_autotune(sgpu_op *op) {
         if (close.size() > 1)
             for (int trial = 0; trial < 3; ++trial)
                 for (const auto &c : close) {
-                    const int reps = std::min(64, std::max(8, (int)(3.0f / std::max(seen[c], 1e-3f)) + 1));
+                    const int reps = std::min(64, std::max(4, (int)(3.0f / std::max(seen[c], 1e-3f)) + 1));
                     float ms = 0;
                     CHK(sample(c.first, c.second, reps, &ms));
                     seen[c] = std::min(seen[c], ms);
