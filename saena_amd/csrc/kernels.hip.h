@@ -1806,6 +1806,30 @@ __global__ __launch_bounds__(BLOCK) void k_cc16_encode(const int *__restrict__ c
     }
 }
 
+// ---- setup: the x-in-LDS plan's window-relative 16-bit columns and (row, window) entry offsets, on the device (round 4) ----
+// One workgroup per row chunk, a thread per row: the columns ascend along a row, so the chunk's windows [cmin + w XL_MAX, ...) cut it
+// into consecutive pieces; entry p gets its column relative to its window, tab[w * rows + k] the first entry of row k in window w
+// (tab[T * rows + k] = the row's end).  The host did this with a few threads and uploaded 2 B per entry.
+__global__ __launch_bounds__(BLOCK) void k_xlds_build(const int *__restrict__ col, const int *__restrict__ row_ptr, const int *__restrict__ blk,
+                                                     const int4 *__restrict__ info, int *__restrict__ tab, unsigned short *__restrict__ xcol, int window) {
+    const int b = blockIdx.x;
+    const int r0 = blk[b], rows = blk[b + 1] - r0;
+    const int4 inf = info[b];
+    const int cmin = inf.x, T = inf.y;
+    int *tb = tab + inf.z;
+    for (int k = threadIdx.x; k < rows; k += BLOCK) {
+        const int p0 = row_ptr[r0 + k], p1 = row_ptr[r0 + k + 1];
+        int p = p0;
+        for (int w = 0; w <= T; ++w) {
+            if (w == T) { tb[(size_t)w * rows + k] = p1; break; }
+            const int lim = cmin + w * window;                    // entries below lim belong to window w - 1 (none for w = 0: cmin is the chunk's smallest column)
+            while (p < p1 && col[p] < lim) { xcol[p] = (unsigned short)(col[p] - (cmin + (w - 1) * window)); ++p; }
+            tb[(size_t)w * rows + k] = p;
+        }
+        for (; p < p1; ++p) xcol[p] = (unsigned short)(col[p] - (cmin + (T - 1) * window));      // the last window takes the rest
+    }
+}
+
 // ---- the streaming ceiling of a byte mix (bench.py's `roofline.peak_measured`) ----
 // What the memory system of THIS device gives a kernel that moves the same bytes as an operator's sweep and does nothing else:
 // per written double a wave-coalesced run of `q` 16-byte loads per lane (the value stream: 1 KiB per wave instruction) and one

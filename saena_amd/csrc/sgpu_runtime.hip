@@ -557,6 +557,21 @@ int build_xlds(CsrPart &P) {
         if (tabsz > INT32_MAX / 2) return SGPU_OK;
     }
     P.xl_piece = (double)P.nnz / (double)std::max<int64_t>(1, pieces);    // mean entries per (row, window): the autotune wants >= 24
+    P.xl_blk_h = blk; P.xl_info_h = info;
+    CHK(dev_upload(&P.xl_blk, blk.data(), blk.size()));
+    CHK(dev_upload(&P.xl_info, info.data(), info.size()));
+    if (P.col && P.row_ptr && !std::getenv("SAENA_HOST_XLDS_BUILD")) {
+        // the window-relative columns and the (row, window) offsets on the device, from the 32-bit columns already there (round 4)
+        const size_t nc = P.h_col.size() + 8, ntab = (size_t)tabsz + 1;
+        if (hipMalloc(reinterpret_cast<void **>(&P.xl_col), nc * sizeof(unsigned short)) != hipSuccess) { P.xl_col = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of the x-in-LDS columns failed"); }
+        if (hipMalloc(reinterpret_cast<void **>(&P.xl_tab), ntab * sizeof(int)) != hipSuccess) { P.xl_tab = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of the x-in-LDS table failed"); }
+        HIPCHK(hipMemsetAsync(P.xl_col, 0, nc * sizeof(unsigned short), g.cs));
+        HIPCHK(hipMemsetAsync(P.xl_tab, 0, ntab * sizeof(int), g.cs));
+        SGPU_LAUNCH(sk::k_xlds_build, dim3(nb), dim3(sk::BLOCK), 0, g.cs, (const int *)P.col, (const int *)P.row_ptr, (const int *)P.xl_blk, (const int4 *)P.xl_info,
+                    P.xl_tab, P.xl_col, (int)sk::XL_MAX);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g.cs));
+    } else {
     std::vector<unsigned short> col(P.h_col.size() + 8, 0);
     std::vector<int> tab((size_t)tabsz + 1, 0);
     const int nt = std::min(host_threads(), std::max(1, nb / 8));
@@ -584,11 +599,9 @@ int build_xlds(CsrPart &P) {
         for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
         for (auto &x : th) x.join();
     }
-    P.xl_blk_h = blk; P.xl_info_h = info;
     CHK(dev_upload(&P.xl_col, col.data(), col.size()));
-    CHK(dev_upload(&P.xl_blk, blk.data(), blk.size()));
     CHK(dev_upload(&P.xl_tab, tab.data(), tab.size()));
-    CHK(dev_upload(&P.xl_info, info.data(), info.size()));
+    }
     if (maxt > 1) HIPCHK(hipMalloc(&P.xl_acc, (size_t)M * sizeof(double)));
     P.xl_nblk = nb;
     P.xl_maxt = maxt;
@@ -746,6 +759,8 @@ int build_sellp(CsrPart &P) {
             const int *c = &ctab[(size_t)cstart[(size_t)i]];
             for (int j = 0; j <= c[0]; ++j) tab[(size_t)i * (W + 1) + j] = c[j];
         }
+        // (experiment, WRONG results: every gather reads the row's own column -- what the kernel costs without the spread of its gathers)
+        if (std::getenv("SAENA_DEBUG_ZERO_OFFSETS")) for (int i = 0; i < npat; ++i) for (int j = 1; j <= W; ++j) tab[(size_t)i * (W + 1) + j] = 0;
     } else {                                                   // per group of SPW_BLOCK rows: [start of its k-th pattern in the group's table] [patterns] [one spare int]
         const int G = sk::SPW_BLOCK, ngrp = (M + G - 1) / G;
         wgptr.assign((size_t)ngrp + 1, 0);
