@@ -77,6 +77,8 @@ struct SpmvArgs {
     int                   ncols;     // k_sellp2: columns of x (its 16-byte loads stay inside the vector)
     int                   nt;        // non-temporal stream loads (k_csr_stream / cc16 / cm / wave / xlds): see ld_stream_*
     int                   nt_from;   // k_sell: first slice read with non-temporal loads (the slices before it stay in the Infinity Cache)
+    int                   uw;        // k_sellp / k_sellp2: every slice has this many positions (0: read the slice pointers) -- a slice's values then
+                                     // start at s * uw * rows-per-slice and the value loads depend on nothing the wave has to fetch first
     // in-kernel fork to the halo stream (multi-rank interior launch only, else nullptr): block 0 stores
     // *flag_x = seq when it starts -- stream order: everything earlier on the compute stream is complete, so
     // the halo stream's pack, which polls the flag, may read x.
@@ -708,7 +710,9 @@ __global__ __launch_bounds__(WIDE ? SPW_BLOCK : BLOCK) void k_sellp(const SpmvAr
     const int s = __builtin_amdgcn_readfirstlane(b0 * SPB + ((int)threadIdx.x >> 6));
     if (s >= a.nblk) return;
     const int r = s * 64 + lane;
-    const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 6;
+    int p, w;
+    if (a.uw) { w = a.uw; p = s * w * 64; }               // uniform slices (a stencil level): no slice pointers in the chain of dependent loads
+    else { p = a.cmptr[s]; w = (a.cmptr[s + 1] - p) >> 6; }
     int pid = 0;
     if (r < nrows) { if constexpr (NT) pid = __builtin_nontemporal_load(a.dst + r); else pid = a.dst[r]; }
     const int *pt = WIDE ? ptab_lds + ptab_lds[pid] : ptab_lds + pid * (a.pt_w + 1);
@@ -887,7 +891,10 @@ __global__ __launch_bounds__(SPX_BLOCK) void k_sellpx(const SpmvArgs a, int nrow
 // every slice of 128 rows holds such a lane).  Measured on that level: the fastest form on the 128^3 operator (110 against
 // k_sellp<WIDE>'s 116 and k_sellpx's 114 us), a tie on the 256^3 one (940 / 945 us; k_sellpx 890).
 constexpr int SPW2_BLOCK = 512;
-template <int EPI, bool HALO, bool NT, bool WIDE = false>
+// PRE (round 4): the epilogue's once-per-sweep operands (rhs, inv_diag, u of the lane's two rows) are fetched at the TOP of the wave, next
+// to the values, instead of after the row sums are complete -- one level less in the wave's chain of dependent memory round trips
+// (ids / pointers -> values + gathers -> epilogue operands -> store), at 12 more registers.  Jacobi and residual launches only.
+template <int EPI, bool HALO, bool NT, bool WIDE = false, bool PRE = false>
 __global__ __launch_bounds__(WIDE ? SPW2_BLOCK : BLOCK) void k_sellp2(const SpmvArgs a, int nrows) {
     constexpr int BS = WIDE ? SPW2_BLOCK : BLOCK;
     extern __shared__ int ptab_lds[];
@@ -906,7 +913,17 @@ __global__ __launch_bounds__(WIDE ? SPW2_BLOCK : BLOCK) void k_sellp2(const Spmv
     const int s = __builtin_amdgcn_readfirstlane(b0 * SPB + ((int)threadIdx.x >> 6));
     if (s >= a.nblk) return;
     const int rA = s * 128 + 2 * lane, rB = rA + 1;
-    const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 7;
+    int p, w;
+    if (a.uw) { w = a.uw; p = s * w * 128; }              // uniform slices: the value loads depend on nothing the wave has to fetch first
+    else { p = a.cmptr[s]; w = (a.cmptr[s + 1] - p) >> 7; }
+    sk_d2v pre_b = {0.0, 0.0}, pre_dg = {0.0, 0.0}, pre_u = {0.0, 0.0};
+    constexpr bool PREF = PRE && (EPI == EPI_JACOBI || EPI == EPI_RESIDUAL);
+    if constexpr (PREF) {
+        if (rB < nrows) {
+            pre_b = ld_once2<NT>(a.rhs + rA);
+            if constexpr (EPI == EPI_JACOBI) { pre_dg = ld_once2<NT>(a.inv_diag + rA); pre_u = *reinterpret_cast<const sk_d2v *>(a.u + rA); }
+        }
+    }
     unsigned ids = 0;
     if (rA < nrows) {                                               // (the id array is padded to a multiple of 128 rows)
         const unsigned *ip = reinterpret_cast<const unsigned *>(a.dst) + (rA >> 1);
@@ -967,7 +984,19 @@ __global__ __launch_bounds__(WIDE ? SPW2_BLOCK : BLOCK) void k_sellp2(const Spmv
         bool both = true;
         if constexpr (HALO)                                        // ... unless one of them is a boundary row (written by the halo stream's kernel)
             if (a.skip) both = ((a.skip[rA >> 5] >> (rA & 31)) & 3u) == 0u;      // rA is even: both bits sit in one word
-        if (both) { epilogue2<EPI, NT>(a, rA, sumA, sumB); return; }
+        if (both) {
+            if constexpr (PREF) {                                  // epilogue2's arithmetic on the operands fetched at the top
+                sk_d2v o;
+                if constexpr (EPI == EPI_RESIDUAL) { o.x = sumA - pre_b.x; o.y = sumB - pre_b.y; }
+                else {
+                    double t0 = sumA - pre_b.x, t1 = sumB - pre_b.y;
+                    t0 *= pre_dg.x * a.c0; t1 *= pre_dg.y * a.c0;
+                    o.x = pre_u.x - t0; o.y = pre_u.y - t1;
+                }
+                st_once2<NT>(a.y + rA, o);
+            } else epilogue2<EPI, NT>(a, rA, sumA, sumB);
+            return;
+        }
     }
     if (rA < nrows) epilogue<EPI, HALO, NT>(a, rA, sumA);
     if (rB < nrows) epilogue<EPI, HALO, NT>(a, rB, sumB);

@@ -157,6 +157,7 @@ struct CsrPart {
     int            *sl_base = nullptr, *sl_segptr = nullptr, *sl_ptr = nullptr;   // segment bases of all groups, group g owns [sl_segptr[g], sl_segptr[g+1])
     int             nslices = 0, sl_ob = 12;
     bool            sl_pair = false;       // two positions per lane side by side (rows of >= 16 entries), else one
+    int             sl_uw = 0, sp2_uw = 0; // every slice of 64 (k_sell / k_sellp) / 128 (k_sellp2) rows has this many positions (0: widths differ)
     bool            sl_ok = false;         // values AND column codes: k_sell can run
     bool            sl_vals = false;       // the values (sl_val, sl_ptr, nslices, sl_pair): what the row-pattern forms need
     char            sl_tried = 0, sl_vals_tried = 0;
@@ -615,6 +616,24 @@ int build_xlds(CsrPart &P) {
 // (round 4) The VALUES are re-ordered on the device from the CSR values already there (k_sell_scatter: 1.0 s -> a few ms for the 558 M
 // entries of 256^3 level 1) and are all the row-pattern forms need; the 16-bit column codes -- a host pass over the entries plus
 // 2 B per entry of upload -- are made only when k_sell itself is a candidate (operators whose rows follow no patterns).
+// all slices of `rows` rows equally wide (a stencil level)?  -> that width, 0 otherwise.  A narrower LAST slice (its rows are
+// boundary rows) is padded up: a few KiB that let the kernels compute a slice's start instead of loading it.
+int uniform_width(std::vector<int> &ptr, int rows, int64_t *tot) {
+    const int ns = (int)ptr.size() - 1;
+    if (ns < 1 || std::getenv("SAENA_NO_UNIFORM_WIDTH")) return 0;
+    const int w0 = (ptr[1] - ptr[0]) / rows;
+    if (w0 == 0) return 0;
+    for (int s = 1; s + 1 < ns; ++s) if ((ptr[(size_t)s + 1] - ptr[(size_t)s]) / rows != w0) return 0;
+    const int wl = (ptr[(size_t)ns] - ptr[(size_t)ns - 1]) / rows;
+    if (wl > w0) return 0;
+    if (wl < w0) {
+        if ((int64_t)ptr[(size_t)ns - 1] + (int64_t)w0 * rows > (int64_t)INT32_MAX - 1024) return 0;
+        ptr[(size_t)ns] = ptr[(size_t)ns - 1] + w0 * rows;
+        *tot = ptr[(size_t)ns];
+    }
+    return w0;
+}
+
 int build_sell_values(CsrPart &P) {
     if (P.sl_vals || P.sl_vals_tried || P.h_rp.empty() || !P.val || !P.row_ptr) return SGPU_OK;
     P.sl_vals_tried = 1;
@@ -633,6 +652,7 @@ int build_sell_values(CsrPart &P) {
     }
     static const double pad_limit = std::getenv("SAENA_SELL_PAD") ? atof(std::getenv("SAENA_SELL_PAD")) : 1.12;
     if ((double)tot > pad_limit * (double)P.nnz) return SGPU_OK;
+    P.sl_uw = uniform_width(ptr, 64, &tot);                       // (pads the last slice up to the others' width where that makes them all equal)
     // 16-byte value loads pay from a few pairs per row on, and on any operator that streams from HBM (256^3 L0, 7 entries
     // per row: 338 vs 343-350 us); the cache-resident 128^3 fine level is the one case that prefers single positions
     const bool pair = P.nnz >= 16 * (int64_t)M || 10 * P.nnz > (int64_t)256 * 1024 * 1024;
@@ -910,6 +930,7 @@ int build_sellp2(CsrPart &P, const std::vector<double> &h_val_all) {
         ptr[(size_t)s + 1] = (int)tot;
     }
     if ((double)tot > 1.12 * (double)P.nnz) return SGPU_OK;
+    P.sp2_uw = uniform_width(ptr, 128, &tot);
     CHK(dev_upload(&P.sp2_ptr, ptr.data(), ptr.size()));
     const size_t nv = (size_t)tot + 128;
     if (hipMalloc(reinterpret_cast<void **>(&P.sp2_val), nv * sizeof(double)) != hipSuccess) { P.sp2_val = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of %zu bytes failed", nv * sizeof(double)); }
@@ -1299,20 +1320,21 @@ XldsKernelFn pick_xlds_h(int epi, int lanes) {
         default:               return pick_xlds_g<sk::EPI_SUB, HALO>(lanes);
     }
 }
-template <bool HALO, bool NT, bool WIDE>
+template <bool HALO, bool NT, bool WIDE, bool PRE = false>
 SellKernelFn pick_sellp2_h(int epi) {
     switch (epi) {
-        case sk::EPI_SPMV:     return sk::k_sellp2<sk::EPI_SPMV, HALO, NT, WIDE>;
-        case sk::EPI_RESIDUAL: return sk::k_sellp2<sk::EPI_RESIDUAL, HALO, NT, WIDE>;
-        case sk::EPI_JACOBI:   return sk::k_sellp2<sk::EPI_JACOBI, HALO, NT, WIDE>;
-        case sk::EPI_CHEBY0:   return sk::k_sellp2<sk::EPI_CHEBY0, HALO, NT, WIDE>;
-        case sk::EPI_CHEBYK:   return sk::k_sellp2<sk::EPI_CHEBYK, HALO, NT, WIDE>;
-        case sk::EPI_RSWEEP:   return sk::k_sellp2<sk::EPI_RSWEEP, HALO, NT, WIDE>;
-        default:               return sk::k_sellp2<sk::EPI_SUB, HALO, NT, WIDE>;
+        case sk::EPI_SPMV:     return sk::k_sellp2<sk::EPI_SPMV, HALO, NT, WIDE, false>;
+        case sk::EPI_RESIDUAL: return sk::k_sellp2<sk::EPI_RESIDUAL, HALO, NT, WIDE, PRE>;
+        case sk::EPI_JACOBI:   return sk::k_sellp2<sk::EPI_JACOBI, HALO, NT, WIDE, PRE>;
+        case sk::EPI_CHEBY0:   return sk::k_sellp2<sk::EPI_CHEBY0, HALO, NT, WIDE, false>;
+        case sk::EPI_CHEBYK:   return sk::k_sellp2<sk::EPI_CHEBYK, HALO, NT, WIDE, false>;
+        case sk::EPI_RSWEEP:   return sk::k_sellp2<sk::EPI_RSWEEP, HALO, NT, WIDE, false>;
+        default:               return sk::k_sellp2<sk::EPI_SUB, HALO, NT, WIDE, false>;
     }
 }
 template <bool WIDE>
-SellKernelFn pick_sellp2(int epi, bool halo, bool nt) {
+SellKernelFn pick_sellp2(int epi, bool halo, bool nt, bool pre = false) {
+    if (pre && !halo) return nt ? pick_sellp2_h<false, true, WIDE, true>(epi) : pick_sellp2_h<false, false, WIDE, true>(epi);
     return halo ? (nt ? pick_sellp2_h<true, true, WIDE>(epi) : pick_sellp2_h<true, false, WIDE>(epi)) : (nt ? pick_sellp2_h<false, true, WIDE>(epi) : pick_sellp2_h<false, false, WIDE>(epi));
 }
 template <bool HALO, bool NT>
@@ -1370,7 +1392,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d; a.y2 = e.y2;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12; a.dst = nullptr; a.cmptr = nullptr;
-    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0; a.ncols = P.ncols; a.nt_from = 0;
+    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0; a.ncols = P.ncols; a.nt_from = 0; a.uw = 0;
     static const int nt_rt = std::getenv("SAENA_STREAM_NT") ? std::atoi(std::getenv("SAENA_STREAM_NT")) : 0;
     a.nt = nt_rt == 1 || (nt_rt == 2 && 12 * P.nnz > (int64_t)256 * 1024 * 1024) ? 1 : 0;
     const bool halo = skip != nullptr || seq != 0;
@@ -1400,11 +1422,14 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         const bool nt = nt_env2 >= 0 ? nt_env2 != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
         a.nt_from = nt ? resident_slices(P.sp2_nslices, 8.0 * (double)P.nnz / (double)std::max(1, P.sp2_nslices)) : 0;
         a.ncols = P.ncols;
+        a.uw = P.sp2_uw;
+        static const int pre_env = std::getenv("SAENA_SELLP2_PRE") ? std::atoi(std::getenv("SAENA_SELLP2_PRE")) : 1;
+        const bool pre = pre_env != 0 && !halo;
         if (P.sp_wide) {                                          // a table per workgroup: 512 threads, 8 slices of 128 rows
             a.segptr = P.sp_wgptr;
-            SGPU_LAUNCH(pick_sellp2<true>(epi, halo, nt), dim3((P.sp2_nslices + 7) / 8), dim3(sk::SPW2_BLOCK), (size_t)P.sp_w * sizeof(int), g.cs, a, P.nrows);
+            SGPU_LAUNCH(pick_sellp2<true>(epi, halo, nt, pre), dim3((P.sp2_nslices + 7) / 8), dim3(sk::SPW2_BLOCK), (size_t)P.sp_w * sizeof(int), g.cs, a, P.nrows);
         } else
-        SGPU_LAUNCH(pick_sellp2<false>(epi, halo, nt), dim3((P.sp2_nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
+        SGPU_LAUNCH(pick_sellp2<false>(epi, halo, nt, pre), dim3((P.sp2_nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
     } else if (P.variant == 13) {                                 // row templates: a thread per row, no operator stream at all
         if (!P.rt_ok) return fail(SGPU_ERR_STATE, "the row-template form was not built");
         a.blk_row = nullptr; a.nblk = 0;
@@ -1434,6 +1459,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         static const int nt_env = std::getenv("SAENA_SELLP_NT") ? std::atoi(std::getenv("SAENA_SELLP_NT")) : -1;
         const bool nt = nt_env >= 0 ? nt_env != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
         a.nt_from = nt ? resident_slices(P.nslices, 8.0 * (double)P.nnz / (double)std::max(1, P.nslices)) : 0;
+        a.uw = P.sl_uw;
         if (P.sp_wide) {                                          // a table per workgroup: 1024 threads, 16 slices of 64 rows
             a.segptr = P.sp_wgptr;
             SGPU_LAUNCH(pick_sellp(epi, halo, P.sl_pair, nt, true), dim3((P.nslices + 15) / 16), dim3(sk::SPW_BLOCK), (size_t)P.sp_w * sizeof(int), g.cs, a, P.nrows);
