@@ -77,6 +77,7 @@ struct SpmvArgs {
     int                   ncols;     // k_sellp2: columns of x (its 16-byte loads stay inside the vector)
     int                   nt;        // non-temporal stream loads (k_csr_stream / cc16 / cm / wave / xlds): see ld_stream_*
     int                   nt_from;   // k_sell: first slice read with non-temporal loads (the slices before it stay in the Infinity Cache)
+    int                   st_plain;  // non-temporal launches: store y with plain stores all the same (it is the next sweep's x)
     int                   uw;        // k_sellp / k_sellp2: every slice has this many positions (0: read the slice pointers) -- a slice's values then
                                      // start at s * uw * rows-per-slice and the value loads depend on nothing the wave has to fetch first
     // in-kernel fork to the halo stream (multi-rank interior launch only, else nullptr): block 0 stores
@@ -123,33 +124,43 @@ __device__ __forceinline__ void st_once(double *p, double v) {
     if constexpr (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
+typedef double sk_d2v_fwd __attribute__((ext_vector_type(2)));
+// the store of y in a non-temporal launch: non-temporal unless the launch asks for plain stores (SpmvArgs::st_plain -- a smoother's
+// output is the next sweep's input: a plain store leaves it in the Infinity Cache)
+template <bool NT>
+__device__ __forceinline__ void st_y(const SpmvArgs &a, double *p, double v) {
+    if constexpr (NT) { if (a.st_plain) *p = v; else __builtin_nontemporal_store(v, p); }
+    else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ void st_y2(const SpmvArgs &a, double *p, sk_d2v_fwd v);
 template <int EPI, bool HALO, bool NT = false>
 __device__ __forceinline__ void epilogue(const SpmvArgs &a, int r, double s) {
     if constexpr (HALO)
         if (a.skip && ((a.skip[r >> 5] >> (r & 31)) & 1u)) return;  // a boundary row: the halo stream's kernel writes it
     if constexpr (EPI == EPI_SPMV) {
-        st_once<NT>(a.y + r, s);
+        st_y<NT>(a, a.y + r, s);
     } else if constexpr (EPI == EPI_RESIDUAL) {
-        st_once<NT>(a.y + r, s - ld_once<NT>(a.rhs + r));
+        st_y<NT>(a, a.y + r, s - ld_once<NT>(a.rhs + r));
     } else if constexpr (EPI == EPI_JACOBI) {
         double t = s - ld_once<NT>(a.rhs + r);
         t *= ld_once<NT>(a.inv_diag + r) * a.c0;
-        st_once<NT>(a.y + r, a.u[r] - t);
+        st_y<NT>(a, a.y + r, a.u[r] - t);
     } else if constexpr (EPI == EPI_CHEBY0) {
         const double dd = (a.c0 * ld_once<NT>(a.inv_diag + r)) * (ld_once<NT>(a.rhs + r) - s);
         st_once<NT>(a.d + r, dd);
-        st_once<NT>(a.y + r, a.u[r] + dd);
+        st_y<NT>(a, a.y + r, a.u[r] + dd);
     } else if constexpr (EPI == EPI_CHEBYK) {
         const double res = (a.c0 * ld_once<NT>(a.inv_diag + r)) * (ld_once<NT>(a.rhs + r) - s);
         const double dd  = (a.c1 * ld_once<NT>(a.d + r)) + res;
         st_once<NT>(a.d + r, dd);
-        st_once<NT>(a.y + r, a.u[r] + dd);
+        st_y<NT>(a, a.y + r, a.u[r] + dd);
     } else if constexpr (EPI == EPI_SUB) {
-        st_once<NT>(a.y + r, a.y[r] - s);
+        st_y<NT>(a, a.y + r, a.y[r] - s);
     } else if constexpr (EPI == EPI_RSWEEP) {
         // the restriction's row r is the coarse level's right-hand side AND the input of that level's first sweep from a zero
         // iterate: k_zero_sweep's arithmetic, on the value just computed instead of on the one read back
-        st_once<NT>(a.y + r, s);
+        st_y<NT>(a, a.y + r, s);
         if (a.c1 != 0.0) {                                     // Chebyshev step 0 (c0 = 1 / theta): d = (c0 inv_diag) rhs, u = d
             const double dd = (a.c0 * a.inv_diag[r]) * s;
             a.d[r] = dd;
@@ -179,21 +190,26 @@ __device__ __forceinline__ void st_once2(double *p, sk_d2v v) {
     if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<sk_d2v *>(p));
     else *reinterpret_cast<sk_d2v *>(p) = v;
 }
+template <bool NT>
+__device__ __forceinline__ void st_y2(const SpmvArgs &a, double *p, sk_d2v_fwd v) {
+    if constexpr (NT) { if (a.st_plain) *reinterpret_cast<sk_d2v_fwd *>(p) = v; else __builtin_nontemporal_store(v, reinterpret_cast<sk_d2v_fwd *>(p)); }
+    else *reinterpret_cast<sk_d2v_fwd *>(p) = v;
+}
 template <int EPI, bool NT>
 __device__ __forceinline__ void epilogue2(const SpmvArgs &a, int r, double s0, double s1) {
     sk_d2v s; s.x = s0; s.y = s1;
     if constexpr (EPI == EPI_SPMV) {
-        st_once2<NT>(a.y + r, s);
+        st_y2<NT>(a, a.y + r, s);
     } else if constexpr (EPI == EPI_RESIDUAL) {
         const sk_d2v b = ld_once2<NT>(a.rhs + r);
         sk_d2v o; o.x = s.x - b.x; o.y = s.y - b.y;
-        st_once2<NT>(a.y + r, o);
+        st_y2<NT>(a, a.y + r, o);
     } else if constexpr (EPI == EPI_JACOBI) {
         const sk_d2v b = ld_once2<NT>(a.rhs + r), dg = ld_once2<NT>(a.inv_diag + r), u = *reinterpret_cast<const sk_d2v *>(a.u + r);
         double t0 = s.x - b.x, t1 = s.y - b.y;
         t0 *= dg.x * a.c0; t1 *= dg.y * a.c0;
         sk_d2v o; o.x = u.x - t0; o.y = u.y - t1;
-        st_once2<NT>(a.y + r, o);
+        st_y2<NT>(a, a.y + r, o);
     } else {                                                      // the remaining forms: per row
         epilogue<EPI, false, NT>(a, r, s0);
         epilogue<EPI, false, NT>(a, r + 1, s1);
@@ -993,7 +1009,7 @@ __global__ __launch_bounds__(WIDE ? SPW2_BLOCK : BLOCK) void k_sellp2(const Spmv
                     t0 *= pre_dg.x * a.c0; t1 *= pre_dg.y * a.c0;
                     o.x = pre_u.x - t0; o.y = pre_u.y - t1;
                 }
-                st_once2<NT>(a.y + rA, o);
+                st_y2<NT>(a, a.y + rA, o);
             } else epilogue2<EPI, NT>(a, rA, sumA, sumB);
             return;
         }

@@ -1393,6 +1393,8 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12; a.dst = nullptr; a.cmptr = nullptr;
     a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0; a.ncols = P.ncols; a.nt_from = 0; a.uw = 0;
+    static const int st_plain_env = std::getenv("SAENA_STORE_PLAIN") ? std::atoi(std::getenv("SAENA_STORE_PLAIN")) : 0;
+    a.st_plain = st_plain_env;
     static const int nt_rt = std::getenv("SAENA_STREAM_NT") ? std::atoi(std::getenv("SAENA_STREAM_NT")) : 0;
     a.nt = nt_rt == 1 || (nt_rt == 2 && 12 * P.nnz > (int64_t)256 * 1024 * 1024) ? 1 : 0;
     const bool halo = skip != nullptr || seq != 0;
