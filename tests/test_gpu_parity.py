@@ -995,6 +995,45 @@ def test_config5_irregular_operator_against_the_oracle(capi, monkeypatch):
         assert rel(dx.download(), wj) <= 1e-12, (v_, lanes)
 
 
+@pytest.mark.parametrize("name", ["poisson24", "irregular5000", "band3000_1400"])
+def test_plan_time_builds_on_the_device_equal_the_host_builds(capi, name, monkeypatch):
+    """Round 4 moved the plan-time re-orderings to the device (16-bit column codes: k_cc16_count / k_cc16_encode; the x-in-LDS
+    plan's window-relative columns and offsets: k_xlds_build; sliced-ELLPACK values: k_sell_scatter).  The host encoders are still
+    there behind SAENA_HOST_CC16 / SAENA_HOST_XLDS_BUILD: both ways must choose the same slot/offset split and give the same bits."""
+    monkeypatch.setenv("SAENA_KEEP_HOST_VALUES", "1")
+    entries, M = get_problem(name)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    x, rhs = inputs.v2(M), inputs.rhs2(M)
+    dx, dr = capi.DeviceVector(M, x), capi.DeviceVector(M, rhs)
+
+    def run(variant, lanes):
+        G = util.gpu_operator(A)
+        try:
+            G.set_variant(variant)
+        except capi.SgpuError:
+            return None
+        G.set_lanes_per_row(lanes)
+        dy, du = capi.DeviceVector(M), capi.DeviceVector(M, x)
+        G.spmv(dx, dy)
+        G.jacobi(2, du, dr)
+        return G.variant()[1], dy.download(), du.download()
+    for variant, lanes in ((3, 1), (4, 4), (9, 1), (10, 8), (16, 8)):
+        dev = run(variant, lanes)
+        monkeypatch.setenv("SAENA_HOST_CC16", "1")
+        monkeypatch.setenv("SAENA_HOST_XLDS_BUILD", "1")
+        hst = run(variant, lanes)
+        monkeypatch.delenv("SAENA_HOST_CC16")
+        monkeypatch.delenv("SAENA_HOST_XLDS_BUILD")
+        assert (dev is None) == (hst is None), (variant, "one encoder accepts what the other refuses")
+        if dev is None:
+            continue
+        assert dev[0] == hst[0], (variant, dev[0], hst[0])            # the same slot / offset split in the kernel's name
+        np.testing.assert_array_equal(dev[1], hst[1])
+        np.testing.assert_array_equal(dev[2], hst[2])
+    bound = abs_bound(entries, M, x)
+    assert np.all(np.abs(run(3, 1)[1] - A.matvec(x)) <= TOL_SPMV * bound + 1e-300)
+
+
 def test_plan_cache_honours_every_variant_the_autotune_can_store(capi, tmp_path, monkeypatch):
     """Round-3 advisor finding: the lookup accepted variants 0..14 while the autotune can pick and store 15 (k_sellpx), so a cached
     k_sellpx line was never honoured and every process tuned again and appended another line.  Lookup, store and set_variant
