@@ -2433,6 +2433,7 @@ void finish_plan(sgpu_op *op, int bv) {
         CsrPart &L = op->loc;
         L.free_sell_columns();
         hipFree(L.sl_val); hipFree(L.sl_ptr); L.sl_val = nullptr; L.sl_ptr = nullptr;
+        L.sl_vals = false; L.sl_vals_tried = 0;                       // (a later set_variant(11) re-orders the values again, from the device's CSR copy)
     } else if (bv != 9 && bv != 11 && bv != 15 && !keep) op->loc.free_sell();
     else if ((bv == 11 || bv == 15) && !keep) op->loc.free_sell_columns();    // k_sellp / k_sellpx keep the values and the slice pointers only
     else if (bv == 9 && !keep) op->loc.free_sellp();
