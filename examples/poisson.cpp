@@ -4,9 +4,12 @@
 // Prints the residual lines the reference prints (src/saena_object_solve.cpp:2502,2681-2682).
 #include "saena.hpp"
 
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 int main(int argc, char **argv) {
     if (argc < 2) { printf("usage: %s <mx> [options.xml]\n", argv[0]); return 1; }
@@ -60,6 +63,21 @@ int main(int argc, char **argv) {
         solver.matmat(&A, &A, &C, true, true);
         if (!rank) printf("matmat: C = A*A has %d rows, %ld nnz\n", C.get_num_rows(), (long)C.get_nnz());
         C.destroy();
+        // assemble(scale = false, use_dense = true): a small band matrix stored as dense rows gives the sparse form's product
+        saena::matrix Bs(comm), Bd(comm);
+        saena::band_matrix(Bs, 600, 9);
+        for (index_t i = 0; i < 600; ++i)
+            for (index_t j = (i > 9 ? i - 9 : 0); j <= (i + 9 < 599 ? i + 9 : 599); ++j) Bd.set(i, j, 1.0 / (i + j + 1));
+        Bd.set_remove_boundary(false);
+        Bd.assemble(false, true);
+        std::vector<value_t> xv((size_t)Bs.get_num_local_rows()), ys, yd;
+        for (size_t i = 0; i < xv.size(); ++i) xv[i] = 1.0 + 0.001 * (double)i;
+        Bs.matvec(xv, ys);
+        Bd.matvec(xv, yd);
+        double dmax = 0, ymax = 0;
+        for (size_t i = 0; i < ys.size(); ++i) { dmax = std::max(dmax, std::abs(ys[i] - yd[i])); ymax = std::max(ymax, std::abs(ys[i])); }
+        if (!rank) printf("use_dense: %d rows, max |sparse - dense| / max |y| = %.2e\n", Bd.get_num_local_rows(), dmax / ymax);
+        Bs.destroy(); Bd.destroy();
     }
 
     saena::free_vector(u);

@@ -111,6 +111,7 @@ private:
     comm c_;
     saena_host::saena_matrix *m_pImpl;
     sgpu_op *dev_ = nullptr;
+    bool use_dense_ = false;       // assemble(scale, use_dense = true): the device operator as dense rows
 };
 
 class vector {

@@ -59,13 +59,14 @@ matrix::matrix() : c_(), m_pImpl(new saena_host::saena_matrix(c_.impl())) {}
 matrix::matrix(comm c) : c_(c), m_pImpl(new saena_host::saena_matrix(c.impl())) {}
 matrix::~matrix() { destroy(); }
 // copies (reference saena.cpp:14-31): the host-side matrix is copied whole; the copy builds its own device operator on first use
-matrix::matrix(const matrix &B) : add_dup(B.add_dup), c_(B.c_), m_pImpl(B.m_pImpl ? new saena_host::saena_matrix(*B.m_pImpl) : nullptr) {}
+matrix::matrix(const matrix &B) : add_dup(B.add_dup), c_(B.c_), m_pImpl(B.m_pImpl ? new saena_host::saena_matrix(*B.m_pImpl) : nullptr), use_dense_(B.use_dense_) {}
 matrix &matrix::operator=(const matrix &B) {
     if (this != &B) {
         destroy();
         c_ = B.c_;
         m_pImpl = B.m_pImpl ? new saena_host::saena_matrix(*B.m_pImpl) : nullptr;
         add_dup = B.add_dup;
+        use_dense_ = B.use_dense_;
     }
     return *this;
 }
@@ -102,7 +103,12 @@ void matrix::set_remove_boundary(bool b) { m_pImpl->remove_boundary = b; }
 void matrix::set_partition_buckets(int n) { m_pImpl->partition_buckets = n < 0 ? 0 : n; }
 int matrix::add_duplicates(bool add) { add_dup = add; m_pImpl->add_duplicates = add; return 0; }
 int matrix::assemble(bool scale, bool use_dense) {
-    if (scale || use_dense) throw std::runtime_error("saena::matrix::assemble: scale/use_dense are not on the GPU path (defaults are false in the reference's drivers)");
+    // scale: the symmetric diagonal scaling is not functional in the reference either (its solvers read inv_sq_diag_orig, which only
+    // scale_matrix(full_scale = true) fills and no call site passes true: DESIGN.md 9); its drivers pass false
+    if (scale) throw std::runtime_error("saena::matrix::assemble: scale = true is not on the GPU path (false in the reference's drivers)");
+    // use_dense (saena_matrix::use_dense -> saena_matrix_dense, src/saena_matrix_dense.cpp:181-260): this matrix's device operator is
+    // stored as dense row-major rows (k_dense_rows / k_dense_rows_halo); refused at first use when it is too large for that
+    use_dense_ = use_dense;
     m_pImpl->add_duplicates = add_dup;
     return m_pImpl->assemble();
 }
@@ -133,6 +139,7 @@ sgpu_op *matrix::device_op() {
         sgpu_op_desc d;
         fill_desc(m_pImpl->L, &m_pImpl->inv_diag, &d);
         gchk(sgpu_op_create(&d, &dev_), "sgpu_op_create");
+        if (use_dense_) gchk(sgpu_op_set_variant(dev_, 5), "saena::matrix::assemble(use_dense = true)");     // dense rows (<= 8192 rows, 64 M entries per rank)
     }
     return dev_;
 }

@@ -333,6 +333,9 @@ def test_cpp_surface_poisson_driver(capi, tmp_path):
     e, M = orc.laplacian3d(32)
     A = sp.csr_matrix((e["val"], (e["row"], e["col"])), shape=(M, M))
     assert f"matmat: C = A*A has {M} rows, {(A @ A).nnz} nnz" in txt, txt
+    # saena::matrix::assemble(scale = false, use_dense = true): dense rows on the device give the sparse form's product
+    m_ = re.search(r"use_dense: 600 rows, max \|sparse - dense\| / max \|y\| = (\S+)", txt)
+    assert m_ and float(m_.group(1)) <= 1e-14, txt
 
 
 @pytest.mark.parametrize("P_", [3, 8])
