@@ -2346,7 +2346,7 @@ int sgpu_op_set_variant(sgpu_op *op, int variant) {
 
 // ---- plan cache: what the autotune chose for an operator of this shape on this device, so that a second process picks the
 // same kernel (same summation order: bit-identical solves across processes) and skips the sweep.  One line per operator in
-// $SAENA_PLAN_CACHE, default $XDG_CACHE_HOME or ~/.cache + /saena_amd/plans-v2.tsv; SAENA_PLAN_CACHE=off disables it.
+// $SAENA_PLAN_CACHE, default $XDG_CACHE_HOME or ~/.cache + /saena_amd/plans-v3.tsv (v3: round 4 added candidate forms -- plans an older library cached must not shadow them); SAENA_PLAN_CACHE=off disables it.
 extern "C++" {                                              // (helpers with C++ types inside the extern "C" block)
 namespace {
 uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
@@ -2366,7 +2366,7 @@ std::string plan_cache_path() {
     ::mkdir(dir.c_str(), 0755);
     dir += "/saena_amd";
     ::mkdir(dir.c_str(), 0755);
-    return dir + "/plans-v2.tsv";
+    return dir + "/plans-v3.tsv";
 }
 // key: device, sizes, what the kernel does (smoother epilogue or plain product, halo mask), the row-length histogram in
 // powers of two and the column ids at 256 evenly spaced entries
