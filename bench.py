@@ -524,7 +524,7 @@ def main():
             free = st.f_bavail * st.f_frsize
         except OSError:
             free = 0
-        need = world * (4 << 30)
+        need = world * (1 << 30)                           # (a room check, not a reservation: a refusal later on falls back as well -- with_shm_fallback)
         box = [free if rank == 0 else None]                # one decision for the job: rank 0's view
         dist.broadcast_object_list(box, src=0)
         if box[0] < need:

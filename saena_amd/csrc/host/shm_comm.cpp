@@ -5,6 +5,7 @@
 #include <cerrno>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -47,6 +48,8 @@ struct ShmComm : Comm {
 
     ShmComm() { for (int i = 0; i < MAXR; ++i) { fd[i] = -1; seg[i] = nullptr; mapped[i] = 0; } }
     ~ShmComm() override {
+        if (std::getenv("SAENA_SETUP_TIMING") && mapped[rank])
+            fprintf(stderr, "[shm] rank %d: the largest exchange needed a segment of %.1f MiB\n", rank, (double)mapped[rank] / 1048576.0);
         for (int p = 0; p < MAXR; ++p) {
             if (seg[p]) munmap(seg[p], mapped[p]);
             if (fd[p] >= 0) close(fd[p]);
