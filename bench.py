@@ -524,7 +524,8 @@ def main():
             free = st.f_bavail * st.f_frsize
         except OSError:
             free = 0
-        need = world * (1 << 30)                           # (a room check, not a reservation: a refusal later on falls back as well -- with_shm_fallback)
+        need = world * (2 << 30)                           # the largest exchange of the setup is 58.5 MiB per rank at 1 M rows per rank (2 ranks, measured:
+                                                           # SAENA_SETUP_TIMING prints the segment growing), ~1 GiB at configs[3] size; a refusal later on falls back as well
         box = [free if rank == 0 else None]                # one decision for the job: rank 0's view
         dist.broadcast_object_list(box, src=0)
         if box[0] < need:

@@ -108,6 +108,8 @@ struct ShmComm : Comm {
             seg[rank] = static_cast<char *>(m);
             mapped[rank] = cap;
             ctl->r[rank].seg_size.store(cap, std::memory_order_release);
+            if (std::getenv("SAENA_SETUP_TIMING") && cap >= ((size_t)64 << 20))
+                fprintf(stderr, "[shm] rank %d: the segment grows to %.0f MiB for an exchange of %.1f MiB\n", rank, (double)cap / 1048576.0, (double)bytes / 1048576.0);
         }
         commit(bytes);
     }
