@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--irregular-blocks", type=int, default=200, help="--gpus 1: diagonal blocks of the configs[4] operator (SiH4 replicated with per-block "
                     "permutations, coupling and hub rows: tests/irregular.py; 200 -> 1 008 200 rows, 34.7 M entries; 0 = skip)")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the V-cycle / pCG leg (host AMG setup takes ~15 s)")
+    ap.add_argument("--no-config2-vcycle", action="store_true", help="--gpus 1: skip the V-cycle / pCG leg on Poisson 256^3 (BASELINE configs[2]; "
+                    "host setup of its 10-level, 1.0 G-entry hierarchy ~20 s, create + plan ~5 s)")
     ap.add_argument("--vcycle-timeout", type=float, default=480.0, help="watchdog of the multi-rank V-cycle legs, seconds")
     ap.add_argument("--config4-vcycle", action="store_true", help="(the default since round 3; kept for old command lines)")
     ap.add_argument("--no-config4-vcycle", action="store_true",
@@ -165,6 +167,18 @@ def vcycle_leg(capi, host, A, m, dist=None, check_residual=False):
     t_v = (time.perf_counter() - t0) / n
     levels = [S.level_info(l) for l in range(S.num_levels)]
     crit = {}
+    if dist is None:
+        # algorithmic bytes of one (3,3) V-cycle as sgpu_vcycle runs it (BASELINE.md section 3 per operator; every coarse level's first
+        # pre-smoothing sweep starts from u = 0 and is the 24 B/row zero sweep, not a pass over the matrix) -> its rate against the peak
+        pre, post = host.OPTIONS001["preSmooth"], host.OPTIONS001["postSmooth"]
+        tot = 0
+        for l in range(S.num_levels - 1):
+            opA, opP, opR = S.device_op(l, 0), S.device_op(l, 1), S.device_op(l, 2)
+            full = pre + post if l == 0 else pre + post - 1
+            tot += full * opA.algorithmic_bytes(1) + opA.algorithmic_bytes(2) + opP.algorithmic_bytes(0) + opR.algorithmic_bytes(0) + (0 if l == 0 else 24 * opA.M)
+        crit["vcycle_algorithmic_bytes"] = int(tot)
+        crit["vcycle_algorithmic_gbs"] = round(tot / t_v / 1e9, 1)
+        crit["vcycle_frac_of_hbm_peak"] = round(tot / t_v / 1e9 / HBM_PEAK_GBS, 4)
     if dist is not None:      # where the levels live: ranks that own rows of each level (all of them -> every k-th -> rank 0: the agglomeration)
         crit["ranks_per_level"] = [int(np.count_nonzero(np.diff(S.level_split(l)) > 0)) for l in range(S.num_levels)]
     if check_residual:
@@ -731,6 +745,13 @@ def main():
     if rank == 0:
         if world == 1 and not multi and not args.no_vcycle:
             out["vcycle"] = vcycle_leg(capi, host, A, m)
+        if world == 1 and not multi and not args.no_vcycle and not args.no_config2_vcycle and m == 128:
+            # BASELINE configs[2]: the full V-cycle with its R / P transfers on Poisson 256^3 (16.4 M rows, 10 levels, 1.0 G entries)
+            A256 = host.Matrix(comm).laplacian3D(256).assemble()
+            leg = vcycle_leg(capi, host, A256, 256)
+            leg["workload"] = "BASELINE configs[2]: Poisson 256^3, 16387064 rows, full (3,3)-Jacobi V-cycle with R / P transfers, solve_pCG, 1 MI355X"
+            out["vcycle_256"] = leg
+            A256.free()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, args.cpu_seconds)
 
