@@ -41,6 +41,13 @@ def test_round4_bench_line_roofline_is_bounded_by_construction():
     assert d["check"]["ok"] is True and d["check"]["max_rel_err"] <= 1e-13
     v = d["vcycle"]
     assert v["pcg_iterations"] == 9 and f"{v['final_residual']:.6e}" == "5.355578e-05" and f"{v['initial_residual']:.6e}" == "5.992963e+04"
+    assert 0.5 < v["vcycle_frac_of_hbm_peak"] <= 1.0 and abs(v["vcycle_algorithmic_gbs"] - v["vcycle_algorithmic_bytes"] / (v["vcycle_ms"] * 1e-3) / 1e9) < 1.0
+    # BASELINE configs[2]: the full V-cycle on Poisson 256^3, in the driver's own line since round 4
+    w = d["vcycle_256"]
+    pin = json.load(open(os.path.join(ROOT, "tests", "golden", "hierarchy_integers.json")))["poisson256"]
+    assert w["levels"] == 10 and w["rows"] == pin["rows"] and w["nnz"] == pin["nnz"]
+    assert w["pcg_iterations"] == 9 and f"{w['initial_residual']:.6e}" == "1.705086e+05" and f"{w['relative_residual']:.3e}" == "5.641e-09"
+    assert 0.5 < w["vcycle_frac_of_hbm_peak"] <= 1.0 and w["vcycle_ms"] > 0
 
 
 def test_committed_bench_line_has_the_contract_keys():
