@@ -705,8 +705,9 @@ def main():
                              f"(remote nnz per rank {halo_all})",
                 "pct_of_hbm_peak": round(B_total / sec_per_step / 1e9 / (HBM_PEAK_GBS * world) * 100, 2),
                 **({"weak_scaling_reference": "the 1-GPU figure at THIS per-GPU size is `spmv_hbm_resident` of the N=1 line (Poisson 256^3, "
-                                              "16.4 M rows, HBM-resident: 5.8-5.9 TB/s, profiles/r02_bench_n1.json); the N=1 `value` is the "
-                                              "Infinity-Cache-resident configs[1] operator (8.1 TB/s) and not the denominator of a weak-scaling ratio"}
+                                              "16.4 M rows, HBM-resident: 7.2-7.7 TB/s in algorithmic bytes, profiles/r04_bench_n1.json); the N=1 `value` "
+                                              "is the Infinity-Cache-resident configs[1] operator (8.8 TB/s) and not the denominator of a weak-scaling "
+                                              "ratio; `partition_imbalance.efficiency_cap` is what the reference's partition allows before any exchange cost"}
                    if world > 1 else {}),
             },
             **({"value_balanced": balanced["value"], "balanced_partition": balanced} if balanced else {}),
