@@ -8,7 +8,7 @@ MASTER_* from the env).  Rank 0 prints ONE JSON line.
 Workload at N=1 (BASELINE.json configs[1]): 3D 7-point Poisson 128^3 -> 126^3 = 2 000 376
 rows, 13 907 376 nnz, fp64 values / int32 indices, operator and vectors resident
 in HBM.  A step = one fine-level SpMV w = A v through sgpu_spmv (the autotuned HIP kernel,
-k_csr_cc16 here; for N>1 interior rows on the compute stream, pack + RCCL send/recv + boundary
+k_sellp here; for N>1 interior rows on the compute stream, pack + RCCL send/recv + boundary
 rows on the halo stream).  value = algorithmic bytes of all ranks' SpMVs
 / wall time.
 Workload at N>1 (BASELINE.json configs[3]): Poisson 512^3 row-partitioned by the reference's
@@ -17,8 +17,12 @@ operator (132 651 000 rows, 16.6 M rows / 116 M nnz per GPU); at N=2 and 4 it is
 those 16.6 M rows per GPU (323^3 and 407^3: weak scaling, isotropic like the 512^3 problem itself),
 neighbours exchange about one plane of the cube per side.
 
-Extra objects: `roofline` (HBM bound; kernel time from HIP events recorded on the compute stream
-around the timed launches; states whether the working set is Infinity-Cache resident),
+Extra objects: `roofline` (kernel time from HIP events recorded on the compute stream around the timed launches; `bound` says
+whether the working set is Infinity-Cache or HBM resident; the streaming ceiling of the operator's stored bytes is measured in the
+same run -- `peak_measured`, `frac_of_measured` <= 1 -- and is what a cache-resident operator's `frac` is taken against),
+`spmv_irregular` (N=1: BASELINE configs[4] at 1 M rows -- the reference's SiH4 replicated, tests/irregular.py), `vcycle_256` (N=1:
+BASELINE configs[2]), at N>1 `config.partition_imbalance`, `value_balanced` / `balanced_partition` (the same measurement under the
+opt-in finer row partition) and `vcycle_balanced_partition`,
 `spmv_hbm_resident` (N=1: the same measurement on Poisson 256^3, 1.7 GB, beyond the 256 MiB cache;
 per-GPU work of configs[3]), `check` (one more SpMV, outside the timed region, against the
 host-formed product incl. halo values), `vcycle` (pCG iterations/s and V-cycles/s on the global
