@@ -2504,8 +2504,9 @@ int sgpu_op_autotune(sgpu_op *op) {
                 if (op->loc.sp_ok) variants.push_back(11);
                 // ... and a lane per two rows: half the gathers.  With a table per workgroup (sp_wide: the 68-entry level) it wins on the
                 // operator of 128^3 (110 against 116 us, k_sellpx 114) and ties on that of 256^3 (940 / 945, k_sellpx 890), whose row-paired
-                // copy is 4.5 GB to build: tried up to 1 GB (profiles/r03_sellp_pergroup_tables.log)
-                if (op->loc.sp_ok && (!op->loc.sp_wide || op->loc.sp_bytes <= ((int64_t)1 << 30)) && !std::getenv("SAENA_NO_SELLP2")) {
+                // copy is 4.5 GB: tried up to 1 GB while that copy was made on the host (profiles/r03_sellp_pergroup_tables.log); the device
+                // makes it in milliseconds (round 4: k_sell_scatter), so up to 6 GB now -- the forms are bit-identical, the faster one is kept
+                if (op->loc.sp_ok && (!op->loc.sp_wide || op->loc.sp_bytes <= ((int64_t)6 << 30)) && !std::getenv("SAENA_NO_SELLP2")) {
                     CHK(build_sellp2(op->loc, op->h_val_all));
                     if (op->loc.sp2_ok) variants.push_back(14);
                 }
