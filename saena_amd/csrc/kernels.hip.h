@@ -1875,6 +1875,49 @@ __global__ __launch_bounds__(BLOCK) void k_xlds_build(const int *__restrict__ co
     }
 }
 
+// ---- setup: k_csr_cm's column-ordered blocks, on the device (round 4) ----
+// One workgroup per row block: the block's entries (<= CAPV) sorted by (column, CSR position) -- a bitonic sort of 64-bit keys in LDS --
+// and written out in that order: value, 16-bit column code (the k_csr_cc16 code of the same entry), the tile slot its product belongs
+// to (its CSR position relative to the block's quad-aligned start).  Padding up to whole quads: value 0 (the arrays are zero-filled),
+// the first entry's column code, the spare slot CAPV + 4.  The host did this with std::stable_sort per block and uploaded 12 B per entry.
+template <int CAPV>
+__global__ __launch_bounds__(BLOCK) void k_cm_build(const double *__restrict__ val, const int *__restrict__ col, const unsigned short *__restrict__ ccol,
+                                                   const int *__restrict__ row_ptr, const int *__restrict__ blk, const int *__restrict__ cmptr,
+                                                   double *__restrict__ cm_val, unsigned short *__restrict__ cm_col, unsigned short *__restrict__ cm_dst) {
+    __shared__ unsigned long long key[CAPV];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int p0 = row_ptr[blk[b]], n = row_ptr[blk[b + 1]] - p0, a0 = p0 & ~3;
+    int N = 1;
+    while (N < n) N <<= 1;
+    for (int i = tid; i < N; i += BLOCK)
+        key[i] = i < n ? ((unsigned long long)(unsigned)col[p0 + i] << 32) | (unsigned)i : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (N >> 1); t += BLOCK) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;      // the pair (lo, lo + j) of this stage
+                const bool up = (lo & k) == 0;
+                const unsigned long long x = key[lo], y = key[hi];
+                if ((x > y) == up) { key[lo] = y; key[hi] = x; }
+            }
+            __syncthreads();
+        }
+    const size_t o = (size_t)cmptr[b];
+    const int npad = (n + 3) & ~3;
+    const unsigned short first = n ? ccol[p0 + (int)(key[0] & 0xffffffffu)] : (unsigned short)0;
+    for (int i = tid; i < npad; i += BLOCK) {
+        if (i < n) {
+            const int p = p0 + (int)(key[i] & 0xffffffffu);
+            cm_val[o + i] = val[p];
+            cm_col[o + i] = ccol[p];
+            cm_dst[o + i] = (unsigned short)(p - a0);
+        } else {
+            cm_col[o + i] = first;
+            cm_dst[o + i] = (unsigned short)(CAPV + 4);
+        }
+    }
+}
+
 // ---- the streaming ceiling of a byte mix (bench.py's `roofline.peak_measured`) ----
 // What the memory system of THIS device gives a kernel that moves the same bytes as an operator's sweep and does nothing else:
 // per written double a wave-coalesced run of `q` 16-byte loads per lane (the value stream: 1 KiB per wave instruction) and one

@@ -468,7 +468,8 @@ int build_cm(CsrPart &P, int k, const std::vector<double> &h_val_all) {
     if (P.cm_ok[k] || P.cm_tried[k] || P.h_rp.empty()) return SGPU_OK;
     P.cm_tried[k] = 1;
     CHK(build_cc16(P, k));
-    if (!P.cc_ok[k] || h_val_all.size() != P.h_col.size()) return SGPU_OK;
+    const bool on_device = P.val && P.col && P.ccol[k] && P.row_ptr && !std::getenv("SAENA_HOST_CM_BUILD");
+    if (!P.cc_ok[k] || (!on_device && h_val_all.size() != P.h_col.size())) return SGPU_OK;
     const std::vector<int> &blk = k ? P.h_blk_big : P.h_blk;
     const int cap = k ? sk::CAP_BIG : sk::CAP;
     const int nblk = (int)blk.size() - 1;
@@ -483,6 +484,27 @@ int build_cm(CsrPart &P, int k, const std::vector<double> &h_val_all) {
         cmptr[(size_t)b + 1] = cmptr[(size_t)b] + ((n + 3) & ~3);
     }
     const size_t tot = (size_t)cmptr[(size_t)nblk];
+    if (P.val && P.col && P.ccol[k] && P.row_ptr && !std::getenv("SAENA_HOST_CM_BUILD")) {
+        // on the device (round 4): the block's entries sorted by (column, CSR position) in LDS, values and column codes taken from the
+        // arrays already there
+        CHK(dev_upload(&P.cm_ptr[k], cmptr.data(), cmptr.size()));
+        const size_t nv = tot + 8;
+        if (hipMalloc(reinterpret_cast<void **>(&P.cm_val[k]), nv * sizeof(double)) != hipSuccess) { P.cm_val[k] = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of the column-ordered values failed"); }
+        if (hipMalloc(reinterpret_cast<void **>(&P.cm_col[k]), nv * sizeof(unsigned short)) != hipSuccess) { P.cm_col[k] = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of the column-ordered codes failed"); }
+        if (hipMalloc(reinterpret_cast<void **>(&P.cm_dst[k]), nv * sizeof(unsigned short)) != hipSuccess) { P.cm_dst[k] = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of the tile slots failed"); }
+        HIPCHK(hipMemsetAsync(P.cm_val[k], 0, nv * sizeof(double), g.cs));
+        HIPCHK(hipMemsetAsync(P.cm_col[k], 0, nv * sizeof(unsigned short), g.cs));
+        HIPCHK(hipMemsetAsync(P.cm_dst[k], 0xff, nv * sizeof(unsigned short), g.cs));      // (the 8 spare entries past the end: never a valid slot)
+        const int *d_blk = k ? P.blk_row_big : P.blk_row;
+        if (k) SGPU_LAUNCH(sk::k_cm_build<sk::CAP_BIG>, dim3(nblk), dim3(sk::BLOCK), 0, g.cs, (const double *)P.val, (const int *)P.col, (const unsigned short *)P.ccol[k],
+                           (const int *)P.row_ptr, d_blk, (const int *)P.cm_ptr[k], P.cm_val[k], P.cm_col[k], P.cm_dst[k]);
+        else SGPU_LAUNCH(sk::k_cm_build<sk::CAP>, dim3(nblk), dim3(sk::BLOCK), 0, g.cs, (const double *)P.val, (const int *)P.col, (const unsigned short *)P.ccol[k],
+                         (const int *)P.row_ptr, d_blk, (const int *)P.cm_ptr[k], P.cm_val[k], P.cm_col[k], P.cm_dst[k]);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g.cs));
+        P.cm_ok[k] = true;
+        return SGPU_OK;
+    }
     // the 16-bit column codes of plan k live on the device only: re-encode on the host with the block's (sorted) table
     const int ob = P.cc_ob[k], om = (1 << ob) - 1;
     std::vector<double> val(tot + 8, 0.0);

@@ -998,8 +998,9 @@ def test_config5_irregular_operator_against_the_oracle(capi, monkeypatch):
 @pytest.mark.parametrize("name", ["poisson24", "irregular5000", "band3000_1400"])
 def test_plan_time_builds_on_the_device_equal_the_host_builds(capi, name, monkeypatch):
     """Round 4 moved the plan-time re-orderings to the device (16-bit column codes: k_cc16_count / k_cc16_encode; the x-in-LDS
-    plan's window-relative columns and offsets: k_xlds_build; sliced-ELLPACK values: k_sell_scatter).  The host encoders are still
-    there behind SAENA_HOST_CC16 / SAENA_HOST_XLDS_BUILD: both ways must choose the same slot/offset split and give the same bits."""
+    plan's window-relative columns and offsets: k_xlds_build; sliced-ELLPACK values: k_sell_scatter; k_csr_cm's column-ordered blocks:
+    k_cm_build, a bitonic sort per block in LDS).  The host encoders are still there behind SAENA_HOST_CC16 / SAENA_HOST_XLDS_BUILD /
+    SAENA_HOST_CM_BUILD: both ways must choose the same slot/offset split and give the same bits."""
     monkeypatch.setenv("SAENA_KEEP_HOST_VALUES", "1")
     entries, M = get_problem(name)
     A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
@@ -1017,13 +1018,15 @@ def test_plan_time_builds_on_the_device_equal_the_host_builds(capi, name, monkey
         G.spmv(dx, dy)
         G.jacobi(2, du, dr)
         return G.variant()[1], dy.download(), du.download()
-    for variant, lanes in ((3, 1), (4, 4), (9, 1), (10, 8), (16, 8)):
+    for variant, lanes in ((3, 1), (4, 4), (7, 1), (8, 4), (9, 1), (10, 8), (16, 8)):
         dev = run(variant, lanes)
         monkeypatch.setenv("SAENA_HOST_CC16", "1")
         monkeypatch.setenv("SAENA_HOST_XLDS_BUILD", "1")
+        monkeypatch.setenv("SAENA_HOST_CM_BUILD", "1")
         hst = run(variant, lanes)
         monkeypatch.delenv("SAENA_HOST_CC16")
         monkeypatch.delenv("SAENA_HOST_XLDS_BUILD")
+        monkeypatch.delenv("SAENA_HOST_CM_BUILD")
         assert (dev is None) == (hst is None), (variant, "one encoder accepts what the other refuses")
         if dev is None:
             continue
