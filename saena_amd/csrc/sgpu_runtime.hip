@@ -766,29 +766,79 @@ int build_sellp(CsrPart &P) {
     const size_t max_ints = (size_t)P.nnz / 8 + 65536;          // an operator whose patterns hold an eighth of its entries is not this kind of operator
     std::vector<int> ctab, cstart;                             // patterns back to back: length, then that many offsets
     std::vector<unsigned short> pat(((size_t)M + 127) / 128 * 128, 0);
-    std::unordered_map<std::string, int> ids;
-    std::string key;
-    int prev = -1, npat = 0;
-    for (int r = 0; r < M; ++r) {
-        const int p0 = P.h_rp[r], n = P.h_rp[r + 1] - p0;
-        if (prev >= 0 && ctab[(size_t)cstart[(size_t)prev]] == n) {   // most rows repeat the row before
-            const int *t = &ctab[(size_t)cstart[(size_t)prev] + 1];
-            int j = 0;
-            while (j < n && P.h_col[(size_t)p0 + j] - r == t[j]) ++j;
-            if (j == n) { pat[(size_t)r] = (unsigned short)prev; continue; }
+    int npat = 0;
+    {
+        // (round 4) on the host's threads: every thread finds the patterns of a contiguous range of rows with a dictionary of its own
+        // (local ids in order of first appearance); the ranges are then merged IN ORDER into the global dictionary, so the global ids
+        // are dealt in order of first appearance over all rows -- what the one-thread loop produced -- whatever the thread count
+        const int nt = std::max(1, std::min(host_threads(), M / 65536));
+        struct Part { std::vector<int> ctab, cstart; std::vector<int> ids; bool overflow = false; };     // ids: the local id of every row of the range
+        std::vector<Part> parts((size_t)nt);
+        auto work = [&](int t) {
+            Part &Q = parts[(size_t)t];
+            const int r0 = (int)((long)M * t / nt), r1 = (int)((long)M * (t + 1) / nt);
+            Q.ids.resize((size_t)(r1 - r0));
+            std::unordered_map<std::string, int> ids;
+            std::string key;
+            int prev = -1, np = 0;
+            for (int r = r0; r < r1; ++r) {
+                const int p0 = P.h_rp[r], n = P.h_rp[r + 1] - p0;
+                if (prev >= 0 && Q.ctab[(size_t)Q.cstart[(size_t)prev]] == n) {   // most rows repeat the row before
+                    const int *tt = &Q.ctab[(size_t)Q.cstart[(size_t)prev] + 1];
+                    int j = 0;
+                    while (j < n && P.h_col[(size_t)p0 + j] - r == tt[j]) ++j;
+                    if (j == n) { Q.ids[(size_t)(r - r0)] = prev; continue; }
+                }
+                key.assign(reinterpret_cast<const char *>(&n), sizeof n);
+                for (int j = 0; j < n; ++j) { const int o = P.h_col[(size_t)p0 + j] - r; key.append(reinterpret_cast<const char *>(&o), sizeof o); }
+                auto it = ids.find(key);
+                if (it == ids.end()) {
+                    if (np == 65535 || Q.ctab.size() + (size_t)n + 1 > max_ints) { Q.overflow = true; return; }
+                    it = ids.emplace(key, np++).first;
+                    Q.cstart.push_back((int)Q.ctab.size());
+                    Q.ctab.push_back(n);
+                    for (int j = 0; j < n; ++j) Q.ctab.push_back(P.h_col[(size_t)p0 + j] - r);
+                }
+                prev = it->second;
+                Q.ids[(size_t)(r - r0)] = prev;
+            }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
         }
-        key.assign(reinterpret_cast<const char *>(&n), sizeof n);
-        for (int j = 0; j < n; ++j) { const int o = P.h_col[(size_t)p0 + j] - r; key.append(reinterpret_cast<const char *>(&o), sizeof o); }
-        auto it = ids.find(key);
-        if (it == ids.end()) {
-            if (npat == 65535 || ctab.size() + (size_t)n + 1 > max_ints) return SGPU_OK;
-            it = ids.emplace(key, npat++).first;
-            cstart.push_back((int)ctab.size());
-            ctab.push_back(n);
-            for (int j = 0; j < n; ++j) ctab.push_back(P.h_col[(size_t)p0 + j] - r);
+        std::unordered_map<std::string, int> gids;
+        std::vector<std::vector<int>> remap((size_t)nt);
+        for (int t = 0; t < nt; ++t) {
+            const Part &Q = parts[(size_t)t];
+            if (Q.overflow) return SGPU_OK;
+            remap[(size_t)t].resize(Q.cstart.size());
+            for (size_t i = 0; i < Q.cstart.size(); ++i) {                      // the range's patterns in ITS order of first appearance
+                const int *c = &Q.ctab[(size_t)Q.cstart[i]];
+                const std::string key(reinterpret_cast<const char *>(c), ((size_t)c[0] + 1) * sizeof(int));
+                auto it = gids.find(key);
+                if (it == gids.end()) {
+                    if (npat == 65535 || ctab.size() + (size_t)c[0] + 1 > max_ints) return SGPU_OK;
+                    it = gids.emplace(key, npat++).first;
+                    cstart.push_back((int)ctab.size());
+                    ctab.insert(ctab.end(), c, c + c[0] + 1);
+                }
+                remap[(size_t)t][i] = it->second;
+            }
         }
-        prev = it->second;
-        pat[(size_t)r] = (unsigned short)prev;
+        auto fill = [&](int t) {
+            const int r0 = (int)((long)M * t / nt);
+            const Part &Q = parts[(size_t)t];
+            for (size_t i = 0; i < Q.ids.size(); ++i) pat[(size_t)r0 + i] = (unsigned short)remap[(size_t)t][(size_t)Q.ids[i]];
+        };
+        if (nt == 1) fill(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(fill, t);
+            for (auto &x : th) x.join();
+        }
     }
     if (npat == 0) return SGPU_OK;
     std::vector<int> tab, wgptr;
@@ -2633,7 +2683,7 @@ int sgpu_op_autotune(sgpu_op *op) {
         return SGPU_OK;
     };
     // round 0 warms up (clocks, caches, code objects) and estimates; round 1 measures the candidates within 30 % of the best
-    // estimate (>= 1 ms each); the deciding rounds then time the ones within 8 % of the fastest three more times, interleaved, >= 3 ms
+    // estimate (>= 1 ms each); the deciding rounds then time the ones within 8 % of the fastest three more times, interleaved, >= 2 ms
     // each, every candidate keeping its best time: single 1 ms samples picked losers now and then
     std::map<std::pair<int, int>, float> est, seen;
     float best_est = 1e30f;
@@ -2664,7 +2714,7 @@ int sgpu_op_autotune(sgpu_op *op) {
             auto it = seen.find(c);
             if (it == seen.end()) seen[c] = ms; else it->second = std::min(it->second, ms);
         }
-    // The deciding rounds (round 4): the candidates within 8 % of the fastest are timed again in three INTERLEAVED trials of >= 3 ms each,
+    // The deciding rounds (round 4): the candidates within 8 % of the fastest are timed again in three INTERLEAVED trials of >= 2 ms each,
     // every one keeping its best time -- two 1 ms samples (six launches of a 0.2 ms kernel) let the fine level of 256^3 come out as
     // k_sellp on one box and k_sellp2 on the next while their times differ by more than the spread of either (204-222 against 218-239 us).
     {
@@ -2675,7 +2725,7 @@ int sgpu_op_autotune(sgpu_op *op) {
         if (close.size() > 1)
             for (int trial = 0; trial < 3; ++trial)
                 for (const auto &c : close) {
-                    const int reps = std::min(64, std::max(4, (int)(3.0f / std::max(seen[c], 1e-3f)) + 1));
+                    const int reps = std::min(64, std::max(3, (int)(2.0f / std::max(seen[c], 1e-3f)) + 1));
                     float ms = 0;
                     CHK(sample(c.first, c.second, reps, &ms));
                     seen[c] = std::min(seen[c], ms);
