@@ -2604,6 +2604,9 @@ int sgpu_op_autotune(sgpu_op *op) {
     const double t_sell = now_s();
     const bool short_rows = sell_like && avg_row <= 128.0 && !all;
     for (int k = 0; k < 2; ++k) {
+        // (round 4) an operator whose rows follow patterns runs at 8 B per entry; the tile kernels' 10 B per entry never came within 15 % of
+        // it (256^3 L0 343 against 277 us, L1 1 190-1 270 against 890): not built, not timed, not freed
+        if (op->loc.sp_ok && !all) continue;
         if (k == 1 && (short_rows || avg_row < 16.0) && !all) continue;                              // 32 KiB tiles never won on the shortest rows (at 18 entries per
                                                                                                      // row -- P1 of 256^3 -- they do: 361 against 385 us, profiles/r03_transfers_sell_padding.log)
         CHK(build_cc16(op->loc, k));
@@ -2662,7 +2665,7 @@ int sgpu_op_autotune(sgpu_op *op) {
         }
     {                                                    // a few milliseconds of the current plan first: a process's first kernels run at ramping clocks
         float ms = 0;
-        for (int burst = 0; burst < 8 && ms < 4.0f; ++burst) {
+        for (int burst = 0; burst < 8 && ms < 2.0f; ++burst) {
             HIPCHK(hipEventRecord(e0, g.cs));
             for (int i = 0; i < 8; ++i) CHK(launch_part(op->loc, epi, x.p, y.p, e));
             HIPCHK(hipEventRecord(e1, g.cs));
@@ -2687,7 +2690,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     // each, every candidate keeping its best time: single 1 ms samples picked losers now and then
     std::map<std::pair<int, int>, float> est, seen;
     float best_est = 1e30f;
-    for (const auto &c : cands) { float ms = 0; CHK(sample(c.first, c.second, 3, &ms)); est[c] = ms; best_est = std::min(best_est, ms); }
+    for (const auto &c : cands) { float ms = 0; CHK(sample(c.first, c.second, 2, &ms)); est[c] = ms; best_est = std::min(best_est, ms); }
     // rows of a few hundred entries: column order inside the block (k_csr_cm) -- a host pass over the entries and a 12 B per entry upload
     // (0.6-0.9 s on the 150-200 M entry operators of 256^3).  Its best rate anywhere was 5.0 TB/s of stored bytes (256^3 L2), so it is
     // built only where the forms timed so far are slower than its bytes at 5.2 TB/s (R1 of 256^3: 438 us against a bound of 351 -> built,
