@@ -2576,9 +2576,10 @@ int sgpu_op_autotune(sgpu_op *op) {
                 if (op->loc.sp_ok) variants.push_back(11);
                 // ... and a lane per two rows: half the gathers.  With a table per workgroup (sp_wide: the 68-entry level) it wins on the
                 // operator of 128^3 (110 against 116 us, k_sellpx 114) and ties on that of 256^3 (940 / 945, k_sellpx 890), whose row-paired
-                // copy is 4.5 GB: tried up to 1 GB while that copy was made on the host (profiles/r03_sellp_pergroup_tables.log); the device
-                // makes it in milliseconds (round 4: k_sell_scatter), so up to 6 GB now -- the forms are bit-identical, the faster one is kept
-                if (op->loc.sp_ok && (!op->loc.sp_wide || op->loc.sp_bytes <= ((int64_t)6 << 30)) && !std::getenv("SAENA_NO_SELLP2")) {
+                // copy is 4.5 GB: tried up to 1 GB (profiles/r03_sellp_pergroup_tables.log).  (Round 4: the device makes the copy in
+                // milliseconds, but allocating and FREEING 4.5 GB costs 0.2 s of the plan and the form lost again on 256^3 -- 942 against
+                // k_sellpx's 888 us: the limit stays)
+                if (op->loc.sp_ok && (!op->loc.sp_wide || op->loc.sp_bytes <= ((int64_t)1 << 30)) && !std::getenv("SAENA_NO_SELLP2")) {
                     CHK(build_sellp2(op->loc, op->h_val_all));
                     if (op->loc.sp2_ok) variants.push_back(14);
                 }
@@ -2756,12 +2757,14 @@ int sgpu_op_autotune(sgpu_op *op) {
         if ((kv.first.first != bv || kv.first.second != bg) && (rv < 0 || kv.second < rms)) { rv = kv.first.first; rg = kv.first.second; rms = kv.second; }
     guard.armed = false;
     op->loc.variant = bv; op->loc.lanes = bg;
+    const double t_fin0 = now_s();
     finish_plan(op, bv);
+    const double t_fin1 = now_s();
     plan_cache_store(key, op, bv, bg, bms, rv, rg, rms);
     if (verbose)
         fprintf(stderr, "[sgpu] autotune of %d rows x %lld nnz (%.1f per row): %zu candidates, variant %d with %d lanes at %.1f us (fastest %.1f us; runner-up variant %d with %d lanes at %.1f us); sliced ELLPACK %.2f s, "
-                        "16-bit columns %.2f s, x in LDS %.2f s, column order %.2f s, timing %.2f s\n", op->M, (long long)op->loc.nnz, avg_row, cands.size(), bv, bg, bms * 1e3,
-                (cm_wins ? best_cm : best) * 1e3, rv, rg, rms * 1e3, t_sell - t_begin, t_cc - t_sell, t_xl - t_cc, t_cm1 - t_cm0, now_s() - t_cm - (t_cm1 - t_cm0));
+                        "16-bit columns %.2f s, x in LDS %.2f s, column order %.2f s, timing %.2f s (of which freeing the forms that lost %.2f s)\n", op->M, (long long)op->loc.nnz, avg_row, cands.size(), bv, bg, bms * 1e3,
+                (cm_wins ? best_cm : best) * 1e3, rv, rg, rms * 1e3, t_sell - t_begin, t_cc - t_sell, t_xl - t_cc, t_cm1 - t_cm0, now_s() - t_cm - (t_cm1 - t_cm0), t_fin1 - t_fin0);
     return SGPU_OK;
 }
 
