@@ -143,12 +143,17 @@ struct Reaper {
     std::thread th;
     bool started = false, stop = false, busy = false;
     int device = 0;
+    ~Reaper() {                                          // a process that ends without sgpu_finalize: the thread must not outlive the object
+        { std::lock_guard<std::mutex> lk(m); if (!started) return; quit = true; stop = true; cv.notify_one(); }
+        if (th.joinable()) th.join();
+    }
+    bool quit = false;                                   // leave what is queued to the end of the process
     void run() {
         (void)hipSetDevice(device);
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
             cv.wait(lk, [&] { return stop || !q.empty(); });
-            if (q.empty() && stop) return;
+            if (quit || (q.empty() && stop)) return;
             void *p = q.front(); q.pop_front();
             busy = true;
             lk.unlock();
