@@ -2580,7 +2580,16 @@ void finish_plan(sgpu_op *op, int bv) {
     if (bv != 12 && !keep) op->loc.free_sellx();
     if (bv != 10 && bv != 12 && bv != 16 && !keep) op->loc.free_xlds();
     else if (bv == 12 && !keep) { dev_free(op->loc.xl_col); dev_free(op->loc.xl_tab); op->loc.xl_col = nullptr; op->loc.xl_tab = nullptr; }      // k_sellx keeps the chunk plan only
-    if (!keep) std::vector<double>().swap(op->h_val_all);       // (a later set_variant(7/8/9/11) on this operator is refused: the values are gone)
+    // the host copy of the values goes (the forms that still need it -- k_sellx, k_rowt -- are refused from here on).  Unmapping 4.5 GB
+    // of resident host memory takes 0.25 s (the 558 M-entry level: most of what the autotune's log called "freeing"): a detached
+    // thread does it, like the host setup's own large temporaries
+    if (!keep && !op->h_val_all.empty()) {
+        if (op->h_val_all.size() >= ((size_t)1 << 22) && !std::getenv("SAENA_NO_ASYNC_FREE")) {
+            auto *junk = new std::vector<double>(std::move(op->h_val_all));
+            std::thread([junk] { delete junk; }).detach();
+        }
+        std::vector<double>().swap(op->h_val_all);
+    }
     for (int k = 0; k < 2 && !keep; ++k)              // free the compressed arrays of the plans that lost
         if (op->loc.cc_ok[k] && bv != 3 + k && bv != 7 + k) {
             dev_free(op->loc.segtab[k]); dev_free(op->loc.segptr[k]); dev_free(op->loc.ccol[k]);
