@@ -17,9 +17,6 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
-#include <deque>
-#include <condition_variable>
-#include <mutex>
 #include <map>
 #include <atomic>
 #include <csignal>
@@ -132,65 +129,6 @@ int dev_upload(T **dst, const T *src, size_t n, size_t pad = 0) {
     return SGPU_OK;
 }
 
-// Frees of the forms that lose a plan-time autotune: hipFree of a multi-gigabyte buffer takes 50-250 ms (0.7 s of the 256^3
-// hierarchy's cold upload, profiles/r04_vcycle256_autotune_phases_final.log), and nothing waits for the memory.  Inside a DeferFrees
-// scope dev_free() hands the pointer to one background thread, which frees in order; sgpu_finalize (and an allocation that fails)
-// drain it.  Outside such a scope dev_free is hipFree.
-struct Reaper {
-    std::mutex m;
-    std::condition_variable cv, idle;
-    std::deque<void *> q;
-    std::thread th;
-    bool started = false, stop = false, busy = false;
-    int device = 0;
-    ~Reaper() {                                          // a process that ends without sgpu_finalize: the thread must not outlive the object
-        { std::lock_guard<std::mutex> lk(m); if (!started) return; quit = true; stop = true; cv.notify_one(); }
-        if (th.joinable()) th.join();
-    }
-    bool quit = false;                                   // leave what is queued to the end of the process
-    void run() {
-        (void)hipSetDevice(device);
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-            cv.wait(lk, [&] { return stop || !q.empty(); });
-            if (quit || (q.empty() && stop)) return;
-            void *p = q.front(); q.pop_front();
-            busy = true;
-            lk.unlock();
-            (void)hipFree(p);
-            lk.lock();
-            busy = false;
-            if (q.empty()) idle.notify_all();
-        }
-    }
-    void push(void *p, int dev) {
-        if (!p) return;
-        std::lock_guard<std::mutex> lk(m);
-        if (!started) { device = dev; stop = false; th = std::thread([this] { run(); }); started = true; }
-        q.push_back(p);
-        cv.notify_one();
-    }
-    void drain() {
-        std::unique_lock<std::mutex> lk(m);
-        if (!started) return;
-        idle.wait(lk, [&] { return q.empty() && !busy; });
-    }
-    void shutdown() {
-        { std::unique_lock<std::mutex> lk(m); if (!started) return; idle.wait(lk, [&] { return q.empty() && !busy; }); stop = true; cv.notify_one(); }
-        th.join();
-        started = false;
-    }
-};
-static Reaper g_reaper;
-static thread_local int g_defer_frees = 0;
-static int g_reaper_device = 0;
-struct DeferFrees { DeferFrees() { if (!std::getenv("SAENA_NO_DEFERRED_FREE")) ++g_defer_frees; else armed = false; } ~DeferFrees() { if (armed) --g_defer_frees; } bool armed = true; };
-static inline void dev_free(void *p) {
-    if (!p) return;
-    if (g_defer_frees > 0) g_reaper.push(p, g_reaper_device);
-    else (void)hipFree(p);
-}
-
 // One CSR part (local, or remote-over-halo) laid out for k_csr_stream.
 struct CsrPart {
     int     nrows = 0;            // rows covered by row_ptr (M, or number of remote rows)
@@ -232,18 +170,18 @@ struct CsrPart {
     int64_t         sp_bytes = 0;      // values + pattern ids + x + y as this form stores them
     bool            sp_ok = false, sp_wide = false;   // sp_wide: a table per group of 1024 rows (k_sellp<WIDE>; sp_w = the largest, in ints)
     char            sp_tried = 0;
-    void free_sellp() { dev_free(sp_pat); dev_free(sp_tab); dev_free(sp_wgptr); sp_pat = nullptr; sp_tab = nullptr; sp_wgptr = nullptr; sp_ok = false; sp_wide = false; sp_tried = 0; }      // (and k_sellpx with it: free_sell)
+    void free_sellp() { hipFree(sp_pat); hipFree(sp_tab); hipFree(sp_wgptr); sp_pat = nullptr; sp_tab = nullptr; sp_wgptr = nullptr; sp_ok = false; sp_wide = false; sp_tried = 0; }      // (and k_sellpx with it: free_sell)
     // the column codes of k_sell alone (k_sellp keeps the values and the slice pointers)
     void free_sell_columns() {
-        dev_free(sl_col); dev_free(sl_len); dev_free(sl_base); dev_free(sl_segptr);
+        hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr);
         sl_col = sl_len = nullptr; sl_base = sl_segptr = nullptr;
         sl_ok = false;                                             // (variant 9 is gone for good: sl_tried stays set)
     }
     void free_sell() {
         free_sellp();
-        dev_free(spx_tab); dev_free(spx_pat); dev_free(spx_win); dev_free(spx_wgptr);                                 // (free_sellpx, declared below)
+        hipFree(spx_tab); hipFree(spx_pat); hipFree(spx_win); hipFree(spx_wgptr);                                 // (free_sellpx, declared below)
         spx_tab = spx_pat = nullptr; spx_win = spx_wgptr = nullptr; spx_ok = false; spx_tried = 0;
-        dev_free(sl_val); dev_free(sl_col); dev_free(sl_len); dev_free(sl_base); dev_free(sl_segptr); dev_free(sl_ptr);
+        hipFree(sl_val); hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr); hipFree(sl_ptr);
         sl_val = nullptr; sl_col = sl_len = nullptr; sl_base = sl_segptr = sl_ptr = nullptr; sl_ok = false; sl_tried = 0; sl_vals = false; sl_vals_tried = 0;
     }
     // x in LDS (variant 10): absolute 16-bit column ids and nnz-balanced row chunks, one per CU
@@ -258,7 +196,7 @@ struct CsrPart {
     bool            xl_ok = false;
     char            xl_tried = 0;
     void free_xlds() {
-        dev_free(xl_col); dev_free(xl_blk); dev_free(xl_tab); dev_free(xl_info); dev_free(xl_acc);
+        hipFree(xl_col); hipFree(xl_blk); hipFree(xl_tab); hipFree(xl_info); hipFree(xl_acc);
         xl_col = nullptr; xl_blk = xl_tab = nullptr; xl_info = nullptr; xl_acc = nullptr; xl_ok = false; xl_tried = 0;
     }
     // k_sellp with a lane per two rows (variant 14, k_sellp2): the values row-paired in slices of 128 rows; shares sp_pat / sp_tab
@@ -267,7 +205,7 @@ struct CsrPart {
     int             sp2_nslices = 0;
     bool            sp2_ok = false;
     char            sp2_tried = 0;
-    void free_sellp2() { dev_free(sp2_val); dev_free(sp2_ptr); sp2_val = nullptr; sp2_ptr = nullptr; sp2_ok = false; sp2_tried = 0; }
+    void free_sellp2() { hipFree(sp2_val); hipFree(sp2_ptr); sp2_val = nullptr; sp2_ptr = nullptr; sp2_ok = false; sp2_tried = 0; }
     // k_sellp with x in LDS windows (variant 15, k_sellpx): the table as 16-bit LDS positions, the windows of x per workgroup;
     // shares sl_val / sl_ptr / sp_pat.  h_pstart / h_ptab: host copy of the patterns (start of each, then length + offsets), kept
     // until the plan settles
@@ -278,7 +216,7 @@ struct CsrPart {
     bool            spx_ok = false;
     char            spx_tried = 0;
     void free_sellpx() {
-        dev_free(spx_tab); dev_free(spx_pat); dev_free(spx_win); dev_free(spx_wgptr);
+        hipFree(spx_tab); hipFree(spx_pat); hipFree(spx_win); hipFree(spx_wgptr);
         spx_tab = spx_pat = nullptr; spx_win = spx_wgptr = nullptr; spx_ok = false; spx_tried = 0;
     }
     // row templates (variant 13, k_rowt, opt-in): a template id per row; tables of (length, relative columns) and of values
@@ -288,7 +226,7 @@ struct CsrPart {
     int             rt_w = 0, rt_n = 0;
     bool            rt_ok = false;
     char            rt_tried = 0;
-    void free_rowt() { dev_free(rt_pat); dev_free(rt_itab); dev_free(rt_vtab); rt_pat = nullptr; rt_itab = nullptr; rt_vtab = nullptr; rt_ok = false; rt_tried = 0; }
+    void free_rowt() { hipFree(rt_pat); hipFree(rt_itab); hipFree(rt_vtab); rt_pat = nullptr; rt_itab = nullptr; rt_vtab = nullptr; rt_ok = false; rt_tried = 0; }
     // sliced ELLPACK inside the (chunk, window) blocks of the x-in-LDS form (variant 12, k_sellx): shares xl_blk / xl_info / xl_acc
     double         *sx_val = nullptr;
     unsigned short *sx_col = nullptr;
@@ -298,17 +236,17 @@ struct CsrPart {
     bool            sx_ok = false;
     char            sx_tried = 0;
     void free_sellx() {
-        dev_free(sx_val); dev_free(sx_col); dev_free(sx_meta); dev_free(sx_bptr); dev_free(sx_sptr);
+        hipFree(sx_val); hipFree(sx_col); hipFree(sx_meta); hipFree(sx_bptr); hipFree(sx_sptr);
         sx_val = nullptr; sx_col = nullptr; sx_meta = nullptr; sx_bptr = sx_sptr = nullptr; sx_ok = false; sx_tried = 0;
     }
     int             cc_ob[2] = {12, 12};   // offset bits of the slot/offset split (12: 16 segments of 4096 columns ... 8: 256 of 256)
     char            cc_tried[2] = {0, 0};  // build_cc16 ran and found no split that fits (do not try again)
     std::vector<int> h_rp, h_col, h_blk, h_blk_big;   // host copies kept for build_cc16 / the coarsest factorisation
     void free_all() {
-        dev_free(row_ptr); dev_free(col); dev_free(blk_row); dev_free(blk_row_big); dev_free(rows); dev_free(val); dev_free(dense);
+        hipFree(row_ptr); hipFree(col); hipFree(blk_row); hipFree(blk_row_big); hipFree(rows); hipFree(val); hipFree(dense);
         dense = nullptr;
-        for (int k = 0; k < 2; ++k) { dev_free(segtab[k]); dev_free(segptr[k]); dev_free(ccol[k]); segtab[k] = segptr[k] = nullptr; ccol[k] = nullptr; }
-        for (int k = 0; k < 2; ++k) { dev_free(cm_val[k]); dev_free(cm_col[k]); dev_free(cm_dst[k]); dev_free(cm_ptr[k]); cm_val[k] = nullptr; cm_col[k] = cm_dst[k] = nullptr; cm_ptr[k] = nullptr; }
+        for (int k = 0; k < 2; ++k) { hipFree(segtab[k]); hipFree(segptr[k]); hipFree(ccol[k]); segtab[k] = segptr[k] = nullptr; ccol[k] = nullptr; }
+        for (int k = 0; k < 2; ++k) { hipFree(cm_val[k]); hipFree(cm_col[k]); hipFree(cm_dst[k]); hipFree(cm_ptr[k]); cm_val[k] = nullptr; cm_col[k] = cm_dst[k] = nullptr; cm_ptr[k] = nullptr; }
         row_ptr = col = blk_row = blk_row_big = rows = nullptr; val = nullptr;
         free_sell();
         free_xlds();
@@ -2077,7 +2015,6 @@ int sgpu_init(int device_id, int rank, int nranks, const void *uid) {
     if (!std::getenv("SAENA_NO_SPIN_WAIT") && hipSetDeviceFlags(hipDeviceScheduleSpin) != hipSuccess) (void)hipGetLastError();
     { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && n > 0) g.ncu = n; }
     g.device = device_id; g.rank = rank; g.nranks = nranks;
-    g_reaper_device = device_id;
     HIPCHK(hipStreamCreateWithFlags(&g.cs, hipStreamNonBlocking));
     {   // the halo stream's small kernels (pack, RCCL, boundary rows) must not queue behind the interior launch
         int least = 0, greatest = 0;
@@ -2135,7 +2072,6 @@ int sgpu_debug_init_host_transport(int device_id, int rank, int nranks, sgpu_hos
 
 int sgpu_finalize(void) {
     if (!g.live) return SGPU_OK;
-    g_reaper.shutdown();                                 // the deferred frees of the plan-time autotune
     sgpu_install_spgemm_hook(0);
     hipDeviceSynchronize();
     if (g.comm) { ncclCommDestroy(g.comm); g.comm = nullptr; }
@@ -2556,12 +2492,11 @@ void plan_cache_store(uint64_t key, const sgpu_op *op, int v, int lanes, float m
 }
 // drop what the chosen plan does not need: alternative forms on the device, the host copy of the values
 void finish_plan(sgpu_op *op, int bv) {
-    DeferFrees defer;                                    // the forms that lost are freed by the background thread
-    if (bv != 5 && op->loc.dense) { dev_free(op->loc.dense); op->loc.dense = nullptr; }
+    if (bv != 5 && op->loc.dense) { hipFree(op->loc.dense); op->loc.dense = nullptr; }
     const bool keep = std::getenv("SAENA_KEEP_HOST_VALUES") != nullptr;   // development sweeps switch variants after the autotune
     for (int k = 0; k < 2 && !keep; ++k)              // the column-major copies of the plans that lost
         if (op->loc.cm_ok[k] && bv != 7 + k) {
-            dev_free(op->loc.cm_val[k]); dev_free(op->loc.cm_col[k]); dev_free(op->loc.cm_dst[k]); dev_free(op->loc.cm_ptr[k]);
+            hipFree(op->loc.cm_val[k]); hipFree(op->loc.cm_col[k]); hipFree(op->loc.cm_dst[k]); hipFree(op->loc.cm_ptr[k]);
             op->loc.cm_val[k] = nullptr; op->loc.cm_col[k] = op->loc.cm_dst[k] = nullptr; op->loc.cm_ptr[k] = nullptr;
             op->loc.cm_ok[k] = false; op->loc.cm_tried[k] = 0;
         }
@@ -2569,7 +2504,7 @@ void finish_plan(sgpu_op *op, int bv) {
     if (bv == 14 && !keep) {                                      // k_sellp2 keeps the pattern ids and the table; k_sell's / k_sellp's arrays go
         CsrPart &L = op->loc;
         L.free_sell_columns();
-        dev_free(L.sl_val); dev_free(L.sl_ptr); L.sl_val = nullptr; L.sl_ptr = nullptr;
+        hipFree(L.sl_val); hipFree(L.sl_ptr); L.sl_val = nullptr; L.sl_ptr = nullptr;
         L.sl_vals = false; L.sl_vals_tried = 0;                       // (a later set_variant(11) re-orders the values again, from the device's CSR copy)
     } else if (bv != 9 && bv != 11 && bv != 15 && !keep) op->loc.free_sell();
     else if ((bv == 11 || bv == 15) && !keep) op->loc.free_sell_columns();    // k_sellp / k_sellpx keep the values and the slice pointers only
@@ -2579,7 +2514,7 @@ void finish_plan(sgpu_op *op, int bv) {
     if (bv != 13 && !keep) op->loc.free_rowt();
     if (bv != 12 && !keep) op->loc.free_sellx();
     if (bv != 10 && bv != 12 && bv != 16 && !keep) op->loc.free_xlds();
-    else if (bv == 12 && !keep) { dev_free(op->loc.xl_col); dev_free(op->loc.xl_tab); op->loc.xl_col = nullptr; op->loc.xl_tab = nullptr; }      // k_sellx keeps the chunk plan only
+    else if (bv == 12 && !keep) { hipFree(op->loc.xl_col); hipFree(op->loc.xl_tab); op->loc.xl_col = nullptr; op->loc.xl_tab = nullptr; }      // k_sellx keeps the chunk plan only
     // the host copy of the values goes (the forms that still need it -- k_sellx, k_rowt -- are refused from here on).  Unmapping 4.5 GB
     // of resident host memory takes 0.25 s (the 558 M-entry level: most of what the autotune's log called "freeing"): a detached
     // thread does it, like the host setup's own large temporaries
@@ -2592,7 +2527,7 @@ void finish_plan(sgpu_op *op, int bv) {
     }
     for (int k = 0; k < 2 && !keep; ++k)              // free the compressed arrays of the plans that lost
         if (op->loc.cc_ok[k] && bv != 3 + k && bv != 7 + k) {
-            dev_free(op->loc.segtab[k]); dev_free(op->loc.segptr[k]); dev_free(op->loc.ccol[k]);
+            hipFree(op->loc.segtab[k]); hipFree(op->loc.segptr[k]); hipFree(op->loc.ccol[k]);
             op->loc.segtab[k] = op->loc.segptr[k] = nullptr; op->loc.ccol[k] = nullptr; op->loc.cc_ok[k] = false; op->loc.cc_tried[k] = 0;
         }
 }
