@@ -2195,10 +2195,13 @@ int sgpu_op_create(const sgpu_op_desc *d, sgpu_op **out) {
         // (whole operator: local + remote entries against the columns this rank reads, owned + halo)
         if (dense_candidate(d->M, d->N_local + d->col_remote_size, d->nnz_l_local + d->nnz_l_remote)) host_copy(op->loc.h_val);
         if (d->M <= sk::CG_MAXN) host_copy(op->h_val);
-        // the column-ordered and sliced-ELLPACK forms (k_csr_cm, k_sell) are built from a host copy of the values at the
-        // plan-time autotune, which drops the copy afterwards; SAENA_KEEP_HOST_VALUES=1: keep it for good (development sweeps)
+        // k_sellx (rows of 96-1024 entries) and the opt-in k_rowt are built from a host copy of the values at the plan-time autotune,
+        // which drops the copy afterwards; every other form is made on the device from the CSR values there (round 4: the copy of the
+        // 558 M-entry level alone was 4.5 GB to write and to unmap).  SAENA_KEEP_HOST_VALUES=1: keep it for good (development sweeps)
         const double avg_row = d->M > 0 ? (double)d->nnz_l_local / d->M : 0.0;
-        if (std::getenv("SAENA_KEEP_HOST_VALUES") || (avg_row <= 768.0 && !std::getenv("SAENA_NO_AUTOTUNE"))) host_copy(op->h_val_all);
+        if (std::getenv("SAENA_KEEP_HOST_VALUES") ||
+            (!std::getenv("SAENA_NO_AUTOTUNE") && ((avg_row >= 96.0 && avg_row <= 1024.0) || (avg_row <= 768.0 && std::getenv("SAENA_ROW_TEMPLATES")))))
+            host_copy(op->h_val_all);
     }
     // remote part: CSC over the receive buffer -> CSR over the halo buffer on the rows that own remote entries
     if (d->nnz_l_remote > 0) {
@@ -2706,7 +2709,7 @@ int sgpu_op_autotune(sgpu_op *op) {
     // built only where the forms timed so far are slower than its bytes at 5.2 TB/s (R1 of 256^3: 438 us against a bound of 351 -> built,
     // wins with 384; L2: k_sellx 440 against 459 -> skipped, it measured 493)
     const double t_cm0 = now_s();
-    if (!op->h_val_all.empty() && avg_row >= 96.0 && avg_row <= 768.0 && !std::getenv("SAENA_NO_CM") &&
+    if (avg_row >= 96.0 && avg_row <= 768.0 && !std::getenv("SAENA_NO_CM") &&
         (all || (double)best_est > 12.0 * (double)op->loc.nnz / 5.2e9)) {
         CHK(build_cm(op->loc, 1, op->h_val_all));
         if (op->loc.cm_ok[1])
