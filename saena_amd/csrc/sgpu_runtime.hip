@@ -1438,8 +1438,7 @@ XldsKernelFn pick_xlds(int epi, int lanes, bool halo) { return halo ? pick_xlds_
 // k_csr_xldsr: four rows per group step (short rows), 4 / 8 / 16 lanes per group
 template <int EPI, bool HALO>
 XldsKernelFn pick_xldsr_g(int lanes) {
-    static const int rp = std::getenv("SAENA_XLDSR_RP") ? std::atoi(std::getenv("SAENA_XLDSR_RP")) : 4;     // (development: rows per group step)
-    if (rp == 8) return lanes <= 8 ? sk::k_csr_xlds<EPI, 8, HALO, 8> : lanes <= 16 ? sk::k_csr_xlds<EPI, 16, HALO, 8> : sk::k_csr_xlds<EPI, 32, HALO, 8>;
+    // (eight rows per step were tried: 128 registers per lane do not hold them -- 136 bytes of scratch per lane, 110 against 94.5 us)
     return lanes <= 4 ? sk::k_csr_xlds<EPI, 4, HALO, 4> : lanes <= 8 ? sk::k_csr_xlds<EPI, 8, HALO, 4> : lanes <= 16 ? sk::k_csr_xlds<EPI, 16, HALO, 4> : sk::k_csr_xlds<EPI, 32, HALO, 4>;
 }
 template <bool HALO>
