@@ -16,7 +16,7 @@ def main():
     lanes = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8, 16]
     capi.init(0)
     print("device:", capi.device_info(), flush=True)
-    r, c, v, M = irregular.sih4_replicated(nblocks)
+    r, c, v, M = irregular.sih4_replicated(nblocks, hub_every=0 if os.environ.get("IRREGULAR_NO_HUBS") else 16)      # (experiment: the operator without its hub rows)
     A = host.Matrix(host.Comm("gpu", "rccl"))
     A.set_remove_boundary(False)
     A.set_many(r, c, v)
