@@ -350,8 +350,9 @@ def stored_bytes(info, kernel_name):
         return 2 * info["M"] + vec
     if kernel_name.startswith("k_sellp"):                # k_sellp, k_sellp2, their <wide> forms, k_sellpx: no column stream, a 16-bit pattern id per row
         return 8 * nnz + 2 * info["M"] + vec             # (+ a table of a few hundred ints / a few KiB per workgroup)
-    if kernel_name in ("k_sell", "k_sellx", "k_csr_xlds", "k_csr_xldsr"):   # 16-bit column codes; k_sell: a 16-bit row length instead of the row pointer (padding < 1 % here)
-        return 10 * nnz + (2 if kernel_name == "k_sell" else 4) * info["M"] + vec
+    if kernel_name in ("k_sell", "k_sell<sorted>", "k_sellx", "k_csr_xlds", "k_csr_xldsr"):   # 16-bit column codes; k_sell: a 16-bit row length instead of the row pointer (padding < 1 % here)
+        per_row = {"k_sell": 2, "k_sell<sorted>": 6}.get(kernel_name, 4)             # (sorted: + the 32-bit row a slice position holds)
+        return 10 * nnz + per_row * info["M"] + vec
     if kernel_name == "k_dense_rows":
         return 8 * info["M"] * info["N_local"] + vec
     col_bytes = 2 if ("cc16" in kernel_name or "k_csr_cm" in kernel_name) else 4

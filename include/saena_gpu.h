@@ -123,7 +123,9 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
  * k_dense_rows_halo), at most 8192 rows and 64 M entries per rank; 6 k_csr_wave (long rows streamed by a wave);
  * 7 / 8 k_csr_cm: compressed columns with the entries of a row block in column order (12 B/nnz, fewer L1 requests on
  * rows of a few hundred entries) on the 16 / 32 KiB plan; 9 k_sell: sliced ELLPACK, a lane per row, 16-bit column codes
- * (operators whose slices of 64 rows pad to at most 12 % more entries); 10 k_csr_xlds: the input vector staged in LDS
+ * (operators whose slices of 64 rows pad to at most 12 % more entries; with SAENA_SELL_SORTED=1 also, as "k_sell<sorted>",
+ * operators that pad to at most 5 % once their rows are sorted by length inside windows of 2048 rows -- opt-in: it
+ * lost to the tile kernels wherever it was measured); 10 k_csr_xlds: the input vector staged in LDS
  * in windows of 20224 columns, one workgroup per CU (row chunks that reach over at most 8 windows; 4-64 lanes per row
  * piece, sgpu_op_set_lanes_per_row); 11 k_sellp: k_sell's values without a column stream -- a 16-bit id per row into a
  * table of (length, columns relative to the row) patterns held in LDS, 8 B per entry + 2 B per row (operators that

@@ -617,6 +617,9 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
     const int r = s * 64 + lane;
     const int p = a.cmptr[s], w = (a.cmptr[s + 1] - p) >> 6;
     const int len = r < nrows ? (int)a.dst[r] : 0;
+    // k_sell<sorted> (round 4): the slices hold the rows SORTED by length inside windows of 2048 rows (uneven rows: 20 % padding ->
+    // 1-2 %); a.blk_row maps a slice position to the row it holds, and that is where the epilogue reads and writes
+    const int ro = a.blk_row ? (r < nrows ? a.blk_row[r] : r) : r;
     const int ob = a.cc_ob;
     const unsigned om = (1u << ob) - 1u;
     if constexpr (!PAIR) {                             // rows of a handful of entries (the stencil level, its transfers): one position per load
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
             for (int u = 0; u < 8; ++u)
                 if (j + u < len) sum += vv[u] * xx[u];
         }
-        if (r < nrows) epilogue<EPI, HALO, NT>(a, r, sum);
+        if (r < nrows) epilogue<EPI, HALO, NT>(a, ro, sum);
         return;
     }
     const int P = w >> 1;                              // pairs of positions; an odd last one follows them
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(BLOCK) void k_sell(const SpmvArgs a, int nrows) {
         }
     }
     if ((w & 1) && w - 1 < len) sum += vt * xt;
-    if (r < nrows) epilogue<EPI, HALO, NT>(a, r, sum);
+    if (r < nrows) epilogue<EPI, HALO, NT>(a, ro, sum);
 }
 
 // ---------------------------------------------------------------------------
@@ -1763,11 +1766,12 @@ __global__ __launch_bounds__(CG_BLOCK) void k_dense_solve(const double *__restri
 // in pairs of positions per lane (an odd last position alone); 2: slices of 128 rows, position-major (k_sellp2's row pairs).
 template <class T>
 __global__ __launch_bounds__(BLOCK) void k_sell_scatter(const T *__restrict__ src, const int *__restrict__ row_ptr, const int *__restrict__ sl_ptr,
-                                                       T *__restrict__ dst, int M, int mode) {
-    const int r = blockIdx.x * BLOCK + threadIdx.x;
+                                                       T *__restrict__ dst, int M, int mode, const int *__restrict__ perm = nullptr) {
+    const int r = blockIdx.x * BLOCK + threadIdx.x;      // the slice position; perm (k_sell<sorted>): the row that sits there
     if (r >= M) return;
-    const size_t q0 = (size_t)row_ptr[r];
-    const int n = row_ptr[r + 1] - row_ptr[r];
+    const int rsrc = perm ? perm[r] : r;
+    const size_t q0 = (size_t)row_ptr[rsrc];
+    const int n = row_ptr[rsrc + 1] - row_ptr[rsrc];
     if (mode == 2) {
         const int s = r >> 7, l = r & 127;
         const size_t p = (size_t)sl_ptr[s];
@@ -1791,18 +1795,28 @@ __global__ __launch_bounds__(BLOCK) void k_sell_scatter(const T *__restrict__ sr
 // host sums the counts into segptr and sees whether every block fits 2^(16-ob) slots) and then numbered by a prefix sum over the
 // bitmap's words (pass 2: ascending segment order = the host encoder's sorted table, so both encoders produce the same arrays).
 constexpr int CC_BM_WORDS = 2048;
+// perm != nullptr (k_sell<sorted>): block b covers the slice positions [blk[b], blk[b + 1]), position q holds row perm[q] -- its entries
+// are not one contiguous range, so the threads walk rows instead of entries
 __global__ __launch_bounds__(BLOCK) void k_cc16_count(const int *__restrict__ col, const int *__restrict__ row_ptr, const int *__restrict__ blk,
-                                                     int ob, int nwords, int maxseg, int *__restrict__ cnt, int *__restrict__ bad) {
+                                                     int ob, int nwords, int maxseg, int *__restrict__ cnt, int *__restrict__ bad,
+                                                     const int *__restrict__ perm = nullptr) {
     __shared__ unsigned bm[CC_BM_WORDS];
     __shared__ int total;
     const int b = blockIdx.x;
-    const int p0 = row_ptr[blk[b]], p1 = row_ptr[blk[b + 1]];
     for (int w = threadIdx.x; w < nwords; w += BLOCK) bm[w] = 0u;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
-    for (int p = p0 + (int)threadIdx.x; p < p1; p += BLOCK) {
-        const int sg = col[p] >> ob;
-        atomicOr(&bm[sg >> 5], 1u << (sg & 31));
+    if (perm) {
+        for (int q = blk[b] + (int)threadIdx.x; q < blk[b + 1]; q += BLOCK) {
+            const int r = perm[q];
+            for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p) { const int sg = col[p] >> ob; atomicOr(&bm[sg >> 5], 1u << (sg & 31)); }
+        }
+    } else {
+        const int p0 = row_ptr[blk[b]], p1 = row_ptr[blk[b + 1]];
+        for (int p = p0 + (int)threadIdx.x; p < p1; p += BLOCK) {
+            const int sg = col[p] >> ob;
+            atomicOr(&bm[sg >> 5], 1u << (sg & 31));
+        }
     }
     __syncthreads();
     int mine = 0;
@@ -1813,17 +1827,24 @@ __global__ __launch_bounds__(BLOCK) void k_cc16_count(const int *__restrict__ co
 }
 __global__ __launch_bounds__(BLOCK) void k_cc16_encode(const int *__restrict__ col, const int *__restrict__ row_ptr, const int *__restrict__ blk,
                                                       int ob, int nwords, const int *__restrict__ segptr, int *__restrict__ segtab,
-                                                      unsigned short *__restrict__ ccol) {
+                                                      unsigned short *__restrict__ ccol, const int *__restrict__ perm = nullptr) {
     __shared__ unsigned bm[CC_BM_WORDS];
     __shared__ int pre[CC_BM_WORDS];                     // set bits in the words before this one
     __shared__ int part[BLOCK];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int p0 = row_ptr[blk[b]], p1 = row_ptr[blk[b + 1]];
+    const int p0 = perm ? 0 : row_ptr[blk[b]], p1 = perm ? 0 : row_ptr[blk[b + 1]];
     for (int w = tid; w < nwords; w += BLOCK) bm[w] = 0u;
     __syncthreads();
-    for (int p = p0 + tid; p < p1; p += BLOCK) {
-        const int sg = col[p] >> ob;
-        atomicOr(&bm[sg >> 5], 1u << (sg & 31));
+    if (perm) {
+        for (int q = blk[b] + tid; q < blk[b + 1]; q += BLOCK) {
+            const int r = perm[q];
+            for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p) { const int sg = col[p] >> ob; atomicOr(&bm[sg >> 5], 1u << (sg & 31)); }
+        }
+    } else {
+        for (int p = p0 + tid; p < p1; p += BLOCK) {
+            const int sg = col[p] >> ob;
+            atomicOr(&bm[sg >> 5], 1u << (sg & 31));
+        }
     }
     __syncthreads();
     // exclusive prefix of the words' population counts: a thread owns a contiguous run of words
@@ -1844,10 +1865,21 @@ __global__ __launch_bounds__(BLOCK) void k_cc16_encode(const int *__restrict__ c
         while (m) { const int bit = __ffs(m) - 1; m &= m - 1; segtab[t0 + k++] = ((w << 5) + bit) << ob; }
     }
     const int om = (1 << ob) - 1;
-    for (int p = p0 + tid; p < p1; p += BLOCK) {
-        const int c = col[p], sg = c >> ob;
-        const int slot = pre[sg >> 5] + __popc(bm[sg >> 5] & ((1u << (sg & 31)) - 1u));
-        ccol[p] = (unsigned short)((slot << ob) | (c & om));
+    if (perm) {
+        for (int q = blk[b] + tid; q < blk[b + 1]; q += BLOCK) {
+            const int r = perm[q];
+            for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
+                const int c = col[p], sg = c >> ob;
+                const int slot = pre[sg >> 5] + __popc(bm[sg >> 5] & ((1u << (sg & 31)) - 1u));
+                ccol[p] = (unsigned short)((slot << ob) | (c & om));
+            }
+        }
+    } else {
+        for (int p = p0 + tid; p < p1; p += BLOCK) {
+            const int c = col[p], sg = c >> ob;
+            const int slot = pre[sg >> 5] + __popc(bm[sg >> 5] & ((1u << (sg & 31)) - 1u));
+            ccol[p] = (unsigned short)((slot << ob) | (c & om));
+        }
     }
 }
 

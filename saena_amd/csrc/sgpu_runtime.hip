@@ -157,6 +157,8 @@ struct CsrPart {
     int            *sl_base = nullptr, *sl_segptr = nullptr, *sl_ptr = nullptr;   // segment bases of all groups, group g owns [sl_segptr[g], sl_segptr[g+1])
     int             nslices = 0, sl_ob = 12;
     bool            sl_pair = false;       // two positions per lane side by side (rows of >= 16 entries), else one
+    int            *sl_perm = nullptr;     // k_sell<sorted>: slice position -> row (rows sorted by length inside windows of SL_SORT_WINDOW rows)
+    bool            sl_sorted = false;
     int             sl_uw = 0, sp2_uw = 0; // every slice of 64 (k_sell / k_sellp) / 128 (k_sellp2) rows has this many positions (0: widths differ)
     bool            sl_ok = false;         // values AND column codes: k_sell can run
     bool            sl_vals = false;       // the values (sl_val, sl_ptr, nslices, sl_pair): what the row-pattern forms need
@@ -181,8 +183,9 @@ struct CsrPart {
         free_sellp();
         hipFree(spx_tab); hipFree(spx_pat); hipFree(spx_win); hipFree(spx_wgptr);                                 // (free_sellpx, declared below)
         spx_tab = spx_pat = nullptr; spx_win = spx_wgptr = nullptr; spx_ok = false; spx_tried = 0;
-        hipFree(sl_val); hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr); hipFree(sl_ptr);
-        sl_val = nullptr; sl_col = sl_len = nullptr; sl_base = sl_segptr = sl_ptr = nullptr; sl_ok = false; sl_tried = 0; sl_vals = false; sl_vals_tried = 0;
+        hipFree(sl_val); hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr); hipFree(sl_ptr); hipFree(sl_perm);
+        sl_val = nullptr; sl_col = sl_len = nullptr; sl_base = sl_segptr = sl_ptr = sl_perm = nullptr; sl_ok = false; sl_tried = 0; sl_vals = false; sl_vals_tried = 0;
+        sl_sorted = false;
     }
     // x in LDS (variant 10): absolute 16-bit column ids and nnz-balanced row chunks, one per CU
     unsigned short *xl_col = nullptr;
@@ -399,7 +402,8 @@ bool encode_cc16(const CsrPart &P, const std::vector<int> &blk, std::vector<unsi
 // The same encoding ON THE DEVICE (round 4), from the 32-bit columns already there: *ok = false when a block touches more than 256
 // segments of 256 columns (the form does not apply) or the operator has more columns than the kernels' bitmap covers (the caller
 // falls back to the host encoder).  d_blk: the row-block boundaries on the device; ccol gets nnz + 8 codes (CSR order).
-int encode_cc16_device(const CsrPart &P, const int *d_blk, int nblk, unsigned short **ccol, int **segptr_d, int **segtab_d, int *ob_out, bool *ok, bool *host_fallback) {
+int encode_cc16_device(const CsrPart &P, const int *d_blk, int nblk, unsigned short **ccol, int **segptr_d, int **segtab_d, int *ob_out, bool *ok, bool *host_fallback,
+                       const int *d_perm = nullptr) {       // d_perm (k_sell<sorted>): d_blk bounds slice POSITIONS, position q holds row d_perm[q]
     *ok = false; *host_fallback = false;
     *ccol = nullptr; *segptr_d = nullptr; *segtab_d = nullptr;
     const int ncols = std::max(1, P.ncols);
@@ -415,7 +419,7 @@ int encode_cc16_device(const CsrPart &P, const int *d_blk, int nblk, unsigned sh
         const int maxseg = 1 << (16 - ob), nsegs_total = (ncols >> ob) + 1, nwords = (nsegs_total + 31) / 32;
         if (nwords > sk::CC_BM_WORDS) { if (ob == 8) { *host_fallback = true; return SGPU_OK; } continue; }   // (a finer split needs a larger bitmap still)
         HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(int), g.cs));
-        SGPU_LAUNCH(sk::k_cc16_count, dim3(nblk), dim3(sk::BLOCK), 0, g.cs, (const int *)P.col, (const int *)P.row_ptr, d_blk, ob, nwords, maxseg, d_cnt, d_bad);
+        SGPU_LAUNCH(sk::k_cc16_count, dim3(nblk), dim3(sk::BLOCK), 0, g.cs, (const int *)P.col, (const int *)P.row_ptr, d_blk, ob, nwords, maxseg, d_cnt, d_bad, d_perm);
         HIPCHK(hipGetLastError());
         int bad = 0;
         HIPCHK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, g.cs));
@@ -430,7 +434,7 @@ int encode_cc16_device(const CsrPart &P, const int *d_blk, int nblk, unsigned sh
         const size_t nc = (size_t)P.nnz + 8;
         if (hipMalloc(reinterpret_cast<void **>(ccol), nc * sizeof(unsigned short)) != hipSuccess) { *ccol = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of the column codes failed"); }
         HIPCHK(hipMemsetAsync(*ccol, 0, nc * sizeof(unsigned short), g.cs));
-        SGPU_LAUNCH(sk::k_cc16_encode, dim3(nblk), dim3(sk::BLOCK), 0, g.cs, (const int *)P.col, (const int *)P.row_ptr, d_blk, ob, nwords, (const int *)*segptr_d, *segtab_d, *ccol);
+        SGPU_LAUNCH(sk::k_cc16_encode, dim3(nblk), dim3(sk::BLOCK), 0, g.cs, (const int *)P.col, (const int *)P.row_ptr, d_blk, ob, nwords, (const int *)*segptr_d, *segtab_d, *ccol, d_perm);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(g.cs));
         *ob_out = ob; *ok = true;
@@ -656,6 +660,13 @@ int uniform_width(std::vector<int> &ptr, int rows, int64_t *tot) {
     return w0;
 }
 
+// k_sell<sorted>: the window the rows are sorted in (a multiple of the 256 rows of a workgroup; y, rhs, inv_diag of a wave's rows lie
+// anywhere inside it: 16 KiB per vector at 2048)
+static const int SL_SORT_WINDOW = [] {
+    const char *e = std::getenv("SAENA_SELL_SORT_WINDOW");
+    const int w = e ? std::atoi(e) : 2048;
+    return std::max(256, (w / 256) * 256);
+}();
 int build_sell_values(CsrPart &P) {
     if (P.sl_vals || P.sl_vals_tried || P.h_rp.empty() || !P.val || !P.row_ptr) return SGPU_OK;
     P.sl_vals_tried = 1;
@@ -673,8 +684,40 @@ int build_sell_values(CsrPart &P) {
         ptr[(size_t)s + 1] = (int)tot;
     }
     static const double pad_limit = std::getenv("SAENA_SELL_PAD") ? atof(std::getenv("SAENA_SELL_PAD")) : 1.12;
-    if ((double)tot > pad_limit * (double)P.nnz) return SGPU_OK;
-    P.sl_uw = uniform_width(ptr, 64, &tot);                       // (pads the last slice up to the others' width where that makes them all equal)
+    std::vector<int> perm;
+    if ((double)tot > pad_limit * (double)P.nnz) {
+        // uneven rows (a transfer operator: P1 of 256^3 pads 20 %): the rows SORTED by length inside windows of SL_SORT_WINDOW rows
+        // (a stable counting sort: rows of one length keep their order) pad 1-2 %.  The slices then hold a permutation of the
+        // window's rows; k_sell's epilogue goes through sl_perm.  No pattern form on top.
+        // OPT-IN (SAENA_SELL_SORTED=1): measured on the two operators it was built for it LOSES -- P1 of 256^3 400-423 us against 361-367
+        // on 32 KiB tiles of 16-bit columns, P2 156-171 against 116 (k_csr_xldsr) / 137 us; windows of 512 / 2048 / 8192 rows, plain or
+        // non-temporal stores alike (profiles/r04_sell_sorted_windows.log): the 64 rows of a wave are no longer neighbours, so a
+        // gather instruction names ~32x the lines of x it named, and that -- not the 20 % of padding -- is what these kernels pay for.
+        if (!std::getenv("SAENA_SELL_SORTED") || P.nnz < 4 * (int64_t)M) return SGPU_OK;
+        perm.resize((size_t)ns * 64);
+        std::vector<int> cnt;
+        for (int w0 = 0; w0 < M; w0 += SL_SORT_WINDOW) {
+            const int w1 = std::min(M, w0 + SL_SORT_WINDOW);
+            int wmax = 0;
+            for (int r = w0; r < w1; ++r) wmax = std::max(wmax, P.h_rp[r + 1] - P.h_rp[r]);
+            cnt.assign((size_t)wmax + 2, 0);
+            for (int r = w0; r < w1; ++r) ++cnt[(size_t)(wmax - (P.h_rp[r + 1] - P.h_rp[r])) + 1];      // longest rows first
+            for (int l = 0; l <= wmax; ++l) cnt[(size_t)l + 1] += cnt[(size_t)l];
+            for (int r = w0; r < w1; ++r) perm[(size_t)w0 + (size_t)cnt[(size_t)(wmax - (P.h_rp[r + 1] - P.h_rp[r]))]++] = r;
+        }
+        for (size_t q = (size_t)M; q < perm.size(); ++q) perm[q] = (int)q;                                 // (positions past the last row: never read)
+        tot = 0;
+        for (int s = 0; s < ns; ++s) {
+            const int r = perm[(size_t)s * 64];                      // the longest row of the slice is its first
+            tot += (int64_t)(P.h_rp[r + 1] - P.h_rp[r]) * 64;
+            ptr[(size_t)s + 1] = (int)tot;
+        }
+        static const double sorted_limit = std::getenv("SAENA_SELL_SORTED_PAD") ? atof(std::getenv("SAENA_SELL_SORTED_PAD")) : 1.05;
+        if ((double)tot > sorted_limit * (double)P.nnz) return SGPU_OK;
+        CHK(dev_upload(&P.sl_perm, perm.data(), perm.size()));
+        P.sl_sorted = true;
+    }
+    if (!P.sl_sorted) P.sl_uw = uniform_width(ptr, 64, &tot);      // (pads the last slice up to the others' width where that makes them all equal)
     // 16-byte value loads pay from a few pairs per row on, and on any operator that streams from HBM (256^3 L0, 7 entries
     // per row: 338 vs 343-350 us); the cache-resident 128^3 fine level is the one case that prefers single positions
     const bool pair = P.nnz >= 16 * (int64_t)M || 10 * P.nnz > (int64_t)256 * 1024 * 1024;
@@ -684,7 +727,7 @@ int build_sell_values(CsrPart &P) {
     if (hipMalloc(reinterpret_cast<void **>(&P.sl_val), nv * sizeof(double)) != hipSuccess) { P.sl_val = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of %zu bytes failed", nv * sizeof(double)); }
     HIPCHK(hipMemsetAsync(P.sl_val, 0, nv * sizeof(double), g.cs));
     SGPU_LAUNCH(sk::k_sell_scatter<double>, dim3((M + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs, (const double *)P.val, (const int *)P.row_ptr,
-                (const int *)P.sl_ptr, P.sl_val, M, pair ? 1 : 0);
+                (const int *)P.sl_ptr, P.sl_val, M, pair ? 1 : 0, (const int *)P.sl_perm);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.cs));
     P.nslices = ns;
@@ -704,6 +747,11 @@ int build_sell(CsrPart &P, const std::vector<double> &) {
     std::vector<unsigned short> ccol, len((size_t)ns * 64, 0);
     std::vector<int> segptr, segtab;
     int ob = 12;
+    if (P.sl_sorted) {                                            // the length of the row that sits at each slice position
+        std::vector<int> perm((size_t)ns * 64);
+        HIPCHK(hipMemcpy(perm.data(), P.sl_perm, perm.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int q = 0; q < M; ++q) len[(size_t)q] = (unsigned short)(P.h_rp[perm[(size_t)q] + 1] - P.h_rp[perm[(size_t)q]]);
+    } else
     for (int r = 0; r < M; ++r) len[(size_t)r] = (unsigned short)(P.h_rp[r + 1] - P.h_rp[r]);
     // the codes in CSR order (made on the device where the bitmap covers the operator's columns, else on the host and uploaded)
     // take the values' way into the slice layout (padding keeps code 0: slot 0, offset 0 = a valid column of the group)
@@ -715,9 +763,9 @@ int build_sell(CsrPart &P, const std::vector<double> &) {
         struct G { int *p; ~G() { hipFree(p); } } gfree{d_grp};
         bool ok = false, fallback = false;
         int *d_segptr = nullptr, *d_segtab = nullptr;
-        CHK(encode_cc16_device(P, d_grp, (int)grp.size() - 1, &d_ccol, &d_segptr, &d_segtab, &ob, &ok, &fallback));
+        CHK(encode_cc16_device(P, d_grp, (int)grp.size() - 1, &d_ccol, &d_segptr, &d_segtab, &ob, &ok, &fallback, P.sl_perm));
         if (ok) { P.sl_segptr = d_segptr; P.sl_base = d_segtab; dev_tabs = true; }
-        else if (!fallback) return SGPU_OK;
+        else if (!fallback || P.sl_sorted) return SGPU_OK;             // (the host encoder knows no permutation: operators of more columns than the device's bitmap covers keep CSR)
     }
     if (!dev_tabs) {
         if (!encode_cc16(P, grp, ccol, segptr, segtab, ob)) return SGPU_OK;
@@ -730,12 +778,12 @@ int build_sell(CsrPart &P, const std::vector<double> &) {
     if (hipMalloc(reinterpret_cast<void **>(&P.sl_col), nc * sizeof(unsigned short)) != hipSuccess) { P.sl_col = nullptr; return fail(SGPU_ERR_NOMEM, "hipMalloc of %zu bytes failed", nc * 2); }
     HIPCHK(hipMemsetAsync(P.sl_col, 0, nc * sizeof(unsigned short), g.cs));
     SGPU_LAUNCH(sk::k_sell_scatter<unsigned short>, dim3((M + sk::BLOCK - 1) / sk::BLOCK), dim3(sk::BLOCK), 0, g.cs, (const unsigned short *)d_ccol, (const int *)P.row_ptr,
-                (const int *)P.sl_ptr, P.sl_col, M, P.sl_pair ? 1 : 0);
+                (const int *)P.sl_ptr, P.sl_col, M, P.sl_pair ? 1 : 0, (const int *)P.sl_perm);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.cs));
     if (std::getenv("SAENA_SETUP_TIMING"))
-        fprintf(stderr, "[sgpu] sliced ELLPACK: %d rows, %lld entries, %.1f %% padding, columns %d+%d bits\n", M, (long long)P.nnz,
-                100.0 * ((double)tot / (double)P.nnz - 1.0), 16 - ob, ob);
+        fprintf(stderr, "[sgpu] sliced ELLPACK%s: %d rows, %lld entries, %.1f %% padding, columns %d+%d bits\n", P.sl_sorted ? " (rows sorted by length per window)" : "",
+                M, (long long)P.nnz, 100.0 * ((double)tot / (double)P.nnz - 1.0), 16 - ob, ob);
     CHK(dev_upload(&P.sl_len, len.data(), len.size()));
     if (!dev_tabs) {
         CHK(dev_upload(&P.sl_base, segtab.data(), segtab.size(), 1));
@@ -757,7 +805,7 @@ int build_sell(CsrPart &P, const std::vector<double> &) {
 // Ids are dealt in order of first appearance, so the tables do not depend on threads or hashing.
 constexpr int SP_MAX_TABLE = 4096;
 int build_sellp(CsrPart &P) {
-    if (P.sp_ok || P.sp_tried || !P.sl_vals || P.h_rp.empty()) return SGPU_OK;
+    if (P.sp_ok || P.sp_tried || !P.sl_vals || P.sl_sorted || P.h_rp.empty()) return SGPU_OK;     // (sorted slices: positions are not rows)
     P.sp_tried = 1;
     const int M = P.nrows;
     int W = 1;
@@ -1540,12 +1588,15 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         SGPU_LAUNCH(pick_sellp(epi, halo, P.sl_pair, nt, false), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), (size_t)P.sp_n * (P.sp_w + 1) * sizeof(int), g.cs, a, P.nrows);
     } else if (P.variant == 9) {                                  // sliced ELLPACK, a lane per row
         if (!P.sl_ok) return fail(SGPU_ERR_STATE, "the sliced-ELLPACK form was not built");
-        a.blk_row = nullptr; a.nblk = P.nslices;
+        a.blk_row = P.sl_sorted ? P.sl_perm : nullptr; a.nblk = P.nslices;
         a.val = P.sl_val; a.ccol = P.sl_col; a.segtab = P.sl_base; a.segptr = P.sl_segptr; a.cc_ob = P.sl_ob; a.cmptr = P.sl_ptr; a.dst = P.sl_len;
         // non-temporal streams once the stored operator is beyond the 256 MiB Infinity Cache (k_sellp in kernels.hip.h; 128^3 L1,
         // 843 MB: 127 -> 121 us, profiles/r03_sell_nt.log)
         static const int nt_env = std::getenv("SAENA_SELL_NT") ? std::atoi(std::getenv("SAENA_SELL_NT")) : -1;
         const bool nt = nt_env >= 0 ? nt_env != 0 : 10 * P.nnz + 18 * (int64_t)P.nrows > (int64_t)256 * 1024 * 1024;
+        // sorted slices: a wave's 64 stores of y name up to 64 lines of its window -- plain stores, which the L2 merges into whole lines
+        static const int sorted_plain = std::getenv("SAENA_SELL_SORTED_PLAIN_STORES") ? std::atoi(std::getenv("SAENA_SELL_SORTED_PLAIN_STORES")) : 1;
+        if (P.sl_sorted && sorted_plain) a.st_plain = 1;
         a.nt_from = nt ? resident_slices(P.nslices, 10.0 * (double)P.nnz / (double)std::max(1, P.nslices)) : 0;
         SGPU_LAUNCH(pick_sell(epi, halo, P.sl_pair, nt), dim3((P.nslices + 3) / 4), dim3(sk::BLOCK), 0, g.cs, a, P.nrows);
     } else if (P.variant == 7 || P.variant == 8) {                       // compressed columns, entries in column order inside a block
@@ -2346,7 +2397,7 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
             const_cast<sgpu_op *>(op)->vname = buf;
             *kernel_name = op->vname.c_str();
         } else {
-            *kernel_name = (v == 11 && op->loc.sp_wide) ? "k_sellp<wide>" : (v == 14 && op->loc.sp_wide) ? "k_sellp2<wide>" : VARIANT_NAMES[v];      // the compact table around 1024 threads
+            *kernel_name = (v == 11 && op->loc.sp_wide) ? "k_sellp<wide>" : (v == 14 && op->loc.sp_wide) ? "k_sellp2<wide>" : (v == 9 && op->loc.sl_sorted) ? "k_sell<sorted>" : VARIANT_NAMES[v];      // the compact table around 1024 threads
         }
     }
     return SGPU_OK;
@@ -2506,8 +2557,8 @@ void finish_plan(sgpu_op *op, int bv) {
     if (bv == 14 && !keep) {                                      // k_sellp2 keeps the pattern ids and the table; k_sell's / k_sellp's arrays go
         CsrPart &L = op->loc;
         L.free_sell_columns();
-        hipFree(L.sl_val); hipFree(L.sl_ptr); L.sl_val = nullptr; L.sl_ptr = nullptr;
-        L.sl_vals = false; L.sl_vals_tried = 0;                       // (a later set_variant(11) re-orders the values again, from the device's CSR copy)
+        hipFree(L.sl_val); hipFree(L.sl_ptr); hipFree(L.sl_perm); L.sl_val = nullptr; L.sl_ptr = nullptr; L.sl_perm = nullptr;
+        L.sl_vals = false; L.sl_vals_tried = 0; L.sl_sorted = false;                       // (a later set_variant(11) re-orders the values again, from the device's CSR copy)
     } else if (bv != 9 && bv != 11 && bv != 15 && !keep) op->loc.free_sell();
     else if ((bv == 11 || bv == 15) && !keep) op->loc.free_sell_columns();    // k_sellp / k_sellpx keep the values and the slice pointers only
     else if (bv == 9 && !keep) op->loc.free_sellp();
@@ -2610,7 +2661,7 @@ int sgpu_op_autotune(sgpu_op *op) {
                 CHK(build_sell(op->loc, op->h_val_all));
                 if (op->loc.sl_ok) variants.push_back(9);
             }
-            sell_like = op->loc.sp_ok || op->loc.sl_ok;
+            sell_like = op->loc.sp_ok || (op->loc.sl_ok && !op->loc.sl_sorted);         // (sorted slices: one more candidate next to the tile kernels)
         }
     }
     const double t_sell = now_s();

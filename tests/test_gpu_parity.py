@@ -109,11 +109,25 @@ def test_spmv_lane_variants(capi, name, lanes):
     assert np.all(np.abs(got - want) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
 
 
-def _sell_eligible(entries, M):
-    """the library's rule for the sliced-ELLPACK form: slices of 64 rows padded to their longest row, <= 12 % padding"""
+def _sell_form(entries, M):
+    """the library's rule for the sliced-ELLPACK form: slices of 64 rows padded to their longest row, <= 12 % padding ->
+    "plain"; else, with the rows sorted by length (longest first) inside windows of 2048 rows, <= 5 % padding and at least
+    4 entries per row -> "sorted" (k_sell<sorted>, opt-in: SAENA_SELL_SORTED=1); else None"""
     n = np.bincount(np.asarray(entries["row"]), minlength=M)
     padded = sum(64 * int(n[s:s + 64].max()) for s in range(0, M, 64))
-    return padded <= 1.12 * len(entries)
+    if padded <= 1.12 * len(entries):
+        return "plain"
+    if len(entries) < 4 * M:
+        return None
+    padded = 0
+    for w in range(0, M, 2048):
+        ns = np.sort(n[w:w + 2048])[::-1]
+        padded += sum(64 * int(ns[s]) for s in range(0, len(ns), 64))
+    return "sorted" if padded <= 1.05 * len(entries) else None
+
+
+def _sell_eligible(entries, M):
+    return _sell_form(entries, M) == "plain"
 
 
 def _sellp_table(entries, M):
@@ -160,7 +174,7 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
         with pytest.raises(capi.SgpuError, match="column-major"):      # rows longer than the 16 KiB tile: refused, not mis-computed
             G.set_variant(variant)
         return
-    if variant == 9 and not _sell_eligible(entries, M):
+    if variant == 9 and _sell_form(entries, M) != "plain":
         with pytest.raises(capi.SgpuError, match="sliced-ELLPACK"):    # uneven rows: more than 12 % padding, refused
             G.set_variant(variant)
         return
@@ -228,6 +242,76 @@ def test_kernel_variants(capi, name, variant, monkeypatch):
     du = capi.DeviceVector(M, rhs)
     G.prolong_correct(dx, du)
     assert rel(du.download(), rhs - A.matvec(x)) <= TOL_SMOOTH
+
+
+def _uneven_rows_operator(M, N, seed, lengths, square=False):
+    """a transfer-like operator: three row lengths in random order (plain slices pad > 40 %), columns around r * N / M; M is
+    no multiple of 64 and spans several sort windows"""
+    rng = np.random.default_rng(seed)
+    lens = rng.choice(lengths, size=M, p=[0.3, 0.4, 0.3])
+    rows = np.repeat(np.arange(M), lens)
+    base = (np.arange(M) * (N / M)).astype(np.int64)
+    cols = np.concatenate([np.sort(rng.choice(np.arange(max(0, b - 60), min(N, b + 60)), size=l, replace=False)) for b, l in zip(base, lens)])
+    vals = np.sin(0.3 * rows + 0.7 * cols) + 1.5
+    if square:                                            # a diagonal that lets the smoothers run: the row's own column, dominant
+        keep = cols != rows
+        rows, cols, vals = rows[keep], cols[keep], vals[keep]
+        rows = np.concatenate([rows, np.arange(M)]); cols = np.concatenate([cols, np.arange(M)]); vals = np.concatenate([vals, np.full(M, 90.0)])
+    return orc.coo_from_arrays(rows.astype(np.int32), cols.astype(np.int32), vals)
+
+
+@pytest.mark.parametrize("M,N,lengths", [(9001, 2300, (12, 18, 27)), (6500, 40000, (4, 6, 9)), (4999, 4999, (12, 18, 27))])
+def test_sliced_ellpack_with_rows_sorted_by_length(capi, M, N, lengths, monkeypatch):
+    """k_sell<sorted> (round 4, OPT-IN with SAENA_SELL_SORTED=1: it lost to the tile kernels on the transfers it was built for,
+    DESIGN 9): an operator whose uneven rows pad a plain sliced-ELLPACK layout beyond 12 % takes the layout
+    with its rows sorted by length inside windows of 2048 rows (a permutation per window, <= 5 % padding).  Same sequential
+    row sums as the reference's loop: every fused epilogue bit-identical to the oracle's / to the CSR kernel's at one lane per
+    row (two positions per load at 12-27 entries per row, one at 4-9); the row-pattern forms refuse the operator."""
+    square = M == N
+    entries = _uneven_rows_operator(M, N, 11, lengths, square)
+    assert _sell_form(entries, M) == "sorted"
+    A = orc.OracleOp(entries, M, N, orc.split_even(M, 1), orc.split_even(N, 1), square=square)
+    G = util.gpu_operator(A)
+    with pytest.raises(capi.SgpuError, match="sliced-ELLPACK"):       # not asked for: refused as before
+        G.set_variant(9)
+    monkeypatch.setenv("SAENA_SELL_SORTED", "1")
+    G = util.gpu_operator(A)
+    G.set_variant(9)
+    assert G.variant() == (9, "k_sell<sorted>")
+    x = inputs.v2(N)
+    dx, dy = capi.DeviceVector(N, x), capi.DeviceVector(M)
+    G.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), A.matvec(x))
+    u = inputs.rhs2(M)                                     # u -= A e (the prolongation's epilogue)
+    du = capi.DeviceVector(M, u)
+    G.prolong_correct(dx, du)
+    np.testing.assert_array_equal(du.download(), u - A.matvec(x))
+    with pytest.raises(capi.SgpuError, match="row-pattern"):
+        G.set_variant(11)
+    if not square:
+        return
+    rhs = inputs.rhs2(M)
+    dr = capi.DeviceVector(M, rhs)
+    G.residual(dx, dr, dy)
+    got = dy.download()
+    H = util.gpu_operator(A)                               # the CSR kernel at one lane per row: the same sums in the same order
+    H.set_variant(0); H.set_lanes_per_row(1)
+    H.residual(dx, dr, dy)
+    np.testing.assert_array_equal(got, dy.download())
+    assert rel(got, A.residual(x, rhs)) <= TOL_SMOOTH
+    for sweep in ("jacobi", "chebyshev"):
+        d1, d2 = capi.DeviceVector(M, x), capi.DeviceVector(M, x)
+        if sweep == "jacobi":
+            G.jacobi(3, d1, dr); H.jacobi(3, d2, dr)
+            assert rel(d1.download(), A.jacobi(3, x, rhs)) <= TOL_SMOOTH
+        else:
+            A.set_eig(1.9371)
+            G.chebyshev(3, 1.9371, d1, dr); H.chebyshev(3, 1.9371, d2, dr)
+            assert rel(d1.download(), A.chebyshev(3, x, rhs)) <= TOL_SMOOTH
+        np.testing.assert_array_equal(d1.download(), d2.download())
+    G.autotune()                                           # the plan-time choice runs with the form among its candidates
+    G.spmv(dx, dy)
+    assert np.all(np.abs(dy.download() - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
 
 
 def _clustered_operator(M, N, clusters, seed):
