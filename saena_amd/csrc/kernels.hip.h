@@ -1173,8 +1173,10 @@ constexpr int XL_PER_CU = 1;              // (half windows around 512 threads, t
 struct XldsArgs {
     const int4 *info;      // per workgroup: first column, windows, offset of its table in `tab`, -
     const int  *tab;
-    double     *acc;       // [M] partial row sums between windows (nullptr when every workgroup has one window)
+    double     *acc;       // [M] partial row sums between windows (nullptr when every workgroup has one window, or with acc_lds)
     int         ncols;
+    int         win;       // columns per window (<= XL_MAX)
+    int         acc_lds;   // the partial row sums of a chunk live in LDS behind the window: xs[win + row in chunk] (the plan keeps rows <= XL_MAX - win)
 };
 // RP > 1 (k_csr_xldsr, round 4): SHORT rows -- an irregular operator of a few dozen entries per row (BASELINE configs[4] scaled to
 // 1 M rows: 13-205 entries, hubs of 3 000).  With one row per group step the kernel is bound by the LATENCY of a row, not by bytes:
@@ -1194,10 +1196,11 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
     const int r0 = a.blk_row[blockIdx.x], nr = a.blk_row[blockIdx.x + 1] - r0;
     const int4 inf = w.info[blockIdx.x];
     const int T = inf.y;
+    double *accs = xs + w.win;
     for (int t = 0; t < T; ++t) {
         if (t > 0) __syncthreads();                               // everyone is done with the previous window
-        const int base = inf.x + t * XL_MAX;
-        const int n = w.ncols - base < XL_MAX ? w.ncols - base : XL_MAX;
+        const int base = inf.x + t * w.win;
+        const int n = w.ncols - base < w.win ? w.ncols - base : w.win;
         for (int i0 = tid; i0 < n; i0 += 8 * XL_BLOCK) {           // eight loads of a thread in flight before their stores
             double v[8];
 #pragma unroll
@@ -1282,8 +1285,9 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
                 }
                 if (l < RP && k + l < nr) {                       // lanes 0 .. RP-1: an epilogue each
                     const int r = r0 + k + l;
-                    if (t > 0) mine = w.acc[r] + mine;
-                    if (t < T - 1) w.acc[r] = mine;
+                    // the row's sum over the windows so far: in LDS behind the window, or in global memory
+                    if (t > 0) mine = (w.acc_lds ? accs[k + l] : w.acc[r]) + mine;
+                    if (t < T - 1) { if (w.acc_lds) accs[k + l] = mine; else w.acc[r] = mine; }
                     else epilogue<EPI, HALO>(a, r, mine);
                 }
                 k = knext;
@@ -1325,8 +1329,8 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
             int nk = 0;
             if (l == 0) {
                 const int r = r0 + k;
-                if (t > 0) sum = w.acc[r] + sum;
-                if (t < T - 1) w.acc[r] = sum;
+                if (t > 0) sum = (w.acc_lds ? accs[k] : w.acc[r]) + sum;
+                if (t < T - 1) { if (w.acc_lds) accs[k] = sum; else w.acc[r] = sum; }
                 else epilogue<EPI, HALO>(a, r, sum);
                 nk = atomicAdd(&next_row, 1);
             }
@@ -1359,6 +1363,7 @@ struct SellxArgs {
     const unsigned short *col;
     double               *acc;
     int                   ncols;
+    int                   win, acc_lds;   // as in XldsArgs
 };
 template <int EPI, bool HALO>
 __global__ __launch_bounds__(XL_BLOCK) void k_sellx(const SpmvArgs a, const SellxArgs w) {
@@ -1371,8 +1376,8 @@ __global__ __launch_bounds__(XL_BLOCK) void k_sellx(const SpmvArgs a, const Sell
     const int T = inf.y;
     for (int t = 0; t < T; ++t) {
         if (t > 0) __syncthreads();                               // everyone is done with the previous window
-        const int base = inf.x + t * XL_MAX;
-        const int n = w.ncols - base < XL_MAX ? w.ncols - base : XL_MAX;
+        const int base = inf.x + t * w.win;
+        const int n = w.ncols - base < w.win ? w.ncols - base : w.win;
         for (int i0 = tid; i0 < n; i0 += 8 * XL_BLOCK) {           // eight loads of a thread in flight before their stores
             double v[8];
 #pragma unroll
@@ -1393,7 +1398,7 @@ __global__ __launch_bounds__(XL_BLOCK) void k_sellx(const SpmvArgs a, const Sell
             // the row's partial sum of the windows before this one: fetched now, needed after the piece (a dependent L2 round
             // trip at the end of every slice otherwise)
             double prev = 0.0;
-            if (row != 0xffffu && !(meta >> 31)) prev = w.acc[r0 + (int)row];
+            if (row != 0xffffu && !(meta >> 31)) prev = w.acc_lds ? xs[w.win + (int)row] : w.acc[r0 + (int)row];
             constexpr int UP = SELLX_UP;
             double sum = 0.0;
             for (int q = 0; q < P; q += UP) {
@@ -1415,7 +1420,7 @@ __global__ __launch_bounds__(XL_BLOCK) void k_sellx(const SpmvArgs a, const Sell
             if (row != 0xffffu) {
                 const int r = r0 + (int)row;
                 if (!(meta >> 31)) sum = prev + sum;
-                if (t < T - 1) w.acc[r] = sum;
+                if (t < T - 1) { if (w.acc_lds) xs[w.win + (int)row] = sum; else w.acc[r] = sum; }
                 else epilogue<EPI, HALO>(a, r, sum);
             }
         }

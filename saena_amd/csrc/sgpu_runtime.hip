@@ -193,6 +193,8 @@ struct CsrPart {
     int4           *xl_info = nullptr;
     double         *xl_acc = nullptr;
     int             xl_nblk = 0, xl_maxt = 1;
+    int             xl_win = 0;            // columns per window of x in LDS: XL_MAX, or less where the chunks' partial row sums live in LDS behind the window
+    bool            xl_acc_lds = false;
     std::vector<int>  xl_blk_h;            // host copies of the chunk plan (k_sellx is built on top of it)
     std::vector<int4> xl_info_h;
     double          xl_piece = 0.0;
@@ -568,21 +570,43 @@ int build_xlds(CsrPart &P) {
     }
     blk[(size_t)nb] = M;
     std::vector<int4> info((size_t)nb);
-    int64_t tabsz = 0, pieces = 0;
-    int maxt = 1;
+    std::vector<int> cmins((size_t)nb), cmaxs((size_t)nb);
+    int maxrows = 0;
     for (int b = 0; b < nb; ++b) {
         int cmin = INT32_MAX, cmax = -1;
         for (int r = blk[b]; r < blk[b + 1]; ++r)
             if (P.h_rp[r + 1] > P.h_rp[r]) { cmin = std::min(cmin, P.h_col[(size_t)P.h_rp[r]]); cmax = std::max(cmax, P.h_col[(size_t)P.h_rp[r + 1] - 1]); }
         if (cmax < 0) { cmin = 0; cmax = 0; }
-        const int T = (cmax - cmin) / sk::XL_MAX + 1, rows = blk[b + 1] - blk[b];
-        if (T > sk::XL_MAXT) return SGPU_OK;
-        maxt = std::max(maxt, T);
-        info[(size_t)b] = make_int4(cmin, T, (int)tabsz, 0);
+        cmins[(size_t)b] = cmin; cmaxs[(size_t)b] = cmax;
+        maxrows = std::max(maxrows, blk[b + 1] - blk[b]);
+    }
+    // The window: all XL_MAX doubles of the LDS array -- or, where chunks reach over several windows, XL_MAX less the chunk's rows:
+    // a row's partial sum then travels from window to window in LDS behind the window of x (round 4) instead of through global
+    // memory (`acc`: an 8-byte load and store per (row, window), the load at the end of a row's chain of dependent round trips).
+    // Measured on the 256^3 hierarchy: R2 (k_csr_xlds, 7 windows) 160.6 -> 153.0 us, level 3 292.0 -> 287.2, R3 79.4 -> 77.9; k_sellx on
+    // the 263-entry level unchanged (407 us either way).  Kept in global memory where a chunk holds more rows than a quarter of the array.
+    auto windows = [&](int win) {
+        int mt = 1;
+        for (int b = 0; b < nb; ++b) mt = std::max(mt, (cmaxs[(size_t)b] - cmins[(size_t)b]) / win + 1);
+        return mt;
+    };
+    int win = sk::XL_MAX, maxt = windows(sk::XL_MAX);
+    if (maxt > sk::XL_MAXT) return SGPU_OK;
+    bool acc_lds = false;
+    if (maxt > 1 && maxrows <= sk::XL_MAX / 4 && !std::getenv("SAENA_XLDS_GLOBAL_ACC")) {
+        const int win2 = sk::XL_MAX - (maxrows + 63) / 64 * 64;
+        const int mt2 = windows(win2);
+        if (mt2 <= sk::XL_MAXT) { win = win2; maxt = mt2; acc_lds = true; }
+    }
+    int64_t tabsz = 0, pieces = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int T = (cmaxs[(size_t)b] - cmins[(size_t)b]) / win + 1, rows = blk[b + 1] - blk[b];
+        info[(size_t)b] = make_int4(cmins[(size_t)b], T, (int)tabsz, 0);
         tabsz += (int64_t)rows * (T + 1);
         pieces += (int64_t)rows * T;
         if (tabsz > INT32_MAX / 2) return SGPU_OK;
     }
+    P.xl_win = win; P.xl_acc_lds = acc_lds;
     P.xl_piece = (double)P.nnz / (double)std::max<int64_t>(1, pieces);    // mean entries per (row, window): the autotune wants >= 24
     P.xl_blk_h = blk; P.xl_info_h = info;
     CHK(dev_upload(&P.xl_blk, blk.data(), blk.size()));
@@ -595,7 +619,7 @@ int build_xlds(CsrPart &P) {
         HIPCHK(hipMemsetAsync(P.xl_col, 0, nc * sizeof(unsigned short), g.cs));
         HIPCHK(hipMemsetAsync(P.xl_tab, 0, ntab * sizeof(int), g.cs));
         SGPU_LAUNCH(sk::k_xlds_build, dim3(nb), dim3(sk::BLOCK), 0, g.cs, (const int *)P.col, (const int *)P.row_ptr, (const int *)P.xl_blk, (const int4 *)P.xl_info,
-                    P.xl_tab, P.xl_col, (int)sk::XL_MAX);
+                    P.xl_tab, P.xl_col, win);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(g.cs));
     } else {
@@ -610,9 +634,9 @@ int build_xlds(CsrPart &P) {
                 const int p0 = P.h_rp[r0 + k], p1 = P.h_rp[r0 + k + 1];
                 int p = p0;
                 for (int w = 0; w <= T; ++w) {                     // columns ascend along a row: the windows cut it into consecutive pieces
-                    const int lim = w == T ? INT32_MAX : cmin + w * sk::XL_MAX;
+                    const int lim = w == T ? INT32_MAX : cmin + w * win;
                     while (p < p1 && P.h_col[(size_t)p] < lim) {
-                        col[(size_t)p] = (unsigned short)(P.h_col[(size_t)p] - (cmin + (w - 1) * sk::XL_MAX));
+                        col[(size_t)p] = (unsigned short)(P.h_col[(size_t)p] - (cmin + (w - 1) * win));
                         ++p;
                     }
                     tb[(size_t)w * rows + k] = w == T ? p1 : p;
@@ -629,7 +653,7 @@ int build_xlds(CsrPart &P) {
     CHK(dev_upload(&P.xl_col, col.data(), col.size()));
     CHK(dev_upload(&P.xl_tab, tab.data(), tab.size()));
     }
-    if (maxt > 1) HIPCHK(hipMalloc(&P.xl_acc, (size_t)M * sizeof(double)));
+    if (maxt > 1 && !acc_lds) HIPCHK(hipMalloc(&P.xl_acc, (size_t)M * sizeof(double)));
     P.xl_nblk = nb;
     P.xl_maxt = maxt;
     P.xl_ok = true;
@@ -1141,7 +1165,7 @@ int build_sellx(CsrPart &P, const std::vector<double> &h_val_all) {
                 const int p0 = P.h_rp[(size_t)r0 + k], p1 = P.h_rp[(size_t)r0 + k + 1];
                 int p = p0;
                 for (int w = 0; w < T; ++w) {
-                    const int lim = w == T - 1 ? INT32_MAX : cmin + (w + 1) * sk::XL_MAX;
+                    const int lim = w == T - 1 ? INT32_MAX : cmin + (w + 1) * P.xl_win;
                     const int q0 = p;
                     while (p < p1 && P.h_col[(size_t)p] < lim) ++p;
                     if (p > q0 || w == T - 1) pw[(size_t)w].push_back(Piece{k, q0, p - q0});
@@ -1181,7 +1205,7 @@ int build_sellx(CsrPart &P, const std::vector<double> &h_val_all) {
                 bptr[(size_t)b * (sk::XL_MAXT + 1) + (size_t)w] = (int)sl;
                 if (w >= T) continue;
                 const auto &v = pieces[(size_t)b][(size_t)w];
-                const int wbase = cmin + w * sk::XL_MAX;
+                const int wbase = cmin + w * P.xl_win;
                 for (size_t i = 0; i < v.size(); i += 64, ++sl) {
                     const int width = (v[i].len + 1) & ~1, PP = width >> 1;
                     sptr[(size_t)sl] = (int)e;
@@ -1564,6 +1588,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         a.blk_row = P.xl_blk; a.nblk = P.xl_nblk;
         sk::SellxArgs w;
         w.info = P.xl_info; w.bptr = P.sx_bptr; w.sptr = P.sx_sptr; w.meta = P.sx_meta; w.val = P.sx_val; w.col = P.sx_col; w.acc = P.xl_acc; w.ncols = P.ncols;
+        w.win = P.xl_win; w.acc_lds = P.xl_acc_lds ? 1 : 0;
         if (nt_rt == 0 && !std::getenv("SAENA_STREAM_NT")) a.nt = 10 * P.nnz > (int64_t)256 * 1024 * 1024 ? 1 : 0;      // non-temporal streams beyond the Infinity Cache (438 -> 426 us)
         SGPU_LAUNCH(halo ? pick_sellx_h<true>(epi) : pick_sellx_h<false>(epi), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, w);
     } else if (P.variant == 10 || P.variant == 16) {              // x in LDS, a workgroup per CU (16: four rows per group step -- short rows)
@@ -1571,6 +1596,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         a.blk_row = P.xl_blk; a.nblk = P.xl_nblk; a.ccol = P.xl_col;
         sk::XldsArgs w;
         w.info = P.xl_info; w.tab = P.xl_tab; w.acc = P.xl_acc; w.ncols = P.ncols;
+        w.win = P.xl_win; w.acc_lds = P.xl_acc_lds ? 1 : 0;
         SGPU_LAUNCH(P.variant == 16 ? pick_xldsr(epi, P.lanes, halo) : pick_xlds(epi, P.lanes, halo), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, w);
     } else if (P.variant == 11) {                                 // sliced ELLPACK values + row patterns, a lane per row
         if (!P.sp_ok || !P.sl_val) return fail(SGPU_ERR_STATE, "the row-pattern form was not built");

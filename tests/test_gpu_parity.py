@@ -367,10 +367,14 @@ def test_compressed_columns_slot_offset_split(capi, clusters, split_expected):
     assert np.all(np.abs(dy.download() - A2.matvec(x)) <= TOL_SPMV * 24 * np.max(np.abs(x)))
 
 
-def test_x_in_lds_column_windows(capi):
+@pytest.mark.parametrize("acc", ["lds", "global"])
+def test_x_in_lds_column_windows(capi, acc, monkeypatch):
     """k_csr_xlds on rows that reach over more columns than one LDS window holds: three clusters of 40 entries 25 000
-    columns apart (three windows per row chunk, partial sums carried between them), against the oracle; an operator whose
-    rows scatter over 2^20 columns is refused, not mis-computed."""
+    columns apart (three windows per row chunk, partial sums carried between them -- in LDS behind a window shortened by the
+    chunk's rows (round 4), or through global memory as operators with many rows per chunk still do: SAENA_XLDS_GLOBAL_ACC=1),
+    against the oracle; an operator whose rows scatter over 2^20 columns is refused, not mis-computed."""
+    if acc == "global":
+        monkeypatch.setenv("SAENA_XLDS_GLOBAL_ACC", "1")
     M = N = 80000
     r = np.repeat(np.arange(M), 120)
     c = (r + np.tile(np.concatenate([k * 25000 + np.arange(40) for k in range(3)]), M)) % N
