@@ -1242,7 +1242,7 @@ int build_sellx(CsrPart &P, const std::vector<double> &h_val_all) {
     CHK(dev_upload(&P.sx_meta, meta.data(), meta.size(), 64));
     CHK(dev_upload(&P.sx_sptr, sptr.data(), sptr.size()));
     CHK(dev_upload(&P.sx_bptr, bptr.data(), bptr.size()));
-    if (!P.xl_acc && P.xl_maxt > 1) HIPCHK(hipMalloc(&P.xl_acc, (size_t)P.nrows * sizeof(double)));
+    if (!P.xl_acc && P.xl_maxt > 1 && !P.xl_acc_lds) HIPCHK(hipMalloc(&P.xl_acc, (size_t)P.nrows * sizeof(double)));
     P.sx_ok = true;
     return SGPU_OK;
 }
