@@ -349,7 +349,7 @@ def stored_bytes(info, kernel_name):
     if kernel_name == "k_rowt":                          # (opt-in) a 16-bit template id per row, nothing per entry
         return 2 * info["M"] + vec
     if kernel_name.startswith("k_sellp"):                # k_sellp, k_sellp2, their <wide> forms, k_sellpx: no column stream, a 16-bit pattern id per row
-        return 8 * nnz + 2 * info["M"] + vec             # (+ a table of a few hundred ints / a few KiB per workgroup)
+        return 8 * nnz + (6 if "rowbase" in kernel_name else 2) * info["M"] + vec   # (+ a table of a few hundred ints / a few KiB per workgroup; rowbase: + the row's first column)
     if kernel_name in ("k_sell", "k_sell<sorted>", "k_sellx", "k_csr_xlds", "k_csr_xldsr"):   # 16-bit column codes; k_sell: a 16-bit row length instead of the row pointer (padding < 1 % here)
         per_row = {"k_sell": 2, "k_sell<sorted>": 6}.get(kernel_name, 4)             # (sorted: + the 32-bit row a slice position holds)
         return 10 * nnz + per_row * info["M"] + vec

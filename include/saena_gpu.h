@@ -131,7 +131,9 @@ int sgpu_op_set_lanes_per_row(sgpu_op *op, int lanes);
  * table of (length, columns relative to the row) patterns held in LDS, 8 B per entry + 2 B per row (operators that
  * qualify for 9 and whose rows follow few enough patterns for a table of 4096 ints: stencils on structured grids, band
  * matrices; or, "k_sellp<wide>", where the patterns that every group of 1024 consecutive rows follows fit 8192 ints -- a
- * table per workgroup: the first smoothed-aggregation level of a structured grid; the local loop of src/saena_matrix_matvec.cpp:68-80 with the same sequential row sum); 12 k_sellx: sliced
+ * table per workgroup: the first smoothed-aggregation level of a structured grid; or, "k_sellp<rowbase>", where the rows repeat
+ * relative to their FIRST COLUMN, kept per row -- the level-0 restriction / prolongation of a structured grid, the loops of
+ * src/restrict_matrix.cpp:674-724 / src/prolong_matrix.cpp:550-614; the local loop of src/saena_matrix_matvec.cpp:68-80 with the same sequential row sum); 12 k_sellx: sliced
  * ELLPACK inside the (row chunk, column window) blocks of the x-in-LDS plan, a lane per row piece (rows of a few hundred
  * entries; at most 25 % padding); 13 k_rowt: row templates -- rows that repeat (length, relative columns, values) served
  * from a table in LDS, a 16-bit template id per row and nothing else of the operator (constant-coefficient stencils; never

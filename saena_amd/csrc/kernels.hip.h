@@ -74,6 +74,7 @@ struct SpmvArgs {
     // dst holds the pattern id of every row
     const int            *ptab;
     int                   pt_w, pt_n;
+    const int            *rbase;     // k_sellp<rowbase>: the column a row's pattern is relative to (its first), or nullptr: relative to the row index
     int                   ncols;     // k_sellp2: columns of x (its 16-byte loads stay inside the vector)
     int                   nt;        // non-temporal stream loads (k_csr_stream / cc16 / cm / wave / xlds): see ld_stream_*
     int                   nt_from;   // k_sell: first slice read with non-temporal loads (the slices before it stay in the Infinity Cache)
@@ -740,7 +741,8 @@ __global__ __launch_bounds__(WIDE ? SPW_BLOCK : BLOCK) void k_sellp(const SpmvAr
     // column of position j of this lane's row: the table is read at a clamped position (no branch per position), positions
     // past the row's length read x[0] and are never added
     const int wmax = WIDE ? (len > 0 ? len - 1 : 0) : a.pt_w - 1;
-    auto colof = [&](int j) { const int c = r + pt[j < wmax ? j : wmax]; return j < len ? c : 0; };
+    const int rf = a.rbase ? (r < nrows ? a.rbase[r] : 0) : r;       // what the pattern's offsets are relative to
+    auto colof = [&](int j) { const int c = rf + pt[j < wmax ? j : wmax]; return j < len ? c : 0; };
     const bool ntv = NT && s >= a.nt_from;                 // (k_sell: the first nt_from slices stay in the Infinity Cache)
     double sum = 0.0;
     if constexpr (!PAIR) {

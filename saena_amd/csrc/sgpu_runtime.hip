@@ -169,10 +169,12 @@ struct CsrPart {
     int            *sp_tab = nullptr;
     int             sp_w = 0, sp_n = 0;
     int            *sp_wgptr = nullptr;   // sp_wide: table of row group g = sp_tab[sp_wgptr[g] .. sp_wgptr[g + 1])
+    int            *sp_rbase = nullptr;   // "k_sellp<rowbase>" (round 4): the patterns are relative to the row's FIRST COLUMN, kept here (a transfer operator
+                                          // of a structured grid: its rows repeat relative to where they start, not to the row index); k_sellp only
     int64_t         sp_bytes = 0;      // values + pattern ids + x + y as this form stores them
     bool            sp_ok = false, sp_wide = false;   // sp_wide: a table per group of 1024 rows (k_sellp<WIDE>; sp_w = the largest, in ints)
     char            sp_tried = 0;
-    void free_sellp() { hipFree(sp_pat); hipFree(sp_tab); hipFree(sp_wgptr); sp_pat = nullptr; sp_tab = nullptr; sp_wgptr = nullptr; sp_ok = false; sp_wide = false; sp_tried = 0; }      // (and k_sellpx with it: free_sell)
+    void free_sellp() { hipFree(sp_pat); hipFree(sp_tab); hipFree(sp_wgptr); hipFree(sp_rbase); sp_pat = nullptr; sp_tab = nullptr; sp_wgptr = nullptr; sp_rbase = nullptr; sp_ok = false; sp_wide = false; sp_tried = 0; }      // (and k_sellpx with it: free_sell)
     // the column codes of k_sell alone (k_sellp keeps the values and the slice pointers)
     void free_sell_columns() {
         hipFree(sl_col); hipFree(sl_len); hipFree(sl_base); hipFree(sl_segptr);
@@ -828,10 +830,20 @@ int build_sell(CsrPart &P, const std::vector<double> &) {
 //     then length + offsets per pattern) and the rows' ids count within it.
 // Ids are dealt in order of first appearance, so the tables do not depend on threads or hashing.
 constexpr int SP_MAX_TABLE = 4096;
+// rowbase = false: a pattern is (length, columns relative to the ROW INDEX) -- square operators of a structured grid.
+// rowbase = true (round 4): ... relative to the row's FIRST COLUMN, which k_sellp then reads per row (4 B): the level-0 transfers of the
+// Poisson hierarchy repeat 30 (R0) / 33 (P0) such patterns where they follow tens of thousands relative to the row index.
+int build_sellp_mode(CsrPart &P, bool rowbase);
 int build_sellp(CsrPart &P) {
     if (P.sp_ok || P.sp_tried || !P.sl_vals || P.sl_sorted || P.h_rp.empty()) return SGPU_OK;     // (sorted slices: positions are not rows)
     P.sp_tried = 1;
+    CHK(build_sellp_mode(P, false));
+    if (!P.sp_ok && !std::getenv("SAENA_NO_SELLP_ROWBASE")) CHK(build_sellp_mode(P, true));
+    return SGPU_OK;
+}
+int build_sellp_mode(CsrPart &P, bool rowbase) {
     const int M = P.nrows;
+    auto ref = [&](int r) { return !rowbase ? r : (P.h_rp[r + 1] > P.h_rp[r] ? P.h_col[(size_t)P.h_rp[r]] : 0); };
     int W = 1;
     for (int r = 0; r < M; ++r) W = std::max(W, P.h_rp[r + 1] - P.h_rp[r]);
     if (W + 3 > sk::SPW_MAX_TABLE) return SGPU_OK;
@@ -854,22 +866,22 @@ int build_sellp(CsrPart &P) {
             std::string key;
             int prev = -1, np = 0;
             for (int r = r0; r < r1; ++r) {
-                const int p0 = P.h_rp[r], n = P.h_rp[r + 1] - p0;
+                const int p0 = P.h_rp[r], n = P.h_rp[r + 1] - p0, rf = ref(r);
                 if (prev >= 0 && Q.ctab[(size_t)Q.cstart[(size_t)prev]] == n) {   // most rows repeat the row before
                     const int *tt = &Q.ctab[(size_t)Q.cstart[(size_t)prev] + 1];
                     int j = 0;
-                    while (j < n && P.h_col[(size_t)p0 + j] - r == tt[j]) ++j;
+                    while (j < n && P.h_col[(size_t)p0 + j] - rf == tt[j]) ++j;
                     if (j == n) { Q.ids[(size_t)(r - r0)] = prev; continue; }
                 }
                 key.assign(reinterpret_cast<const char *>(&n), sizeof n);
-                for (int j = 0; j < n; ++j) { const int o = P.h_col[(size_t)p0 + j] - r; key.append(reinterpret_cast<const char *>(&o), sizeof o); }
+                for (int j = 0; j < n; ++j) { const int o = P.h_col[(size_t)p0 + j] - rf; key.append(reinterpret_cast<const char *>(&o), sizeof o); }
                 auto it = ids.find(key);
                 if (it == ids.end()) {
                     if (np == 65535 || Q.ctab.size() + (size_t)n + 1 > max_ints) { Q.overflow = true; return; }
                     it = ids.emplace(key, np++).first;
                     Q.cstart.push_back((int)Q.ctab.size());
                     Q.ctab.push_back(n);
-                    for (int j = 0; j < n; ++j) Q.ctab.push_back(P.h_col[(size_t)p0 + j] - r);
+                    for (int j = 0; j < n; ++j) Q.ctab.push_back(P.h_col[(size_t)p0 + j] - rf);
                 }
                 prev = it->second;
                 Q.ids[(size_t)(r - r0)] = prev;
@@ -956,14 +968,19 @@ int build_sellp(CsrPart &P) {
     if (std::getenv("SAENA_SETUP_TIMING")) {
         if (wide) fprintf(stderr, "[sgpu] row patterns: %d rows follow %d patterns of <= %d entries (%zu offsets in all); a table per %d rows, at most %zu ints, %.1f MB in all\n", M, npat, W,
                           ctab.size() - (size_t)npat, sk::SPW_BLOCK, max_group, (double)tab.size() * 4e-6);
-        else fprintf(stderr, "[sgpu] row patterns: %d rows follow %d patterns of <= %d entries (%zu ints, fixed-width table)\n", M, npat, W, tab.size());
+        else fprintf(stderr, "[sgpu] row patterns%s: %d rows follow %d patterns of <= %d entries (%zu ints, fixed-width table)\n", rowbase ? " relative to the row's first column" : "", M, npat, W, tab.size());
+    }
+    if (rowbase) {
+        std::vector<int> rb((size_t)((M + 127) / 128 * 128), 0);
+        for (int r = 0; r < M; ++r) rb[(size_t)r] = ref(r);
+        CHK(dev_upload(&P.sp_rbase, rb.data(), rb.size()));
     }
     CHK(dev_upload(&P.sp_pat, wide ? lpat.data() : pat.data(), pat.size()));
     CHK(dev_upload(&P.sp_tab, tab.data(), tab.size()));
     if (wide) CHK(dev_upload(&P.sp_wgptr, wgptr.data(), wgptr.size()));
     P.sp_w = wide ? (int)max_group : W; P.sp_n = npat; P.sp_wide = wide;
     P.h_pstart = std::move(cstart); P.h_ptab = std::move(ctab); P.h_pat = std::move(pat);      // (for build_sellpx; dropped when the plan settles)
-    P.sp_bytes = 8 * (int64_t)P.h_rp.back() + 2 * (int64_t)M + 8 * (int64_t)P.ncols + 8 * (int64_t)M + (wide ? 4 * (int64_t)tab.size() : 0);
+    P.sp_bytes = 8 * (int64_t)P.h_rp.back() + (rowbase ? 6 : 2) * (int64_t)M + 8 * (int64_t)P.ncols + 8 * (int64_t)M + (wide ? 4 * (int64_t)tab.size() : 0);
     P.sp_ok = true;
     return SGPU_OK;
 }
@@ -975,7 +992,7 @@ int build_sellp(CsrPart &P) {
 // appearance -- and its rows' ids count within it.  The form applies when windows and the largest of these tables fit
 // SPX_LDS_BYTES (two workgroups per CU).
 int build_sellpx(CsrPart &P) {
-    if (P.spx_ok || P.spx_tried || !P.sp_ok || !P.sl_val || P.h_ptab.empty() || P.h_pat.empty()) return SGPU_OK;
+    if (P.spx_ok || P.spx_tried || !P.sp_ok || P.sp_rbase || !P.sl_val || P.h_ptab.empty() || P.h_pat.empty()) return SGPU_OK;
     P.spx_tried = 1;
     const int npat = (int)P.h_pstart.size(), M = P.nrows;
     std::vector<int> offs;
@@ -1059,7 +1076,7 @@ int build_sellpx(CsrPart &P) {
 // The row-paired values of k_sellp2 on top of build_sellp's pattern ids: slices of 128 rows, a slice padded to its longest
 // row, position-major with the values of rows 2 l and 2 l + 1 side by side.
 int build_sellp2(CsrPart &P, const std::vector<double> &h_val_all) {
-    if (P.sp2_ok || P.sp2_tried || !P.sp_ok || P.h_rp.empty()) return SGPU_OK;
+    if (P.sp2_ok || P.sp2_tried || !P.sp_ok || P.sp_rbase || P.h_rp.empty()) return SGPU_OK;      // (rows r and r + 1 of a rowbase operator do not read adjacent columns)
     P.sp2_tried = 1;
     const int M = P.nrows;
     if (M < 2 || P.ncols < 2 || !P.val || !P.row_ptr) return SGPU_OK;      // (the kernel reads x 16 bytes at a time)
@@ -1535,7 +1552,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
     a.x = x; a.y = y; a.rhs = e.rhs; a.inv_diag = e.inv_diag; a.u = e.u; a.d = e.d; a.y2 = e.y2;
     a.c0 = e.c0; a.c1 = e.c1; a.skip = skip;
     a.segtab = nullptr; a.segptr = nullptr; a.ccol = nullptr; a.cc_ob = 12; a.dst = nullptr; a.cmptr = nullptr;
-    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0; a.ncols = P.ncols; a.nt_from = 0; a.uw = 0;
+    a.ptab = nullptr; a.pt_w = 0; a.pt_n = 0; a.ncols = P.ncols; a.nt_from = 0; a.uw = 0; a.rbase = nullptr;
     static const int st_plain_env = std::getenv("SAENA_STORE_PLAIN") ? std::atoi(std::getenv("SAENA_STORE_PLAIN")) : 0;
     a.st_plain = st_plain_env;
     static const int nt_rt = std::getenv("SAENA_STREAM_NT") ? std::atoi(std::getenv("SAENA_STREAM_NT")) : 0;
@@ -1602,6 +1619,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         if (!P.sp_ok || !P.sl_val) return fail(SGPU_ERR_STATE, "the row-pattern form was not built");
         a.blk_row = nullptr; a.nblk = P.nslices;
         a.val = P.sl_val; a.cmptr = P.sl_ptr; a.dst = P.sp_pat; a.ptab = P.sp_tab; a.pt_w = P.sp_w; a.pt_n = P.sp_n;
+        a.rbase = P.sp_rbase;
         // non-temporal streams once the stored operator (values, pattern ids, x, y) is beyond the 256 MiB Infinity Cache
         static const int nt_env = std::getenv("SAENA_SELLP_NT") ? std::atoi(std::getenv("SAENA_SELLP_NT")) : -1;
         const bool nt = nt_env >= 0 ? nt_env != 0 : P.sp_bytes > (int64_t)256 * 1024 * 1024;
@@ -2423,7 +2441,7 @@ int sgpu_op_get_variant(const sgpu_op *op, int *variant, const char **kernel_nam
             const_cast<sgpu_op *>(op)->vname = buf;
             *kernel_name = op->vname.c_str();
         } else {
-            *kernel_name = (v == 11 && op->loc.sp_wide) ? "k_sellp<wide>" : (v == 14 && op->loc.sp_wide) ? "k_sellp2<wide>" : (v == 9 && op->loc.sl_sorted) ? "k_sell<sorted>" : VARIANT_NAMES[v];      // the compact table around 1024 threads
+            *kernel_name = (v == 11 && op->loc.sp_rbase) ? (op->loc.sp_wide ? "k_sellp<wide,rowbase>" : "k_sellp<rowbase>") : (v == 11 && op->loc.sp_wide) ? "k_sellp<wide>" : (v == 14 && op->loc.sp_wide) ? "k_sellp2<wide>" : (v == 9 && op->loc.sl_sorted) ? "k_sell<sorted>" : VARIANT_NAMES[v];      // the compact table around 1024 threads
         }
     }
     return SGPU_OK;
@@ -2683,7 +2701,7 @@ int sgpu_op_autotune(sgpu_op *op) {
             // k_sell itself (10 B per entry: the same values + 16-bit column codes, which cost a host pass over the entries and 2 B per
             // entry of upload) only where the rows follow no patterns -- it never beat k_sellp on an operator that has them (8 B per
             // entry, the same structure: 128^3 level 1 137.8 against 119.3 us, profiles/r03_sellp_wide_l1_128.log)
-            if (!op->loc.sp_ok || all) {
+            if (!op->loc.sp_ok || op->loc.sp_rbase || all) {             // (... and next to a rowbase table: the 4 B per row it adds are a fifth of what the codes cost on 6-entry rows)
                 CHK(build_sell(op->loc, op->h_val_all));
                 if (op->loc.sl_ok) variants.push_back(9);
             }

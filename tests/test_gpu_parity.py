@@ -314,6 +314,58 @@ def test_sliced_ellpack_with_rows_sorted_by_length(capi, M, N, lengths, monkeypa
     assert np.all(np.abs(dy.download() - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
 
 
+def _transfer_like_operator(M, seed):
+    """a prolongation-like M x M/2 operator of a structured grid: row r reads a few runs of columns that start at r // 2 (its
+    aggregate) -- the same runs for rows of the same parity class, so the rows repeat a handful of patterns RELATIVE TO THEIR FIRST
+    COLUMN and tens of thousands relative to the row index; 6-7 entries per row (plain slices pad < 12 %)"""
+    N = M // 2 + 400
+    shapes = [np.array([0, 1, 2, 130, 131, 260]), np.array([0, 1, 129, 130, 131, 259, 260]), np.array([0, 2, 3, 128, 130, 258])]
+    r = np.arange(M)
+    rows = np.concatenate([r[(r // 7) % 3 == k].repeat(len(shapes[k])) for k in range(3)])
+    cols = np.concatenate([(r[(r // 7) % 3 == k][:, None] // 2 + shapes[k][None, :]).ravel() for k in range(3)])
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    vals = np.sin(0.3 * rows + 0.7 * cols) + 1.5
+    return orc.coo_from_arrays(rows.astype(np.int32), cols.astype(np.int32), vals), N
+
+
+def test_row_patterns_relative_to_the_first_column(capi, monkeypatch):
+    """k_sellp<rowbase> (round 4): a transfer operator whose rows repeat relative to their first column gets the row-pattern form
+    with that column kept per row (8 B per entry + 6 B per row instead of 10 + 2); same sequential sums -- bit-identical to the
+    oracle's loop, to k_sell and to the CSR kernel at one lane per row; the row-paired and x-in-LDS pattern forms refuse it;
+    SAENA_NO_SELLP_ROWBASE=1 leaves the operator without a pattern form as before."""
+    M = 140001                                             # (more than 65 535 patterns relative to the row index: that form is refused first)
+    entries, N = _transfer_like_operator(M, 3)
+    A = orc.OracleOp(entries, M, N, orc.split_even(M, 1), orc.split_even(N, 1), square=False)
+    G = util.gpu_operator(A)
+    G.set_variant(11)
+    assert G.variant() == (11, "k_sellp<rowbase>")
+    x, u = inputs.v2(N), inputs.rhs2(M)
+    dx, dy = capi.DeviceVector(N, x), capi.DeviceVector(M)
+    G.spmv(dx, dy)
+    got = dy.download()
+    np.testing.assert_array_equal(got, A.matvec(x))
+    du = capi.DeviceVector(M, u)
+    G.prolong_correct(dx, du)
+    np.testing.assert_array_equal(du.download(), u - A.matvec(x))
+    for v in (9, 0):
+        H = util.gpu_operator(A)
+        H.set_variant(v); H.set_lanes_per_row(1)
+        H.spmv(dx, dy)
+        np.testing.assert_array_equal(dy.download(), got)
+    for v, what in ((14, "row-paired"), (15, "x in LDS")):
+        with pytest.raises(capi.SgpuError, match=what):
+            G.set_variant(v)
+    G.autotune()                                           # the plan-time choice: k_sellp<rowbase> or k_sell, the same sums either way
+    assert G.variant()[1] in ("k_sellp<rowbase>", "k_sell")
+    G.spmv(dx, dy)
+    np.testing.assert_array_equal(dy.download(), got)
+    monkeypatch.setenv("SAENA_NO_SELLP_ROWBASE", "1")
+    G2 = util.gpu_operator(A)
+    with pytest.raises(capi.SgpuError, match="row-pattern"):
+        G2.set_variant(11)
+
+
 def _clustered_operator(M, N, clusters, seed):
     """rectangular operator whose rows touch `clusters` runs of 8 consecutive columns spread over all N columns; the 64
     rows of a group share their clusters (a row block then touches a few hundred short segments far apart)"""
