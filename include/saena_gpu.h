@@ -165,6 +165,12 @@ int sgpu_op_autotune(sgpu_op *op);
 int sgpu_spmv(sgpu_op *op, const value_t *v, value_t *w);
 /* res = A u - rhs.  saena_matrix::residual (saena_matrix.tpp:16-23) */
 int sgpu_residual(sgpu_op *op, const value_t *u, const value_t *rhs, value_t *res);
+/* res = rhs - A u.  saena_matrix::residual_negative (saena_matrix.tpp:26-33; the GMRES drivers of saena_object_solve.cpp:3848-4291).
+ * Computed as 1 * 1 * (rhs - A u) through sgpu_residual_multiply: the same bits, signs of zeros included. */
+int sgpu_residual_negative(sgpu_op *op, const value_t *u, const value_t *rhs, value_t *res);
+/* res = c * w o (rhs - A u), evaluated as (c w_i) (rhs_i - (A u)_i).  saena_matrix::residual_multiply (saena_matrix.tpp:35-43: the
+ * Chebyshev steps of saena_matrix.cpp:1099,1119 with w = inv_diag); fused into the operator's kernel.  res must not alias u, rhs or w. */
+int sgpu_residual_multiply(sgpu_op *op, const value_t *u, const value_t *rhs, value_t *res, const value_t *w, value_t c);
 /* iter damped-Jacobi sweeps, u in/out.  saena_matrix::jacobi (saena_matrix.cpp:1044-1071).
  * omega is the reference's float(2.0/3) promoted to double unless overridden. */
 int sgpu_jacobi(sgpu_op *op, int iter, value_t omega, value_t *u, const value_t *rhs);

@@ -246,6 +246,15 @@ class OracleOp:
         lib().orc_residual(self.p, _pd(np.ascontiguousarray(u)), _pd(np.ascontiguousarray(rhs)), _pd(res))
         return res
 
+    def residual_negative(self, u, rhs):
+        """res = rhs - A u: saena_matrix::residual_negative (include/saena_matrix.tpp:26-33) -- matvec, then res[i] = rhs[i] - res[i]"""
+        return np.asarray(rhs, np.float64) - self.matvec(u)
+
+    def residual_multiply(self, u, rhs, w, c):
+        """res = c * w o (rhs - A u): saena_matrix::residual_multiply (include/saena_matrix.tpp:35-43) -- matvec, then
+        res[i] = c * w[i] * (rhs[i] - res[i]), the product left to right"""
+        return (float(c) * np.asarray(w, np.float64)) * (np.asarray(rhs, np.float64) - self.matvec(u))
+
     def jacobi(self, it, u, rhs):
         u = np.array(u, np.float64)
         lib().orc_jacobi(self.p, it, _pd(u), _pd(np.ascontiguousarray(rhs, np.float64)))

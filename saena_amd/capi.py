@@ -71,6 +71,8 @@ SYMBOLS = {
     "sgpu_op_get_variant": (C.c_int, [_VP, _PI, C.POINTER(C.c_char_p)]),
     "sgpu_spmv": (C.c_int, [_VP, _VP, _VP]),
     "sgpu_residual": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "sgpu_residual_negative": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "sgpu_residual_multiply": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_double]),
     "sgpu_jacobi": (C.c_int, [_VP, C.c_int, C.c_double, _VP, _VP]),
     "sgpu_chebyshev": (C.c_int, [_VP, C.c_int, C.c_double, _VP, _VP]),
     "sgpu_prolong_correct": (C.c_int, [_VP, _VP, _VP]),
@@ -333,6 +335,12 @@ class Operator:
 
     def residual(self, u, rhs, res):
         check(lib().sgpu_residual(self.h, u.ptr, rhs.ptr, res.ptr))
+
+    def residual_negative(self, u, rhs, res):
+        check(lib().sgpu_residual_negative(self.h, u.ptr, rhs.ptr, res.ptr))
+
+    def residual_multiply(self, u, rhs, res, w, c):
+        check(lib().sgpu_residual_multiply(self.h, u.ptr, rhs.ptr, res.ptr, w.ptr, float(c)))
 
     def jacobi(self, it, u, rhs, omega=0.0):
         check(lib().sgpu_jacobi(self.h, int(it), float(omega), u.ptr, rhs.ptr))

@@ -1272,6 +1272,7 @@ struct sgpu_op {
     bool    has_remote = false;
     double *inv_diag = nullptr;
     double *tmp = nullptr;        // smoother ping-pong buffer [M]
+    double *ones = nullptr;       // [M] of 1.0 (sgpu_residual_negative: rhs - A u as 1 * 1 * (rhs - A u)), made at its first call
     double *dvec = nullptr;       // chebyshev d [M]
     // halo plan
     int     vIndexSize = 0, recvSize = 0;
@@ -1295,7 +1296,7 @@ struct sgpu_op {
     ~sgpu_op() {                  // also runs when sgpu_op_create bails out half-way: nothing leaks
         loc.free_all(); rem.free_all();
         hipFree(dense_rem);
-        hipFree(skip); hipFree(inv_diag); hipFree(tmp); hipFree(dvec); hipFree(vIndex); hipFree(send_buf); hipFree(recv_buf); hipFree(send_f); hipFree(recv_f);
+        hipFree(skip); hipFree(inv_diag); hipFree(tmp); hipFree(ones); hipFree(dvec); hipFree(vIndex); hipFree(send_buf); hipFree(recv_buf); hipFree(send_f); hipFree(recv_f);
         if (ev_x) hipEventDestroy(ev_x);
         if (ev_halo) hipEventDestroy(ev_halo);
     }
@@ -2885,6 +2886,27 @@ int sgpu_residual(sgpu_op *op, const value_t *u, const value_t *rhs, value_t *re
     if (!op || !u || !rhs || !res) return fail(SGPU_ERR_ARG, "null argument");
     EpiArgs e; e.rhs = rhs;
     return apply(op, sk::EPI_RESIDUAL, u, res, e);
+}
+
+// res = c * w o (rhs - A u): the epilogue of the first Chebyshev step with w in inv_diag's place -- (c w_i) (rhs_i - (A u)_i), the
+// reference's left-to-right product; that epilogue also writes u + res, here into the operator's ping-pong buffer, which nobody reads
+int sgpu_residual_multiply(sgpu_op *op, const value_t *u, const value_t *rhs, value_t *res, const value_t *w, value_t c) {
+    CHK(need_ctx());
+    if (!op || !u || !rhs || !res || !w) return fail(SGPU_ERR_ARG, "null argument");
+    if (res == u || res == rhs || res == w) return fail(SGPU_ERR_ARG, "residual_multiply: res must not alias u, rhs or w");
+    CHK(ensure_tmp(op));
+    EpiArgs e; e.rhs = rhs; e.inv_diag = w; e.u = u; e.d = res; e.c0 = c;
+    return apply(op, sk::EPI_CHEBY0, u, op->tmp, e);
+}
+
+int sgpu_residual_negative(sgpu_op *op, const value_t *u, const value_t *rhs, value_t *res) {
+    CHK(need_ctx());
+    if (!op || !u || !rhs || !res) return fail(SGPU_ERR_ARG, "null argument");
+    if (!op->ones && op->M > 0) {
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&op->ones), (size_t)op->M * sizeof(double)));
+        CHK(sgpu_vec_fill(op->ones, 1.0, (size_t)op->M));
+    }
+    return sgpu_residual_multiply(op, u, rhs, res, op->ones, 1.0);      // 1 * 1 * (rhs - A u): exact, signs of zeros included
 }
 
 int sgpu_jacobi(sgpu_op *op, int iter, value_t omega, value_t *u, const value_t *rhs) {

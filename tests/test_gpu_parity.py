@@ -518,6 +518,18 @@ def test_residual_jacobi_chebyshev(capi, name):
     du, dr, dres = capi.DeviceVector(M, u0), capi.DeviceVector(M, rhs), capi.DeviceVector(M)
     G.residual(du, dr, dres)
     np.testing.assert_array_equal(dres.download(), A.residual(u0, rhs))
+    # residual_negative (rhs - A u) and residual_multiply (c w o (rhs - A u)): saena_matrix.tpp:26-43, the same bits
+    G.residual_negative(du, dr, dres)
+    got = dres.download()
+    np.testing.assert_array_equal(got, A.residual_negative(u0, rhs))
+    np.testing.assert_array_equal(np.signbit(got), np.signbit(A.residual_negative(u0, rhs)))
+    w = inputs.v_sin(M) + 2.0
+    dw = capi.DeviceVector(M, w)
+    G.residual_multiply(du, dr, dres, dw, 0.37)
+    np.testing.assert_array_equal(dres.download(), A.residual_multiply(u0, rhs, w, 0.37))
+    np.testing.assert_array_equal(du.download(), u0)                             # u untouched
+    with pytest.raises(capi.SgpuError, match="alias"):
+        G.residual_multiply(du, dr, du, dw, 0.37)
     for it in (1, 2, 3, 4):
         du.upload(u0)
         G.jacobi(it, du, dr)
