@@ -31,7 +31,7 @@ DT = {"f64": np.float64, "i32": np.int32, "i64": np.int64}
 CASES = [
     (("poisson", "8"), (1, 2, 4)),
     (("poisson", "12"), (1, 2, 4)),
-    (("poisson", "16"), (1, 3)),
+    (("poisson", "16"), (1, 3, 8)),      # 8 ranks: north_star's count (343 / 300 / 386-row parts: the nparts^2-bucket partition)
     (("band", "300", "7"), (1, 2, 4)),
     (("band", "64", "63"), (1, 2)),
 ]

@@ -29,7 +29,7 @@ MPIRUN = "/opt/conda/bin/mpirun"
 REFDATA = "/root/reference/data"
 
 CASES = [
-    ("poisson16", dict(kind="poisson", m=16), (1, 2, 4)),
+    ("poisson16", dict(kind="poisson", m=16), (1, 2, 4, 8)),
     ("plat362", dict(kind="file", path=f"{REFDATA}/old/plat362.mtx"), (1, 2)),
 ]
 

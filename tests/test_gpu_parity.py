@@ -661,6 +661,52 @@ def test_halo_path_emulated_ranks(capi, name, nprocs, fp32):
         assert rel(W.gather(us), A.chebyshev(1, x, rhs)) <= TOL_SMOOTH
 
 
+@pytest.mark.parametrize("fixture", ["ref_poisson16.np8.npz", "ref_poisson12.np4.npz", "ref_SiH4.np4.npz"])
+def test_emulated_ranks_against_compiled_reference_golden(capi, fixture):
+    """The compiled reference's own outputs at 8 (and 4) MPI ranks -- `mpirun -np 8 oracle/_ref/ref_dump`: north_star's rank count, which
+    one card cannot host as 8 processes -- against the device path with that many EMULATED ranks at the reference's own partition:
+    pack kernel, halo, interior + boundary kernels per rank; matvec (fp64 and fp32 halo), residual, Jacobi and Chebyshev sweeps."""
+    ref = dict(np.load(os.path.join(GOLDEN, fixture)))
+    tag = fixture.split(".")[0][4:]
+    entries, M = orc.laplacian3d(int(tag[7:])) if tag.startswith("poisson") else matrices.entries(tag)
+    split = ref["split"]
+    nprocs = len(split) - 1
+    assert nprocs == int(fixture.split(".np")[1].split(".")[0])
+    v, v2, rhs2 = inputs.v_sin(M), inputs.v2(M), inputs.rhs2(M)
+    for fp32 in (False, True):
+        A = orc.OracleOp(entries, M, M, split)
+        A.set_use_double(not fp32)
+        W = util.EmulatedWorld(A, halo_fp32=fp32)
+        xs, ys = W.slices(v2, split), W.slices(np.zeros(M), split)
+        W.exchange(xs)
+        for r in range(nprocs):
+            W.g[r].spmv(xs[r], ys[r])
+        assert np.all(np.abs(W.gather(ys) - ref["Av2_float" if fp32 else "Av2"]) <= TOL_SPMV * abs_bound(entries, M, v2) + 1e-300)
+        if fp32:
+            continue
+        xs = W.slices(v, split)
+        W.exchange(xs)
+        for r in range(nprocs):
+            W.g[r].spmv(xs[r], ys[r])
+        assert np.all(np.abs(W.gather(ys) - ref["Av"]) <= TOL_SPMV * abs_bound(entries, M, v) + 1e-300)
+        xs, rs = W.slices(v2, split), W.slices(rhs2, split)
+        W.exchange(xs)
+        for r in range(nprocs):
+            W.g[r].residual(xs[r], rs[r], ys[r])
+        assert rel(W.gather(ys), ref["residual_v2_rhs2"]) <= TOL_SMOOTH
+        us = W.slices(v2, split)
+        for sweep in range(2):
+            W.exchange(us)
+            for r in range(nprocs):
+                W.g[r].jacobi(1, us[r], rs[r])
+        assert rel(W.gather(us), ref["jacobi2_v2_rhs2"]) <= TOL_SMOOTH
+        us = W.slices(v2, split)
+        W.exchange(us)
+        for r in range(nprocs):
+            W.g[r].chebyshev(1, 1.9371, us[r], rs[r])
+        assert rel(W.gather(us), ref["cheby1_v2_rhs2"]) <= TOL_SMOOTH
+
+
 @pytest.mark.parametrize("name,nprocs", [("poisson20", 3), ("band64_63", 2), ("irregular5000", 5)])
 def test_halo_path_column_ordered_kernel(capi, name, nprocs, monkeypatch):
     """k_csr_cm (and k_sell) with a halo in play (boundary rows masked out of the local launch, computed by k_csr_boundary): the
@@ -791,7 +837,7 @@ def test_dense_variant(capi, name):
     assert np.all(np.abs(dy.download() - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
 
 
-@pytest.mark.parametrize("fixture", ["ref_band64_63.np2.npz", "ref_band300_7.np4.npz", "ref_poisson8.np4.npz", "ref_plat362.np2.npz", "ref_band64_63.np1.npz"])
+@pytest.mark.parametrize("fixture", ["ref_band64_63.np2.npz", "ref_band300_7.np4.npz", "ref_poisson8.np4.npz", "ref_plat362.np2.npz", "ref_band64_63.np1.npz", "ref_poisson16.np8.npz"])
 @pytest.mark.parametrize("fp32", [False, True], ids=["fp64", "float"])
 def test_dense_operator_with_halo_against_compiled_reference(capi, fixture, fp32):
     """SURVEY 8 row f3 across ranks: the row-partitioned dense operator (saena_matrix_dense::matvec_dense /
