@@ -138,6 +138,9 @@ def _worker(rank, world, port, case, ret):
             rhs_want = None
         split = orc.split_nnz(entries, Mbig, world)
         np.testing.assert_array_equal(A.split, split)
+        golden = os.path.join(ROOT, "tests", "golden", f"ref_{case[0]}{case[1]}.np{world}.npz")
+        if case[0] == "poisson" and os.path.exists(golden):                  # ... and the compiled reference's own partition at this rank count
+            np.testing.assert_array_equal(A.split, np.load(golden)["split"])
         O = orc.OracleOp(entries, Mbig, Mbig, split)
         assert_layout_equal(A.layout(), oracle_layout(O, rank), f"{case} rank {rank}")
         if rhs_want is not None:
@@ -163,7 +166,7 @@ def _worker(rank, world, port, case, ret):
 
 
 @pytest.mark.parametrize("world,case", [(2, ("poisson", 8)), (3, ("poisson", 12)), (2, ("band", 150, 7)), (4, ("band", 16, 15)),
-                                        (3, ("file", "plat362"))])
+                                        (3, ("file", "plat362")), (8, ("poisson", 16))])      # 8: north_star's rank count (fixture: mpirun -np 8 of the compiled reference)
 def test_distributed_assemble_gloo(world, case):
     import torch.multiprocessing as mp
     port = _free_port()
