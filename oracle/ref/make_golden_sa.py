@@ -31,9 +31,9 @@ CONN = 0.2                                     # data/options001.xml conn_str (h
 CASES = [
     ("poisson8", dict(kind="poisson", m=8), (1, 2, 4)),
     ("poisson12", dict(kind="poisson", m=12), (1, 2, 4)),
-    ("poisson16", dict(kind="poisson", m=16), (1, 2, 4)),
+    ("poisson16", dict(kind="poisson", m=16), (1, 2, 4, 8)),
     ("plat362", dict(kind="file", path=f"{REFDATA}/old/plat362.mtx"), (1, 2)),
-    ("poisson24", dict(kind="poisson", m=24), (1, 3)),
+    ("poisson24", dict(kind="poisson", m=24), (1, 3, 8)),
 ]
 
 

@@ -42,7 +42,7 @@ def fixtures():
 
 def test_fixture_set_is_complete():
     have = fixtures()
-    for tag, nps in (("poisson8", (1, 2, 4)), ("poisson12", (1, 2, 4)), ("poisson16", (1, 2, 4)), ("plat362", (1, 2)), ("poisson24", (1, 3))):
+    for tag, nps in (("poisson8", (1, 2, 4)), ("poisson12", (1, 2, 4)), ("poisson16", (1, 2, 4, 8)), ("plat362", (1, 2)), ("poisson24", (1, 3, 8))):      # 8: north_star's rank count
         for p in nps:
             assert f"{tag}.np{p}" in have
 
