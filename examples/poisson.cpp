@@ -59,6 +59,12 @@ int main(int argc, char **argv) {
                           solver.residual_history().front(), solver.residual_history().back());
         solver.solve(u, &opts);                           // stationary V-cycle iteration
         if (!rank) printf("solve: %d iterations\n", solver.last_iterations());
+        value_t *ug = nullptr;                            // compiled out in the reference (#if 0): returns 0, u untouched (zeros when null)
+        if (solver.solve_pGMRES(ug, &opts) != 0 || solver.solve_GMRES(ug, &opts) != 0 || ug == nullptr || ug[0] != 0.0) {
+            if (!rank) printf("solve_GMRES / solve_pGMRES: not the reference's no-op\n");
+            return 5;
+        }
+        saena::free_vector(ug);
         saena::matrix C(comm);
         solver.matmat(&A, &A, &C, true, true);
         if (!rank) printf("matmat: C = A*A has %d rows, %ld nnz\n", C.get_num_rows(), (long)C.get_nnz());

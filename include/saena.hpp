@@ -6,7 +6,7 @@
 // of include/data_struct.h:36-38, so that a driver such as experiments/Poisson.cpp ports by
 // replacing `MPI_Comm` with `saena::comm` -- or, unchanged, by including include/saena_mpi.hpp instead
 // (MPI_Comm overloads; tests/test_cpp_surface.py compiles the reference's flow against it).  Only the members on (or feeding) the V-cycle hot path
-// are provided; GMRES, lazy updates, matmat, PETSc bridges etc. are out of scope.
+// are provided; lazy updates, PETSc bridges etc. are out of scope; solve_GMRES / solve_pGMRES mirror the reference's compiled-out bodies.
 //
 // Differences from the reference, all at the boundary:
 //   * the communicator is the GPU runtime's (one process = one rank = one MI355X, RCCL), wrapped
@@ -223,6 +223,11 @@ public:
     void profile_matvecs();                                   // average matvec time of every level's A
     int solve_pCG_profile(value_t *&u, saena::options *opts);  // solve_pCG with its timing printed (the reference prints a per-phase profile)
     int solve_petsc(value_t *&u, saena::options *opts);        // PETSc bridge: out of scope -- prints why and returns 1 (kept so that drivers compile)
+    // The reference declares both (saena.hpp:230-231) and compiles their bodies OUT (`#if 0`, saena_object_solve.cpp:3808 / 4077: GMRES and
+    // pGMRES return 0 without touching u).  Mirrored as that: the solve parameters are re-read like every solve* does, u is left as it
+    // was (allocated and zeroed when null), a line says so, 0 is returned.
+    int solve_GMRES(value_t *&u, saena::options *opts);
+    int solve_pGMRES(value_t *&u, saena::options *opts);
     comm get_orig_comm();
 
     int  switch_to_dense(bool val);                 // dense row-major storage for the coarse levels past the density threshold
@@ -260,6 +265,7 @@ private:
     int max_level_override_ = -1;
     void drop_device();
     int run(value_t *&u, saena::options *opts, int which, bool print_info);   // which: 0 solve, 1 solve_pCG, 2 solve_CG, 3 solve_smoother
+    int gmres_compiled_out(const char *name, value_t *&u, saena::options *opts);
 };
 
 void free_vector(value_t *u);

@@ -398,6 +398,21 @@ int amg::solve_petsc(value_t *&, saena::options *) {
     fprintf(stderr, "saena::amg::solve_petsc: the PETSc bridge is not part of the MI355X path (SURVEY.md 2: out of scope)\n");
     return 1;
 }
+// solve_GMRES / solve_pGMRES (saena.cpp:818-835 -> saena_object::GMRES / pGMRES, whose bodies sit inside `#if 0`, saena_object_solve.cpp:3808 /
+// 4077): set_solve_params, then nothing
+int amg::gmres_compiled_out(const char *name, value_t *&u, saena::options *opts) {
+    if (!damg_) throw std::runtime_error("saena::amg: set_matrix first");
+    if (opts)
+        gchk(sgpu_amg_set_solve_params(damg_, opts->get_max_iter(), opts->get_tol(), opts->get_smoother() == "jacobi" ? 0 : 1,
+                                       opts->get_preSmooth(), opts->get_postSmooth()), "set_solve_params");
+    const size_t n = (size_t)A_->get_num_local_rows();
+    if (!u) u = static_cast<value_t *>(std::calloc(std::max<size_t>(1, n), sizeof(value_t)));
+    if (A_->get_comm().rank() == 0)
+        printf("saena::amg::%s: the reference compiles this solver out (#if 0 in saena_object_solve.cpp) and returns 0 with u untouched; so does this\n", name);
+    return 0;
+}
+int amg::solve_GMRES(value_t *&u, saena::options *opts) { return gmres_compiled_out("solve_GMRES", u, opts); }
+int amg::solve_pGMRES(value_t *&u, saena::options *opts) { return gmres_compiled_out("solve_pGMRES", u, opts); }
 comm amg::get_orig_comm() { return A_ ? A_->get_comm() : comm(); }
 
 void free_vector(value_t *u) { std::free(u); }
