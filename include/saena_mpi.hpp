@@ -13,7 +13,8 @@
 //     on rank 0 and handed round with MPI_Bcast, then saena::init() (INTEGRATION.md section 1 shows the same code spelled out).
 //     From then on MPI carries nothing on the data path: halos and dots ride RCCL over xGMI.
 //   * the helpers those drivers take from the reference's other headers: saena::find_split (aux_functions2.cpp:1511-1528),
-//     print_time (aux_functions.cpp:72-128), saena_free (aux_functions.h:306-312), omp_get_wtime when OpenMP is off.
+//     print_time (aux_functions.cpp:72-128), saena_free / saena_aligned_alloc (aux_functions.h:299-312), read_from_file_rhs
+//     (aux_functions.cpp:347-497: the rhs reader of experiments/profile_file.cpp), omp_get_wtime when OpenMP is off.
 // Out of the path's scope and therefore absent: GMRES, lazy updates, the Nektar++ set_matrix, PETSc (solve_petsc compiles and
 // reports that it is not available).
 #pragma once
@@ -21,8 +22,11 @@
 #define SAENA_MPI_HPP
 #include <mpi.h>
 
+#include <algorithm>
+#include <cassert>
 #include <chrono>
 #include <cstdlib>
+#include <fstream>
 #include <iomanip>
 #include <iostream>
 #include <stdexcept>
@@ -123,5 +127,68 @@ inline double print_time(double t_dif, const std::string &function_name, MPI_Com
 template <class T>
 inline void saena_free(T *&v) {
     if (v != nullptr) { std::free(v); v = nullptr; }
+}
+
+// saena_aligned_alloc (reference include/aux_functions.h:299-303): sz elements, 64-byte aligned, released with saena_free
+template <class T>
+inline T *saena_aligned_alloc(const nnz_t sz) {
+    const size_t bytes = ((size_t)(sz > 0 ? sz : 1) * sizeof(T) + 63) / 64 * 64;
+    return static_cast<T *>(std::aligned_alloc(64, bytes));
+}
+
+// read_from_file_rhs (reference src/aux_functions.cpp:347-497, the rhs reader of experiments/profile_file.cpp): this rank's rows
+// [split[rank], split[rank + 1]) of a vector file.  "<name>.bin": the doubles of the whole vector, row after row.  Any other
+// extension: a text file -- `%` comment lines, the size, then one "row value" pair per line with rows counted from 1 -- which rank 0
+// turns into "<name>.bin" next to it first, sorted by row, unless that file is already there (the reference's behaviour, side
+// effect included).  A missing file is the reference's message and exit.
+inline int read_from_file_rhs(value_t *v, const std::vector<index_t> &split, char *file, MPI_Comm c) {
+    int rank = 0;
+    MPI_Comm_rank(c, &rank);
+    const std::string filename(file);
+    {
+        std::ifstream probe(filename.c_str());
+        if (!probe.is_open()) {
+            if (!rank) std::cout << "\nCould not open the rhs file <" << filename << ">" << std::endl;
+            MPI_Finalize();
+            std::exit(EXIT_FAILURE);
+        }
+    }
+    const size_t ext = filename.find_last_of('.');
+    if (ext == std::string::npos || ext == filename.size() - 1) {
+        if (!rank) std::cout << "The rhs file name does not have an extension!" << std::endl;
+        MPI_Abort(c, 1);
+    }
+    const std::string binname = filename.substr(0, ext) + ".bin";
+    if (filename.substr(ext + 1) != "bin") {
+        if (!rank && !std::ifstream(binname.c_str()).is_open()) {
+            std::ifstream in(filename.c_str());
+            while (in.peek() == '%') in.ignore(2048, '\n');
+            nnz_t sz = 0;
+            in >> sz;
+            std::vector<std::pair<index_t, value_t>> e;
+            e.reserve((size_t)std::max<nnz_t>(sz, 0));
+            index_t a = 0;
+            value_t val = 0.0;
+            while (in >> a >> val) e.emplace_back(a - 1, val);
+            std::stable_sort(e.begin(), e.end(), [](const std::pair<index_t, value_t> &x, const std::pair<index_t, value_t> &y) { return x.first < y.first; });
+            std::ofstream out(binname.c_str(), std::ios::out | std::ios::binary);
+            for (nnz_t i = 0; i < sz && (size_t)i < e.size(); ++i) out.write(reinterpret_cast<const char *>(&e[(size_t)i].second), sizeof(value_t));
+        }
+        MPI_Barrier(c);                                   // the binary file written by rank 0 is ready
+    }
+    std::ifstream in(binname.c_str(), std::ios::in | std::ios::binary);
+    if (!in.is_open()) {
+        if (!rank) std::cout << "Unable to open the rhs vector file!" << std::endl;
+        MPI_Finalize();
+        return -1;
+    }
+    const index_t lo = split[(size_t)rank], n = split[(size_t)rank + 1] - lo;
+    in.seekg((std::streamoff)lo * (std::streamoff)sizeof(value_t));
+    in.read(reinterpret_cast<char *>(v), (std::streamsize)n * (std::streamsize)sizeof(value_t));
+    if (in.gcount() != (std::streamsize)n * (std::streamsize)sizeof(value_t)) {
+        if (!rank) std::cout << "Error: Size of RHS does not match the number of rows of the LHS matrix!" << std::endl;
+        MPI_Abort(c, 1);
+    }
+    return 0;
 }
 #endif // SAENA_MPI_HPP

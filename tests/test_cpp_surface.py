@@ -30,12 +30,69 @@ def _compile_and_link(src, tmp_path, extra=()):
 
 @pytest.mark.skipif(not HAVE_MPI, reason="no MPI in this image")
 @pytest.mark.skipif(not os.path.isdir(REF), reason="/root/reference is not here (GPU box)")
-@pytest.mark.parametrize("driver", ["Poisson.cpp", "banded.cpp"])
+@pytest.mark.parametrize("driver", ["Poisson.cpp", "banded.cpp", "profile_file.cpp"])      # (Poisson.cpp and profile_file.cpp: the two experiments the reference's CMake builds)
 def test_the_reference_s_own_driver_compiles_and_links_unchanged(driver, tmp_path):
     """the file is read where it lies under /root/reference; nothing of it is copied.  Every name it uses resolves against
     include/compat + include/saena_mpi.hpp and every symbol against libsaena_amd.so (an undefined one fails the link)."""
     assert os.path.exists(os.path.join(ROOT, "saena_amd", "libsaena_amd.so")), "build first (__graft_entry__.build())"
     _compile_and_link(os.path.join(REF, driver), tmp_path)
+
+
+RHS_READER = r"""
+#include "saena_mpi.hpp"
+int main(int argc, char **argv) {
+    MPI_Init(&argc, &argv);
+    int rank = 0, np = 1;
+    MPI_Comm_rank(MPI_COMM_WORLD, &rank); MPI_Comm_size(MPI_COMM_WORLD, &np);
+    const int n = std::atoi(argv[2]);
+    std::vector<index_t> split((size_t)np + 1);
+    for (int r = 0; r <= np; ++r) split[(size_t)r] = (index_t)((long)n * r / np);
+    const nnz_t mine = split[(size_t)rank + 1] - split[(size_t)rank];
+    value_t *v = saena_aligned_alloc<value_t>(mine);
+    assert(v && ((size_t)v & 63) == 0);
+    if (read_from_file_rhs(v, split, argv[1], MPI_COMM_WORLD) != 0) return 3;
+    for (int r = 0; r < np; ++r) {
+        if (r == rank) for (nnz_t i = 0; i < mine; ++i) printf("%d %.17g\n", (int)(split[(size_t)rank] + i), v[i]);
+        fflush(stdout);
+        MPI_Barrier(MPI_COMM_WORLD);
+    }
+    saena_free(v);
+    MPI_Finalize();
+    return 0;
+}
+"""
+
+
+@pytest.mark.skipif(not HAVE_MPI, reason="no MPI in this image")
+@pytest.mark.parametrize("ext", ["txt", "bin"])
+def test_read_from_file_rhs_like_the_reference(ext, tmp_path):
+    """the rhs reader of the reference's file-driven experiment (src/aux_functions.cpp:347-497): a text vector file (comments, size,
+    "row value" lines in any order, rows from 1) is turned into <name>.bin by rank 0 and every rank reads its slice; a .bin file is
+    read as it is.  Two ranks under mpirun."""
+    import numpy as np
+    n = 37
+    want = np.sin(0.3 * np.arange(n)) * 1e3
+    if ext == "txt":
+        order = np.random.default_rng(5).permutation(n)
+        with open(tmp_path / "v.txt", "w") as f:
+            f.write("% a comment line\n% another\n" + str(n) + "\n")
+            for i in order:
+                f.write("%d %.17g\n" % (i + 1, want[i]))
+    else:
+        want.astype(np.float64).tofile(tmp_path / "v.bin")
+    src = tmp_path / "rhs_reader.cpp"
+    src.write_text(RHS_READER)
+    exe = _compile_and_link(str(src), tmp_path)
+    env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:" + os.path.join(MPI, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([os.path.join(MPI, "bin", "mpirun"), "-np", "2", exe, str(tmp_path / f"v.{ext}"), str(n)], capture_output=True, text=True,
+                         timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
+    got = np.full(n, np.nan)
+    for ln in out.stdout.splitlines():
+        i, v = ln.split()
+        got[int(i)] = float(v)
+    np.testing.assert_array_equal(got, want)
+    assert os.path.exists(tmp_path / "v.bin")
 
 
 @pytest.mark.skipif(not HAVE_MPI, reason="no MPI in this image")
