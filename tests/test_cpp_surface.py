@@ -127,3 +127,66 @@ def test_mpi_idiom_driver_runs_and_prints_the_reference_line(tmp_path):
     assert re.search(r"final absolute residual = 2\.24625\de-05", txt), txt
     assert "Setup:" in txt and "Solve:" in txt and "solve_pCG profile: 7 iterations" in txt
     assert len(re.findall(r"matvec level \d+: ", txt)) == 5, txt
+
+
+def _run_reference_driver(exe, args, tmp_path):
+    mpirun = shutil.which("mpirun") or os.path.join(MPI, "bin", "mpirun")
+    env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:" + os.path.join(MPI, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([mpirun, "-np", "1", exe, *args], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    return out.stdout
+
+
+REF_DRIVERS = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_MPI, reason="no MPI in this image")
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DRIVERS, "ref_driver_poisson")), reason="oracle/_ref/ref_driver_* not built (make -C oracle ref)")
+def test_the_reference_s_own_poisson_driver_runs_on_the_card(tmp_path):
+    """oracle/_ref/ref_driver_poisson = the reference's experiments/Poisson.cpp, compiled UNCHANGED in the build container against
+    include/compat + include/saena_mpi.hpp and linked against libsaena_amd.so (oracle/ref/Makefile): it runs its flow on the MI355X path
+    and prints the reference's own residual line for 32^3 (7 iterations, 7.227341e+03 -> 2.246251e-05)."""
+    xml = tmp_path / "options001.xml"
+    xml.write_text(OPTIONS001)
+    txt = _run_reference_driver(os.path.join(REF_DRIVERS, "ref_driver_poisson"), ["32", str(xml)], tmp_path)
+    assert re.search(r"initial residual\s+= 7\.227341e\+03", txt), txt
+    assert re.search(r"stopped at iteration\s+= 7", txt), txt
+    assert re.search(r"final absolute residual = 2\.24625\de-05", txt), txt
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_MPI, reason="no MPI in this image")
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DRIVERS, "ref_driver_profile_file")), reason="oracle/_ref/ref_driver_* not built (make -C oracle ref)")
+def test_the_reference_s_own_file_driver_runs_on_the_card(tmp_path):
+    """oracle/_ref/ref_driver_profile_file = the reference's experiments/profile_file.cpp (matrix and right-hand side from files:
+    BASELINE configs[4]'s driver), compiled unchanged like the one above: a MatrixMarket file (7-point Laplacian of 12^3) with a
+    text rhs file -> read_file, read_from_file_rhs, saena::vector, set_matrix, 15 x solve_pCG, solve_pCG_profile, profile_matvecs."""
+    import numpy as np
+    m = 12                                                  # the 7-point Laplacian of an m^3 grid (Dirichlet rows eliminated), as a MatrixMarket file
+    n = m ** 3
+    idx = np.arange(n).reshape(m, m, m)
+    rows, cols, vals = [idx.ravel()], [idx.ravel()], [np.full(n, 6.0)]
+    for ax in range(3):
+        a = np.take(idx, np.arange(m - 1), axis=ax).ravel()
+        b = np.take(idx, np.arange(1, m), axis=ax).ravel()
+        rows += [a, b]; cols += [b, a]; vals += [np.full(a.size, -1.0)] * 2
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    mtx = str(tmp_path / "lap12.mtx")
+    with open(mtx, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (n, n, rows.size))
+        for r, c, v in zip(rows, cols, vals):
+            f.write("%d %d %.17g\n" % (r + 1, c + 1, v))
+    rhs = np.sin(0.37 * np.arange(n)) + 1.0
+    with open(tmp_path / "rhs.txt", "w") as f:
+        f.write("% rhs of the file-driver test\n" + str(n) + "\n")
+        for i in range(n):
+            f.write("%d %.17g\n" % (i + 1, rhs[i]))
+    xml = tmp_path / "options001.xml"
+    xml.write_text(OPTIONS001)
+    txt = _run_reference_driver(os.path.join(REF_DRIVERS, "ref_driver_profile_file"), [mtx, str(tmp_path / "rhs.txt"), str(xml)], tmp_path)
+    assert "matrix file:" in txt and "rhs file:" in txt and "Setup:" in txt and "Solve:" in txt, txt
+    m = re.findall(r"relative residual\s+= ([0-9.e+-]+)", txt)
+    assert m and float(m[0]) < 1e-8, txt                   # solve_pCG converged to the options' tolerance
+    assert "solve_pCG profile:" in txt and re.search(r"matvec level 0: ", txt), txt
