@@ -154,6 +154,11 @@ def test_the_reference_s_own_poisson_driver_runs_on_the_card(tmp_path):
     assert re.search(r"initial residual\s+= 7\.227341e\+03", txt), txt
     assert re.search(r"stopped at iteration\s+= 7", txt), txt
     assert re.search(r"final absolute residual = 2\.24625\de-05", txt), txt
+    # ... and BASELINE configs[1]'s size: the line the reference prints for 128^3 (9 iterations, 5.992963e+04 -> 5.355578e-05)
+    txt = _run_reference_driver(os.path.join(REF_DRIVERS, "ref_driver_poisson"), ["128", str(xml)], tmp_path)
+    assert re.search(r"initial residual\s+= 5\.992963e\+04", txt), txt
+    assert re.search(r"stopped at iteration\s+= 9", txt), txt
+    assert re.search(r"final absolute residual = 5\.35557\de-05", txt), txt
 
 
 @pytest.mark.gpu
