@@ -104,6 +104,8 @@ public:
     void matvec(saena::vector &v, saena::vector &w);
 
     int  erase();
+    int  erase_lazy_update() { return erase(); }        // (reference saena.hpp:67-68: erase variants of its lazy-update path; one erase here)
+    int  erase_no_shrink_to_fit() { return erase(); }
     void destroy();
 
     sgpu_op *device_op();          // created on first use (sgpu_op_create)
@@ -131,6 +133,14 @@ public:
     index_t first_index() const { return idx_.empty() ? 0 : idx_.front(); }
     const std::vector<index_t> &indices() const { return idx_; }
     comm get_comm() { return c_; }
+    // return_vec (saena.cpp:357: the solution back in the order the entries were set): the entries are kept in ascending index order here
+    // and solve* returns u in the matrix's row order, so this is a copy (u2 allocated when null)
+    int return_vec(value_t *&u1, value_t *&u2) {
+        if (!u2) u2 = static_cast<value_t *>(std::malloc(std::max<size_t>(1, val_.size()) * sizeof(value_t)));
+        if (u1 != u2) for (size_t i = 0; i < val_.size(); ++i) u2[i] = u1[i];
+        return 0;
+    }
+    int print_entry(int ran);           // (index, value) of this rank's entries when ran < 0 or ran == rank (saena_vector.cpp:504)
 private:
     comm c_;
     index_t ofst_ = 0;
@@ -221,6 +231,7 @@ public:
     // C = A B (host SpGEMM, one rank in this round); C is erased first and assembled unless assemble == false
     void matmat(saena::matrix *A, saena::matrix *B, saena::matrix *C, bool assemble = true, bool print_timing = false);
     void profile_matvecs();                                   // average matvec time of every level's A
+    void profile_matvecs_breakdown() { profile_matvecs(); }   // (saena.hpp:261: the same loop with the reference's CPU phases split out; one kernel per matvec here)
     int solve_pCG_profile(value_t *&u, saena::options *opts);  // solve_pCG with its timing printed (the reference prints a per-phase profile)
     int solve_petsc(value_t *&u, saena::options *opts);        // PETSc bridge: out of scope -- prints why and returns 1 (kept so that drivers compile)
     // The reference declares both (saena.hpp:230-231) and compiles their bodies OUT (`#if 0`, saena_object_solve.cpp:3808 / 4077: GMRES and

@@ -25,6 +25,8 @@
 #include <algorithm>
 #include <cassert>
 #include <chrono>
+#include <cmath>
+#include <random>
 #include <cstdlib>
 #include <fstream>
 #include <iomanip>
@@ -88,6 +90,133 @@ inline index_t find_split(index_t loc_size, index_t &my_split, MPI_Comm c) {
     MPI_Allgather(&loc_size, 1, MPI_INT, all.data(), 1, MPI_INT, c);
     my_split = 0;
     for (int i = 0; i < rank; ++i) my_split += all[(size_t)i];
+    return 0;
+}
+
+// ---- the rest of the generators / checkers of the reference's public header (include/saena.hpp:271-298, src/aux_functions2.cpp), so
+// that a driver which calls them compiles; formulas as there.  (In the reference's own drivers every call of the 2-D family and of the
+// solution checkers is commented out: solve* returns u WITHOUT the removed boundary rows, which these index -- saena.cpp:782-811.)
+
+// laplacian2D (aux_functions2.cpp:3-88): the 5-point Laplacian of an mx x my grid, boundary nodes as rows of their own; serial only,
+// like the reference.  scale = true is the reference's default and asks for the symmetric diagonal scaling this path does not have
+// (saena::matrix::assemble refuses it): pass false.
+inline int laplacian2D(saena::matrix *A, index_t mx, index_t my, bool scale = true) {
+    if (A->get_comm().size() > 1) {
+        if (A->get_comm().rank() == 0) printf("laplacian2D works only in serial!\n");
+        MPI_Abort(mpi_world(), 1);
+    }
+    const value_t Hx = 1.0 / (mx - 1), Hy = 1.0 / (my - 1), HydHx = Hy / Hx, HxdHy = Hx / Hy;
+    const index_t XMAX = mx - 1, YMAX = my - 1;
+    for (index_t j = 0; j < my; ++j)
+        for (index_t i = 0; i < mx; ++i) {
+            const index_t node = mx * j + i;
+            if (i != 0 && j != 0 && i != XMAX && j != YMAX) {
+                if (j - 1 != 0)    A->set(node, node - mx, -HxdHy);
+                if (i - 1 != 0)    A->set(node, node - 1, -HydHx);
+                if (i + 1 != XMAX) A->set(node, node + 1, -HydHx);
+                if (j + 1 != YMAX) A->set(node, node + mx, -HxdHy);
+            }
+            A->set(node, node, 2.0 * (HxdHy + HydHx));
+        }
+    A->assemble(scale);
+    return 0;
+}
+// laplacian2D_set_rhs (:90-132): f = 8 pi^2 sin(2 pi x) sin(2 pi y) at every node of the grid
+inline int laplacian2D_set_rhs(std::vector<double> &rhs, index_t mx, index_t my, MPI_Comm) {
+    const double PI = 3.14159265358979323846, Hx = 1.0 / (mx - 1), Hy = 1.0 / (my - 1);
+    rhs.resize((size_t)mx * my);
+    size_t it = 0;
+    for (index_t j = 0; j < my; ++j)
+        for (index_t i = 0; i < mx; ++i) rhs[it++] = 8 * PI * PI * std::sin(2 * PI * i * Hx) * std::sin(2 * PI * j * Hy);
+    return 0;
+}
+// laplacian2D_check_solution (:134-179): || u - sin(2 pi x) sin(2 pi y) ||_2 over the grid, printed; returned through *norm too
+inline int laplacian2D_check_solution(std::vector<double> &u, index_t mx, index_t my, MPI_Comm, double *norm = nullptr) {
+    const double PI = 3.14159265358979323846, Hx = 1.0 / (mx - 1), Hy = 1.0 / (my - 1);
+    double dif = 0.0;
+    size_t it = 0;
+    for (index_t j = 0; j < my; ++j)
+        for (index_t i = 0; i < mx; ++i) { const double t = u[it++] - std::sin(2 * PI * i * Hx) * std::sin(2 * PI * j * Hy); dif += t * t; }
+    std::cout << "\nnorm of diff = " << std::sqrt(dif) << std::endl;
+    if (norm) *norm = std::sqrt(dif);
+    return 0;
+}
+// laplacian3D_check_solution (:702-763): this rank's z-slab of the grid against sin sin sin; rank 0 prints sqrt(its OWN sum / (mx my mz)) --
+// the reference reduces the sums and then prints the local one (:761); kept, the reduced figure goes to *norm
+inline int laplacian3D_check_solution(std::vector<double> &u, index_t mx, index_t my, index_t mz, MPI_Comm c, double *norm = nullptr) {
+    int rank = 0, nprocs = 1;
+    MPI_Comm_size(c, &nprocs); MPI_Comm_rank(c, &rank);
+    const double PI = 3.14159265358979323846;
+    double dif = 0.0;
+    if (rank < mz) {
+        const double Hx = 1.0 / (mx - 1), Hy = 1.0 / (my - 1), Hz = 1.0 / (mz - 1);
+        index_t zm = 1, zs = rank;
+        if (mz > nprocs) { zm = mz / nprocs; zs = rank * zm; if (rank == nprocs - 1) zm = mz - (nprocs - 1) * zm; }
+        size_t it = 0;
+        for (index_t k = zs; k < zs + zm; ++k)
+            for (index_t j = 0; j < my; ++j)
+                for (index_t i = 0; i < mx; ++i) {
+                    const double t = u[it++] - std::sin(2 * PI * i * Hx) * std::sin(2 * PI * j * Hy) * std::sin(2 * PI * k * Hz);
+                    dif += t * t;
+                }
+    }
+    double tot = 0.0;
+    MPI_Reduce(&dif, &tot, 1, MPI_DOUBLE, MPI_SUM, 0, c);
+    if (!rank) std::cout << "\nnorm of diff = " << std::sqrt(dif / ((double)mx * my * mz)) << std::endl;
+    if (norm) *norm = std::sqrt(tot / ((double)mx * my * mz));
+    return 0;
+}
+// laplacian3D_set_rhs_zero (:1249-1294): zero the boundary nodes of a right-hand side over the WHOLE grid (global node index, as there)
+inline int laplacian3D_set_rhs_zero(std::vector<double> &rhs, unsigned int mx, unsigned int my, unsigned int mz, MPI_Comm c) {
+    int rank = 0, nprocs = 1;
+    MPI_Comm_size(c, &nprocs); MPI_Comm_rank(c, &rank);
+    unsigned zm = mz / (unsigned)nprocs;
+    const unsigned zs = (unsigned)rank * zm;
+    if (rank == nprocs - 1) zm = mz - (unsigned)(nprocs - 1) * zm;
+    for (unsigned k = zs; k < zs + zm; ++k)
+        for (unsigned j = 0; j < my; ++j)
+            for (unsigned i = 0; i < mx; ++i)
+                if (i == 0 || j == 0 || k == 0 || i == mx - 1 || j == my - 1 || k == mz - 1) rhs[(size_t)mx * my * k + (size_t)mx * j + i] = 0;
+    return 0;
+}
+// random_symm_matrix (:1384-1460): M rows per rank, a random diagonal in (0, 1) and floor(density M Mbig) entries in all, mirrored;
+// seeded from std::random_device like the reference (no two runs alike there either)
+inline int random_symm_matrix(saena::matrix &A, index_t M, float density) {
+    const int rank = A.get_comm().rank(), nprocs = A.get_comm().size();
+    if (density <= 0 || density > 1) {
+        if (!rank) printf("Error: density should be in the range (0,1].\n");
+        std::exit(EXIT_FAILURE);
+    }
+    const index_t Mbig = nprocs * M, offset = M * rank;
+    const unsigned long nnz_l = (unsigned long)std::floor((double)density * M * Mbig);
+    std::uniform_real_distribution<value_t> dist(0, 1);
+    std::uniform_int_distribution<index_t> drow(0, M - 1), dcol(0, Mbig - 1);
+    std::mt19937 rng(std::random_device{}()), rng2(std::random_device{}()), rng3(std::random_device{}());
+    for (index_t i = offset; i < (rank == nprocs - 1 ? Mbig : offset + M); ++i) A.set(i, i, dist(rng));
+    if (nnz_l > (unsigned long)M) {
+        unsigned long left = (nnz_l - M) / 2;
+        while (left) {
+            const value_t vv = dist(rng);
+            const index_t ii = drow(rng2) + offset, jj = dcol(rng3);
+            if (ii > jj) { --left; A.set(ii, jj, vv); A.set(jj, ii, vv); }
+        }
+    }
+    A.assemble();
+    return 0;
+}
+// read_vector_file (:1462-1509): this rank's rows of a file of doubles, at the matrix's (assembled) partition
+inline int read_vector_file(std::vector<value_t> &v, saena::matrix &A, char *file, MPI_Comm c) {
+    int rank = 0;
+    MPI_Comm_rank(c, &rank);
+    std::ifstream in(file, std::ios::in | std::ios::binary);
+    if (!in.is_open()) {
+        if (rank == 0) std::cout << "Unable to open the rhs vector file!" << std::endl;
+        MPI_Finalize();
+        return -1;
+    }
+    v.resize((size_t)A.get_num_local_rows());
+    in.seekg((std::streamoff)A.get_split()[(size_t)rank] * 8);
+    in.read(reinterpret_cast<char *>(v.data()), (std::streamsize)v.size() * 8);
     return 0;
 }
 

@@ -298,6 +298,13 @@ int amg::set_matrix(saena::matrix *A, saena::options *opts) {
     return 0;
 }
 
+int vector::print_entry(int ran) {
+    if (ran < 0 || ran == c_.rank()) {
+        printf("vector on proc %d, size %zu\n", c_.rank(), val_.size());
+        for (size_t i = 0; i < val_.size(); ++i) printf("%zu \t%d \t%.14g\n", i, (int)idx_[i], val_[i]);
+    }
+    return 0;
+}
 int amg::set_rhs(saena::vector &rhs) {
     if (!A_) throw std::runtime_error("saena::amg::set_rhs: set_matrix first");
     value_t *p = nullptr;

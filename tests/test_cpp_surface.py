@@ -195,3 +195,113 @@ def test_the_reference_s_own_file_driver_runs_on_the_card(tmp_path):
     m = re.findall(r"relative residual\s+= ([0-9.e+-]+)", txt)
     assert m and float(m[0]) < 1e-8, txt                   # solve_pCG converged to the options' tolerance
     assert "solve_pCG profile:" in txt and re.search(r"matvec level 0: ", txt), txt
+
+
+GENERATORS = r"""
+#include "saena_mpi.hpp"
+// the public generators / checkers of the reference's saena.hpp that its drivers do not call (include/saena.hpp:271-298)
+int main(int argc, char **argv) {
+    MPI_Init(&argc, &argv);
+    const bool gpu = argc > 1 && std::string(argv[1]) == "gpu";
+    const index_t mx = 9, my = 7;
+    std::vector<double> rhs;
+    saena::laplacian2D_set_rhs(rhs, mx, my, MPI_COMM_WORLD);
+    printf("RHS2D");
+    for (double v : rhs) printf(" %.17g", v);
+    printf("\n");
+    std::vector<double> u(rhs.size());
+    for (size_t i = 0; i < u.size(); ++i) u[i] = 0.01 * (double)i;
+    double n2 = 0.0, n3 = 0.0;
+    saena::laplacian2D_check_solution(u, mx, my, MPI_COMM_WORLD, &n2);
+    std::vector<double> u3((size_t)5 * 4 * 3);
+    for (size_t i = 0; i < u3.size(); ++i) u3[i] = 0.02 * (double)i - 0.3;
+    saena::laplacian3D_check_solution(u3, 5, 4, 3, MPI_COMM_WORLD, &n3);
+    printf("NORMS %.17g %.17g\n", n2, n3);
+    std::vector<double> z((size_t)5 * 4 * 3, 1.0);
+    saena::laplacian3D_set_rhs_zero(z, 5, 4, 3, MPI_COMM_WORLD);
+    printf("ZERO");
+    for (double v : z) printf(" %g", v);
+    printf("\n");
+    if (gpu) {
+        saena::matrix A(MPI_COMM_WORLD);
+        A.set_remove_boundary(false);
+        saena::laplacian2D(&A, mx, my, false);
+        printf("LAP2D rows %d nnz %ld\n", A.get_num_rows(), (long)A.get_nnz());
+        std::vector<value_t> x((size_t)A.get_num_local_rows(), 1.0), y;
+        A.matvec(x, y);                                    // row sums: 4 on a boundary row (its diagonal), 0 deep inside, > 0 next to the boundary
+        printf("ROWSUM %.17g %.17g %.17g\n", y[0], y[(size_t)mx * 3 + 4], y[(size_t)mx + 1]);
+        saena::matrix B(MPI_COMM_WORLD);
+        B.set_remove_boundary(false);
+        saena::random_symm_matrix(B, 60, 0.1f);
+        printf("RANDSYMM rows %d nnz %ld\n", B.get_num_rows(), (long)B.get_nnz());
+        std::vector<value_t> v;
+        if (saena::read_vector_file(v, A, argv[2], MPI_COMM_WORLD) != 0) return 4;
+        printf("VEC %zu %.17g %.17g\n", v.size(), v.front(), v.back());
+        A.destroy(); B.destroy();
+    }
+    MPI_Finalize();
+    return 0;
+}
+"""
+
+
+def _generators_expected():
+    import numpy as np
+    mx, my = 9, 7
+    i, j = np.meshgrid(np.arange(mx), np.arange(my))              # rows j, columns i: node = mx * j + i
+    hx, hy = 1.0 / (mx - 1), 1.0 / (my - 1)
+    rhs = (8 * np.pi * np.pi * np.sin(2 * np.pi * i * hx) * np.sin(2 * np.pi * j * hy)).ravel()
+    u = 0.01 * np.arange(mx * my)
+    n2 = np.sqrt(np.sum((u - (np.sin(2 * np.pi * i * hx) * np.sin(2 * np.pi * j * hy)).ravel()) ** 2))
+    k3, j3, i3 = np.meshgrid(np.arange(3), np.arange(4), np.arange(5), indexing="ij")
+    ex3 = (np.sin(2 * np.pi * i3 / 4.0) * np.sin(2 * np.pi * j3 / 3.0) * np.sin(2 * np.pi * k3 / 2.0)).ravel()
+    u3 = 0.02 * np.arange(60) - 0.3
+    n3 = np.sqrt(np.sum((u3 - ex3) ** 2) / 60.0)
+    zero = np.ones((3, 4, 5)); zero[0] = zero[-1] = 0; zero[:, 0] = zero[:, -1] = 0; zero[:, :, 0] = zero[:, :, -1] = 0
+    return rhs, n2, n3, zero.ravel()
+
+
+def _check_generator_output(txt):
+    import numpy as np
+    rhs, n2, n3, zero = _generators_expected()
+    lines = {ln.split()[0]: ln.split()[1:] for ln in txt.splitlines() if ln and ln.split()[0] in ("RHS2D", "NORMS", "ZERO", "LAP2D", "ROWSUM", "RANDSYMM", "VEC")}
+    np.testing.assert_allclose(np.array(lines["RHS2D"], float), rhs, rtol=1e-14, atol=1e-13)
+    np.testing.assert_allclose(np.array(lines["NORMS"], float), [n2, n3], rtol=1e-13)
+    np.testing.assert_array_equal(np.array(lines["ZERO"], float), zero)
+    return lines
+
+
+@pytest.mark.skipif(not HAVE_MPI, reason="no MPI in this image")
+def test_the_other_public_generators_and_checkers_formulas(tmp_path):
+    """laplacian2D_set_rhs / laplacian2D_check_solution / laplacian3D_check_solution / laplacian3D_set_rhs_zero of the reference's public
+    header (src/aux_functions2.cpp:90-179, 702-763, 1249-1294): formulas against numpy (no device involved)"""
+    src = tmp_path / "generators.cpp"
+    src.write_text(GENERATORS)
+    exe = _compile_and_link(str(src), tmp_path)
+    env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:" + os.path.join(MPI, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([os.path.join(MPI, "bin", "mpirun"), "-np", "1", exe, "cpu"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    _check_generator_output(out.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_MPI, reason="no MPI in this image")
+def test_the_other_public_generators_on_the_card(tmp_path):
+    """... and the ones that assemble a matrix: laplacian2D (5-point stencil, boundary nodes as rows of their own: aux_functions2.cpp:3-88),
+    random_symm_matrix (:1384-1460), read_vector_file (:1462-1509)"""
+    import numpy as np
+    src = tmp_path / "generators.cpp"
+    src.write_text(GENERATORS)
+    exe = _compile_and_link(str(src), tmp_path)
+    vec = np.cos(0.1 * np.arange(63))
+    vec.tofile(tmp_path / "vec.bin")
+    txt = _run_reference_driver(exe, ["gpu", str(tmp_path / "vec.bin")], tmp_path)
+    lines = _check_generator_output(txt)
+    # 9 x 7 grid: 63 rows; 35 interior nodes with a 5-point stencil less the couplings to boundary nodes, 28 boundary rows of one entry
+    interior = 7 * 5
+    assert lines["LAP2D"] == ["rows", "63", "nnz", str(28 + interior * 5 - 2 * 7 - 2 * 5)]
+    hx, hy = 1 / 8.0, 1 / 6.0
+    d = 2.0 * (hx / hy + hy / hx)
+    np.testing.assert_allclose(np.array(lines["ROWSUM"], float), [d, 0.0, hx / hy + hy / hx], rtol=1e-13, atol=1e-13)
+    assert lines["RANDSYMM"][:2] == ["rows", "60"] and int(lines["RANDSYMM"][3]) > 60
+    assert lines["VEC"][0] == "63" and float(lines["VEC"][1]) == vec[0] and float(lines["VEC"][2]) == vec[-1]
