@@ -33,6 +33,22 @@ namespace saena {
 void init(int device_id = 0, int rank = 0, int nranks = 1, const void *rccl_unique_id = nullptr);
 void unique_id(void *out128);
 void finalize();
+// Several ranks on ONE card (validation; include/saena_mpi.hpp uses it under SAENA_MPI_HOST_TRANSPORT=1): the context of rank `rank` of
+// `nranks` WITHOUT an RCCL communicator -- RCCL refuses two ranks on one device.  The device path's halo exchanges and scalar
+// reductions go through `exchange` / `allreduce_sum` (sgpu_debug_init_host_transport, include/saena_gpu_debug.h), the host setup's
+// collectives through the four callbacks of saena_comm_callbacks (include/saena_c.h).  Everything above the transport is the
+// multi-rank code.
+struct host_transport {
+    void *user;
+    int (*exchange)(void *user, const void *send, const int *send_rank, const int *send_count, int nsend,
+                    void *recv, const int *recv_rank, const int *recv_count, int nrecv, int elem_bytes);
+    int (*allreduce_sum)(void *user, double *v, int n);
+    int (*allgather)(void *user, const void *send, void *recv, size_t bytes);
+    int (*alltoallv)(void *user, const void *send, const size_t *scounts, const size_t *sdispls, void *recv, const size_t *rcounts, const size_t *rdispls);
+    int (*allreduce_i64)(void *user, long *v, int n);
+    int (*allreduce_f64)(void *user, double *v, int n);
+};
+void init_host_transport(int device_id, int rank, int nranks, const host_transport &t);
 
 class comm {
 public:

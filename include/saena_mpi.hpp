@@ -53,6 +53,53 @@ namespace saena {
 // the MPI communicator the GPU runtime was brought up over (one job = one communicator, as in the reference's drivers)
 inline MPI_Comm &mpi_world() { static MPI_Comm c = MPI_COMM_NULL; return c; }
 
+// The callbacks of saena::init_host_transport over the job's MPI communicator (SAENA_MPI_HOST_TRANSPORT=1: a multi-rank job on one card)
+inline const host_transport &mpi_host_transport() {
+    struct F {
+        static MPI_Comm comm_() { return mpi_world(); }
+        static int exchange(void *, const void *send, const int *send_rank, const int *send_count, int nsend,
+                            void *recv, const int *recv_rank, const int *recv_count, int nrecv, int elem_bytes) {
+            std::vector<MPI_Request> rq((size_t)(nsend + nrecv));
+            size_t off = 0;
+            int k = 0;
+            for (int i = 0; i < nrecv; ++i) {
+                MPI_Irecv(static_cast<char *>(recv) + off, recv_count[i] * elem_bytes, MPI_BYTE, recv_rank[i], 7701, comm_(), &rq[(size_t)k++]);
+                off += (size_t)recv_count[i] * (size_t)elem_bytes;
+            }
+            off = 0;
+            for (int i = 0; i < nsend; ++i) {
+                MPI_Isend(static_cast<const char *>(send) + off, send_count[i] * elem_bytes, MPI_BYTE, send_rank[i], 7701, comm_(), &rq[(size_t)k++]);
+                off += (size_t)send_count[i] * (size_t)elem_bytes;
+            }
+            return MPI_Waitall(k, rq.data(), MPI_STATUSES_IGNORE) == MPI_SUCCESS ? 0 : 1;
+        }
+        static int allreduce(void *, double *v, int n) { return MPI_Allreduce(MPI_IN_PLACE, v, n, MPI_DOUBLE, MPI_SUM, comm_()) == MPI_SUCCESS ? 0 : 1; }
+        static int allreduce_i64(void *, long *v, int n) { return MPI_Allreduce(MPI_IN_PLACE, v, n, MPI_LONG, MPI_SUM, comm_()) == MPI_SUCCESS ? 0 : 1; }
+        static int allgather(void *, const void *send, void *recv, size_t bytes) {
+            return MPI_Allgather(send, (int)bytes, MPI_BYTE, recv, (int)bytes, MPI_BYTE, comm_()) == MPI_SUCCESS ? 0 : 1;
+        }
+        static int alltoallv(void *, const void *send, const size_t *sc, const size_t *sd, void *recv, const size_t *rc, const size_t *rd) {
+            int np = 1;
+            MPI_Comm_size(comm_(), &np);
+            const size_t CH = (size_t)1 << 30;                      // pieces of at most 1 GiB: MPI counts are ints
+            std::vector<MPI_Request> rq;
+            for (int p = 0; p < np; ++p)
+                for (size_t o = 0; o < rc[p]; o += CH) {
+                    rq.emplace_back();
+                    MPI_Irecv(static_cast<char *>(recv) + rd[p] + o, (int)std::min(CH, rc[p] - o), MPI_BYTE, p, 7702, comm_(), &rq.back());
+                }
+            for (int p = 0; p < np; ++p)
+                for (size_t o = 0; o < sc[p]; o += CH) {
+                    rq.emplace_back();
+                    MPI_Isend(static_cast<const char *>(send) + sd[p] + o, (int)std::min(CH, sc[p] - o), MPI_BYTE, p, 7702, comm_(), &rq.back());
+                }
+            return MPI_Waitall((int)rq.size(), rq.data(), MPI_STATUSES_IGNORE) == MPI_SUCCESS ? 0 : 1;
+        }
+    };
+    static const host_transport t{nullptr, &F::exchange, &F::allreduce, &F::allgather, &F::alltoallv, &F::allreduce_i64, &F::allreduce};
+    return t;
+}
+
 inline comm::comm(MPI_Comm c) : comm([c]() -> comm {
     MPI_Comm &w = mpi_world();
     if (w == MPI_COMM_NULL) {
@@ -69,6 +116,12 @@ inline comm::comm(MPI_Comm c) : comm([c]() -> comm {
             MPI_Bcast(id, 128, MPI_BYTE, 0, c);
         }
         if (const char *d = std::getenv("SAENA_DEVICE")) local = std::atoi(d);
+        if (size > 1 && std::getenv("SAENA_MPI_HOST_TRANSPORT")) {
+            // several ranks on ONE card (RCCL refuses that): halos, reductions and the setup's collectives over MPI itself
+            w = c;
+            saena::init_host_transport(local, rank, size, mpi_host_transport());
+            return comm();
+        }
         saena::init(local, rank, size, size > 1 ? id : nullptr);
         w = c;
     } else {

@@ -3,6 +3,8 @@
 #ifdef SAENA_WITH_GPU
 #include "../../../include/saena.hpp"
 #include "../../../include/saena_gpu.h"
+#include "../../../include/saena_gpu_debug.h"
+#include "comm.h"
 #include "amg_setup.h"
 #include "saena_matrix.h"
 
@@ -21,8 +23,10 @@ namespace {
 void gchk(int s, const char *what) {
     if (s != SGPU_OK) throw std::runtime_error(std::string(what) + ": " + sgpu_last_error());
 }
+saena_host::Comm *&world_override() { static saena_host::Comm *o = nullptr; return o; }      // saena::init_host_transport
 saena_host::Comm *world() {
     static saena_host::Comm *w = nullptr;
+    if (world_override()) return world_override();
     if (!w) {
         w = sgpu_new_host_comm();
         if (!w) throw std::runtime_error("saena::init() has not been called (no MI355X context)");
@@ -48,6 +52,15 @@ namespace saena {
 
 void init(int device_id, int rank, int nranks, const void *uid) { gchk(sgpu_init(device_id, rank, nranks, uid), "saena::init"); }
 void unique_id(void *out128) { gchk(sgpu_get_unique_id(out128), "saena::unique_id"); }
+void init_host_transport(int device_id, int rank, int nranks, const host_transport &t) {
+    if (!t.exchange || !t.allreduce_sum || !t.allgather || !t.alltoallv || !t.allreduce_i64 || !t.allreduce_f64)
+        throw std::runtime_error("saena::init_host_transport: every callback is needed");
+    gchk(sgpu_debug_init_host_transport(device_id, rank, nranks, t.exchange, t.allreduce_sum, t.user), "saena::init_host_transport");
+    auto *cb = new saena_host::CallbackComm();
+    cb->rank = rank; cb->nranks = nranks; cb->user = t.user;
+    cb->cb_allgather = t.allgather; cb->cb_alltoallv = t.alltoallv; cb->cb_i64 = t.allreduce_i64; cb->cb_f64 = t.allreduce_f64;
+    world_override() = cb;
+}
 void finalize() { sgpu_finalize(); }
 
 comm::comm() : c_(world()) {}

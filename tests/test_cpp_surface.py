@@ -129,11 +129,13 @@ def test_mpi_idiom_driver_runs_and_prints_the_reference_line(tmp_path):
     assert len(re.findall(r"matvec level \d+: ", txt)) == 5, txt
 
 
-def _run_reference_driver(exe, args, tmp_path):
+def _run_reference_driver(exe, args, tmp_path, np_=1):
     mpirun = shutil.which("mpirun") or os.path.join(MPI, "bin", "mpirun")
     env = dict(os.environ, LD_LIBRARY_PATH="/usr/lib/x86_64-linux-gnu:" + os.path.join(MPI, "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([mpirun, "-np", "1", exe, *args], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    if np_ > 1:                                            # several ranks on this ONE card: no RCCL (it refuses that), MPI carries halos and collectives
+        env.update(SAENA_MPI_HOST_TRANSPORT="1", SAENA_DEVICE="0")
+    out = subprocess.run([mpirun, "-np", str(np_), exe, *args], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     return out.stdout
 
@@ -305,3 +307,20 @@ def test_the_other_public_generators_on_the_card(tmp_path):
     np.testing.assert_allclose(np.array(lines["ROWSUM"], float), [d, 0.0, hx / hy + hy / hx], rtol=1e-13, atol=1e-13)
     assert lines["RANDSYMM"][:2] == ["rows", "60"] and int(lines["RANDSYMM"][3]) > 60
     assert lines["VEC"][0] == "63" and float(lines["VEC"][1]) == vec[0] and float(lines["VEC"][2]) == vec[-1]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_MPI, reason="no MPI in this image")
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DRIVERS, "ref_driver_poisson")), reason="oracle/_ref/ref_driver_* not built (make -C oracle ref)")
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_the_reference_s_own_poisson_driver_runs_multi_rank_under_mpirun(ranks, tmp_path):
+    """`mpirun -np 2 / 4` of the reference's unchanged Poisson.cpp on this one card (SAENA_MPI_HOST_TRANSPORT=1: the device path's halos
+    and reductions and the host setup's collectives ride on MPI, include/saena_mpi.hpp; everything above the transport is the
+    multi-rank code: the reference's partitioner, the row-distributed setup, interior / boundary kernels, agglomerated coarse levels).
+    Rank 0 prints the reference's residual line for 32^3 -- the same digits as at one rank."""
+    xml = tmp_path / "options001.xml"
+    xml.write_text(OPTIONS001)
+    txt = _run_reference_driver(os.path.join(REF_DRIVERS, "ref_driver_poisson"), ["32", str(xml)], tmp_path, np_=ranks)
+    assert re.search(r"initial residual\s+= 7\.227341e\+03", txt), txt
+    assert re.search(r"stopped at iteration\s+= 7", txt), txt
+    assert re.search(r"final absolute residual = 2\.24625\de-05", txt), txt
