@@ -324,3 +324,8 @@ def test_the_reference_s_own_poisson_driver_runs_multi_rank_under_mpirun(ranks, 
     assert re.search(r"initial residual\s+= 7\.227341e\+03", txt), txt
     assert re.search(r"stopped at iteration\s+= 7", txt), txt
     assert re.search(r"final absolute residual = 2\.24625\de-05", txt), txt
+    if ranks == 4:                                         # BASELINE configs[1]'s size over 4 ranks: the reference's 128^3 line
+        txt = _run_reference_driver(os.path.join(REF_DRIVERS, "ref_driver_poisson"), ["128", str(xml)], tmp_path, np_=ranks)
+        assert re.search(r"initial residual\s+= 5\.992963e\+04", txt), txt
+        assert re.search(r"stopped at iteration\s+= 9", txt), txt
+        assert re.search(r"final absolute residual = 5\.3555[67]\de-05", txt), txt
