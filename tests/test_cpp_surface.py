@@ -166,7 +166,8 @@ def test_the_reference_s_own_poisson_driver_runs_on_the_card(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.skipif(not HAVE_MPI, reason="no MPI in this image")
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF_DRIVERS, "ref_driver_profile_file")), reason="oracle/_ref/ref_driver_* not built (make -C oracle ref)")
-def test_the_reference_s_own_file_driver_runs_on_the_card(tmp_path):
+@pytest.mark.parametrize("ranks", [1, 3])
+def test_the_reference_s_own_file_driver_runs_on_the_card(ranks, tmp_path):
     """oracle/_ref/ref_driver_profile_file = the reference's experiments/profile_file.cpp (matrix and right-hand side from files:
     BASELINE configs[4]'s driver), compiled unchanged like the one above: a MatrixMarket file (7-point Laplacian of 12^3) with a
     text rhs file -> read_file, read_from_file_rhs, saena::vector, set_matrix, 15 x solve_pCG, solve_pCG_profile, profile_matvecs."""
@@ -192,7 +193,8 @@ def test_the_reference_s_own_file_driver_runs_on_the_card(tmp_path):
             f.write("%d %.17g\n" % (i + 1, rhs[i]))
     xml = tmp_path / "options001.xml"
     xml.write_text(OPTIONS001)
-    txt = _run_reference_driver(os.path.join(REF_DRIVERS, "ref_driver_profile_file"), [mtx, str(tmp_path / "rhs.txt"), str(xml)], tmp_path)
+    # (3 ranks: every rank reads its chunk of the matrix file and its slice of the rhs, MPI as the transport on this one card)
+    txt = _run_reference_driver(os.path.join(REF_DRIVERS, "ref_driver_profile_file"), [mtx, str(tmp_path / "rhs.txt"), str(xml)], tmp_path, np_=ranks)
     assert "matrix file:" in txt and "rhs file:" in txt and "Setup:" in txt and "Solve:" in txt, txt
     m = re.findall(r"relative residual\s+= ([0-9.e+-]+)", txt)
     assert m and float(m[0]) < 1e-8, txt                   # solve_pCG converged to the options' tolerance
