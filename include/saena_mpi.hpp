@@ -76,6 +76,7 @@ inline const host_transport &mpi_host_transport() {
         static int allreduce(void *, double *v, int n) { return MPI_Allreduce(MPI_IN_PLACE, v, n, MPI_DOUBLE, MPI_SUM, comm_()) == MPI_SUCCESS ? 0 : 1; }
         static int allreduce_i64(void *, long *v, int n) { return MPI_Allreduce(MPI_IN_PLACE, v, n, MPI_LONG, MPI_SUM, comm_()) == MPI_SUCCESS ? 0 : 1; }
         static int allgather(void *, const void *send, void *recv, size_t bytes) {
+            if (bytes > (size_t)1 << 30) return 1;                  // (the setup gathers counts and small tables: MPI counts are ints)
             return MPI_Allgather(send, (int)bytes, MPI_BYTE, recv, (int)bytes, MPI_BYTE, comm_()) == MPI_SUCCESS ? 0 : 1;
         }
         static int alltoallv(void *, const void *send, const size_t *sc, const size_t *sd, void *recv, const size_t *rc, const size_t *rd) {
@@ -118,8 +119,9 @@ inline comm::comm(MPI_Comm c) : comm([c]() -> comm {
         if (const char *d = std::getenv("SAENA_DEVICE")) local = std::atoi(d);
         if (size > 1 && std::getenv("SAENA_MPI_HOST_TRANSPORT")) {
             // several ranks on ONE card (RCCL refuses that): halos, reductions and the setup's collectives over MPI itself
-            w = c;
-            saena::init_host_transport(local, rank, size, mpi_host_transport());
+            w = c;                                                // (the callbacks reach the communicator through mpi_world())
+            try { saena::init_host_transport(local, rank, size, mpi_host_transport()); }
+            catch (...) { w = MPI_COMM_NULL; throw; }
             return comm();
         }
         saena::init(local, rank, size, size > 1 ? id : nullptr);
