@@ -1177,6 +1177,9 @@ struct XldsArgs {
     const int  *tab;
     double     *acc;       // [M] partial row sums between windows (nullptr when every workgroup has one window, or with acc_lds)
     int         ncols;
+    const int  *ord;       // [M] or nullptr: the order in which a chunk's groups take its rows (position in chunk -> row in chunk), LONGEST ROWS
+                           // FIRST in chunks that hold rows many times the mean (an irregular operator's hub rows: started last, such a
+                           // row is the tail of its workgroup -- and the workgroup the tail of the launch)
     int         win;       // columns per window (<= XL_MAX)
     int         acc_lds;   // the partial row sums of a chunk live in LDS behind the window: xs[win + row in chunk] (the plan keeps rows <= XL_MAX - win)
 };
@@ -1219,15 +1222,19 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
             if (tid == 0) next_row = NG * RP;                     // (rewritten before the barrier above took effect for RP == 1: set again here)
             __syncthreads();
             int k = (tid / G) * RP;
-            int np0[RP], np1[RP];                                 // the NEXT step's entry ranges, fetched one step ahead
+            int np0[RP], np1[RP], nrw[RP];                        // the NEXT step's rows (in chunk) and entry ranges, fetched one step ahead
 #pragma unroll
-            for (int j = 0; j < RP; ++j) { const bool have = k + j < nr; np0[j] = have ? ts[k + j] : 0; np1[j] = have ? te[k + j] : 0; }
+            for (int j = 0; j < RP; ++j) {
+                const bool have = k + j < nr;
+                nrw[j] = have ? (w.ord ? w.ord[r0 + k + j] : k + j) : 0;
+                np0[j] = have ? ts[nrw[j]] : 0; np1[j] = have ? te[nrw[j]] : 0;
+            }
             while (k < nr) {
-                int p0[RP], p1[RP], a0[RP], qe[RP];               // entry range, its quad-aligned start, end of the row's quads in the group's sequence
+                int p0[RP], p1[RP], a0[RP], qe[RP], rw[RP];       // entry range, its quad-aligned start, end of the row's quads in the group's sequence
                 int nq = 0;
 #pragma unroll
                 for (int j = 0; j < RP; ++j) {
-                    p0[j] = np0[j]; p1[j] = np1[j];
+                    p0[j] = np0[j]; p1[j] = np1[j]; rw[j] = nrw[j];
                     a0[j] = p0[j] & ~3;
                     nq += p1[j] > p0[j] ? (p1[j] - a0[j] + 3) >> 2 : 0;
                     qe[j] = nq;
@@ -1238,7 +1245,11 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
                 if (l == 0) nk = atomicAdd(&next_row, RP);
                 const int knext = __shfl(nk, lane & ~(G - 1), 64);
 #pragma unroll
-                for (int j = 0; j < RP; ++j) { const bool have = knext + j < nr; np0[j] = have ? ts[knext + j] : 0; np1[j] = have ? te[knext + j] : 0; }
+                for (int j = 0; j < RP; ++j) {
+                    const bool have = knext + j < nr;
+                    nrw[j] = have ? (w.ord ? w.ord[r0 + knext + j] : knext + j) : 0;
+                    np0[j] = have ? ts[nrw[j]] : 0; np1[j] = have ? te[nrw[j]] : 0;
+                }
                 double sum[RP];
 #pragma unroll
                 for (int j = 0; j < RP; ++j) sum[j] = 0.0;
@@ -1286,10 +1297,13 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
                     if (l == j) mine = sj;
                 }
                 if (l < RP && k + l < nr) {                       // lanes 0 .. RP-1: an epilogue each
-                    const int r = r0 + k + l;
+                    int rk = rw[0];
+#pragma unroll
+                    for (int j = 1; j < RP; ++j) if (l == j) rk = rw[j];
+                    const int r = r0 + rk;
                     // the row's sum over the windows so far: in LDS behind the window, or in global memory
-                    if (t > 0) mine = (w.acc_lds ? accs[k + l] : w.acc[r]) + mine;
-                    if (t < T - 1) { if (w.acc_lds) accs[k + l] = mine; else w.acc[r] = mine; }
+                    if (t > 0) mine = (w.acc_lds ? accs[rk] : w.acc[r]) + mine;
+                    if (t < T - 1) { if (w.acc_lds) accs[rk] = mine; else w.acc[r] = mine; }
                     else epilogue<EPI, HALO>(a, r, mine);
                 }
                 k = knext;
@@ -1297,7 +1311,8 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
         } else {
         int k = tid / G;
         while (k < nr) {
-            const int p0 = ts[k], p1 = te[k];
+            const int rk = w.ord ? w.ord[r0 + k] : k;
+            const int p0 = ts[rk], p1 = te[rk];
             const int a0 = p0 & ~3;
             const int nq = (p1 - a0 + 3) >> 2;
             double sum = 0.0;
@@ -1330,9 +1345,9 @@ __global__ __launch_bounds__(XL_BLOCK) void k_csr_xlds(const SpmvArgs a, const X
             sum = group_sum<G>(sum);
             int nk = 0;
             if (l == 0) {
-                const int r = r0 + k;
-                if (t > 0) sum = (w.acc_lds ? accs[k] : w.acc[r]) + sum;
-                if (t < T - 1) { if (w.acc_lds) accs[k] = sum; else w.acc[r] = sum; }
+                const int r = r0 + rk;
+                if (t > 0) sum = (w.acc_lds ? accs[rk] : w.acc[r]) + sum;
+                if (t < T - 1) { if (w.acc_lds) accs[rk] = sum; else w.acc[r] = sum; }
                 else epilogue<EPI, HALO>(a, r, sum);
                 nk = atomicAdd(&next_row, 1);
             }

@@ -195,6 +195,7 @@ struct CsrPart {
     int4           *xl_info = nullptr;
     double         *xl_acc = nullptr;
     int             xl_nblk = 0, xl_maxt = 1;
+    int            *xl_ord = nullptr;      // [M] or nullptr: per chunk, the order its rows are taken in (longest first where a chunk holds long rows)
     int             xl_win = 0;            // columns per window of x in LDS: XL_MAX, or less where the chunks' partial row sums live in LDS behind the window
     bool            xl_acc_lds = false;
     std::vector<int>  xl_blk_h;            // host copies of the chunk plan (k_sellx is built on top of it)
@@ -203,8 +204,8 @@ struct CsrPart {
     bool            xl_ok = false;
     char            xl_tried = 0;
     void free_xlds() {
-        hipFree(xl_col); hipFree(xl_blk); hipFree(xl_tab); hipFree(xl_info); hipFree(xl_acc);
-        xl_col = nullptr; xl_blk = xl_tab = nullptr; xl_info = nullptr; xl_acc = nullptr; xl_ok = false; xl_tried = 0;
+        hipFree(xl_col); hipFree(xl_blk); hipFree(xl_tab); hipFree(xl_info); hipFree(xl_acc); hipFree(xl_ord);
+        xl_col = nullptr; xl_blk = xl_tab = xl_ord = nullptr; xl_info = nullptr; xl_acc = nullptr; xl_ok = false; xl_tried = 0;
     }
     // k_sellp with a lane per two rows (variant 14, k_sellp2): the values row-paired in slices of 128 rows; shares sp_pat / sp_tab
     double         *sp2_val = nullptr;
@@ -609,6 +610,25 @@ int build_xlds(CsrPart &P) {
         if (tabsz > INT32_MAX / 2) return SGPU_OK;
     }
     P.xl_win = win; P.xl_acc_lds = acc_lds;
+    // Longest rows first in the chunks that hold rows of more than 8x the chunk's mean length (BASELINE configs[4]: hub rows of 3 000
+    // entries among rows of 34): a group that STARTS such a row last is the tail of its workgroup, and that workgroup the tail of the
+    // launch.  A stable sort by length, descending, of the chunk's rows; other chunks keep the natural order (no array at all when no
+    // chunk qualifies).  Same sums: only the order in which rows are picked up changes.
+    if (!std::getenv("SAENA_XLDS_NATURAL_ORDER")) {
+        std::vector<int> ord;
+        for (int b = 0; b < nb; ++b) {
+            const int r0 = blk[b], rows = blk[b + 1] - r0;
+            if (rows < 2) continue;
+            int longest = 0;
+            for (int r = r0; r < r0 + rows; ++r) longest = std::max(longest, P.h_rp[r + 1] - P.h_rp[r]);
+            const double mean = (double)(P.h_rp[r0 + rows] - P.h_rp[r0]) / rows;
+            if ((double)longest <= 8.0 * std::max(mean, 1.0)) continue;
+            if (ord.empty()) { ord.resize((size_t)M); for (int c = 0; c < nb; ++c) for (int r = blk[c]; r < blk[c + 1]; ++r) ord[(size_t)r] = r - blk[c]; }
+            std::stable_sort(ord.begin() + r0, ord.begin() + r0 + rows, [&](int x, int y) {
+                return P.h_rp[r0 + x + 1] - P.h_rp[r0 + x] > P.h_rp[r0 + y + 1] - P.h_rp[r0 + y]; });
+        }
+        if (!ord.empty()) CHK(dev_upload(&P.xl_ord, ord.data(), ord.size()));
+    }
     P.xl_piece = (double)P.nnz / (double)std::max<int64_t>(1, pieces);    // mean entries per (row, window): the autotune wants >= 24
     P.xl_blk_h = blk; P.xl_info_h = info;
     CHK(dev_upload(&P.xl_blk, blk.data(), blk.size()));
@@ -1614,7 +1634,7 @@ int launch_part(const CsrPart &P, int epi, const double *x, double *y, const Epi
         a.blk_row = P.xl_blk; a.nblk = P.xl_nblk; a.ccol = P.xl_col;
         sk::XldsArgs w;
         w.info = P.xl_info; w.tab = P.xl_tab; w.acc = P.xl_acc; w.ncols = P.ncols;
-        w.win = P.xl_win; w.acc_lds = P.xl_acc_lds ? 1 : 0;
+        w.win = P.xl_win; w.acc_lds = P.xl_acc_lds ? 1 : 0; w.ord = P.xl_ord;
         SGPU_LAUNCH(P.variant == 16 ? pick_xldsr(epi, P.lanes, halo) : pick_xlds(epi, P.lanes, halo), dim3(P.xl_nblk), dim3(sk::XL_BLOCK), 0, g.cs, a, w);
     } else if (P.variant == 11) {                                 // sliced ELLPACK values + row patterns, a lane per row
         if (!P.sp_ok || !P.sl_val) return fail(SGPU_ERR_STATE, "the row-pattern form was not built");

@@ -314,6 +314,46 @@ def test_sliced_ellpack_with_rows_sorted_by_length(capi, M, N, lengths, monkeypa
     assert np.all(np.abs(dy.download() - A.matvec(x)) <= TOL_SPMV * abs_bound(entries, M, x) + 1e-300)
 
 
+@pytest.mark.parametrize("acc", ["lds", "global"])
+def test_x_in_lds_longest_rows_first_over_several_windows(capi, acc, monkeypatch):
+    """k_csr_xlds / k_csr_xldsr with a chunk's rows taken LONGEST FIRST (round 4: chunks that hold rows of more than 8x their mean
+    length -- hub rows of an irregular operator) on rows that reach over three column windows: the permutation, the partial sums
+    carried between windows (in LDS or in global memory) and the epilogues all go by the row, not by the position it is taken at;
+    SAENA_XLDS_NATURAL_ORDER=1 gives the same sums bit for bit (the order rows are picked up in changes nothing else)."""
+    if acc == "global":
+        monkeypatch.setenv("SAENA_XLDS_GLOBAL_ACC", "1")
+    M = N = 70000
+    rng = np.random.default_rng(9)
+    r = np.repeat(np.arange(M), 24)
+    c = (r + np.tile(np.concatenate([k * 23000 + np.arange(8) for k in range(3)]), M)) % N
+    hubs = np.arange(5, M, 997)                                    # a hub row every 997 rows: 1 500 entries over the same three windows
+    hr = np.repeat(hubs, 1500)
+    hc = (hr + np.tile(np.concatenate([k * 23000 + np.arange(500) for k in range(3)]), len(hubs))) % N
+    key = np.unique(np.concatenate([r.astype(np.int64) * N + c, hr.astype(np.int64) * N + hc]))
+    rows, cols = (key // N).astype(np.int32), (key % N).astype(np.int32)
+    entries = orc.coo_from_arrays(rows, cols, np.sin(0.37 * rows + 0.11 * cols) + (rows == cols) * 400.0)
+    A = orc.OracleOp(entries, M, M, orc.split_even(M, 1))
+    x, rhs = inputs.v2(M), inputs.rhs2(M)
+    bound = abs_bound(entries, M, x)
+    dx, dy, dr = capi.DeviceVector(M, x), capi.DeviceVector(M), capi.DeviceVector(M, rhs)
+    got = {}
+    for order in ("longest-first", "natural"):
+        if order == "natural":
+            monkeypatch.setenv("SAENA_XLDS_NATURAL_ORDER", "1")
+        G = util.gpu_operator(A)
+        for variant, lanes in ((10, 8), (16, 8), (16, 16)):
+            G.set_variant(variant); G.set_lanes_per_row(lanes)
+            G.spmv(dx, dy)
+            y = dy.download()
+            assert np.all(np.abs(y - A.matvec(x)) <= TOL_SPMV * bound + 1e-300), (order, variant, lanes)
+            if order == "natural":
+                np.testing.assert_array_equal(y, got[(variant, lanes)])
+            got[(variant, lanes)] = y
+            du = capi.DeviceVector(M, x)
+            G.jacobi(2, du, dr)
+            assert rel(du.download(), A.jacobi(2, x, rhs)) <= TOL_SMOOTH, (order, variant, lanes)
+
+
 def _transfer_like_operator(M, seed):
     """a prolongation-like M x M/2 operator of a structured grid: row r reads a few runs of columns that start at r // 2 (its
     aggregate) -- the same runs for rows of the same parity class, so the rows repeat a handful of patterns RELATIVE TO THEIR FIRST
